@@ -1,0 +1,127 @@
+"""Synthetic mesh graphs of the reference's dataset shapes (datasets are not shipped with the reference:
+``data/*/input`` is empty).  Pure host-side tensor construction, no kernels.
+
+``grid_graph`` builds a triangulated nx x ny grid the way ``FlagModel.build_graph`` sees a flag_simple frame
+(/root/reference src/model/flag.py:65-128): 5-dim node features (velocity(3) + one-hot type(2)), two-way mesh
+edges from the triangle rule of src/util.py:50-70, 7-dim edge features (relative world pos(3) + norm +
+relative mesh pos(2) + norm).  Optional extras mirror the edge sets the remote-message-passing and
+graph-balancer layers emit (hierarchical_connector.py:85-137, abstract_graph_balancer.py:48-63).
+"""
+import collections
+
+import torch
+
+EdgeSet = collections.namedtuple('EdgeSet', ['name', 'features', 'senders', 'receivers'])
+MultiGraph = collections.namedtuple('MultiGraph', ['node_features', 'edge_sets'])
+
+
+def grid_triangles(nx: int, ny: int) -> torch.Tensor:
+    ii, jj = torch.meshgrid(torch.arange(nx - 1), torch.arange(ny - 1), indexing='ij')
+    a = (ii * ny + jj).flatten()
+    b = a + 1
+    c = a + ny
+    d = c + 1
+    return torch.cat([torch.stack([a, b, d], 1), torch.stack([a, d, c], 1)], 0)
+
+
+def two_way_edges(faces: torch.Tensor):
+    """Unique undirected edges of the triangles, then both directions (src/util.py:50-70 semantics)."""
+    e = torch.cat([faces[:, 0:2], faces[:, 1:3], torch.stack([faces[:, 2], faces[:, 0]], 1)], 0)
+    lo, hi = e.min(1).values, e.max(1).values
+    uniq = torch.unique(torch.stack([hi, lo], 1), dim=0)
+    s, r = uniq[:, 0].long(), uniq[:, 1].long()
+    return torch.cat([s, r]), torch.cat([r, s])
+
+
+def _rel_features(pos_w, pos_m, s, r):
+    rw = pos_w[s] - pos_w[r]
+    rm = pos_m[s] - pos_m[r]
+    return torch.cat([rw, rw.norm(dim=-1, keepdim=True), rm, rm.norm(dim=-1, keepdim=True)], -1)
+
+
+def grid_graph(seed: int = 0, nx: int = 40, ny: int = 40, clusters: int = 0, balance: int = 0, world: int = 0,
+               normalise: bool = True, dtype=torch.float32) -> MultiGraph:
+    g = torch.Generator().manual_seed(seed)
+    N = nx * ny
+    xs = torch.linspace(0, 3, nx)
+    ys = torch.linspace(0, 2, ny)
+    mesh_pos = torch.stack(torch.meshgrid(xs, ys, indexing='ij'), -1).reshape(N, 2)
+    world_pos = torch.cat([mesh_pos, 0.1 * torch.randn(N, 1, generator=g)], -1)
+    prev = world_pos + 0.01 * torch.randn(N, 3, generator=g)
+    node_type = torch.zeros(N, dtype=torch.long)
+    node_type[:3] = 1                                    # HANDLE nodes -> one-hot column 1 (flag.py:72-73)
+    node_feat = torch.cat([world_pos - prev, torch.nn.functional.one_hot(node_type, 2).float()], -1)
+    s, r = two_way_edges(grid_triangles(nx, ny))
+    mesh_feat = _rel_features(world_pos, mesh_pos, s, r)
+
+    def norm(x):
+        if not normalise:
+            return x
+        return (x - x.mean(0)) / x.std(0).clamp(min=1e-8)
+
+    sets = [EdgeSet('mesh_edges', norm(mesh_feat).to(dtype), s, r)]
+    nodes = [norm(node_feat).to(dtype)]
+    if balance:
+        bs = torch.randint(0, N, (balance,), generator=g)
+        br = (bs + 1 + torch.randint(0, N - 1, (balance,), generator=g)) % N
+        s2, r2 = torch.cat([bs, br]), torch.cat([br, bs])
+        sets.append(EdgeSet('balance', norm(_rel_features(world_pos, mesh_pos, s2, r2)).to(dtype), s2, r2))
+    if world:
+        ws = torch.randint(0, N, (world,), generator=g)
+        wr = (ws + 1 + torch.randint(0, N - 1, (world,), generator=g)) % N
+        s2, r2 = torch.cat([ws, wr]), torch.cat([wr, ws])
+        rw = world_pos[s2] - world_pos[r2]
+        sets.append(EdgeSet('world_edges', norm(torch.cat([rw, rw.norm(dim=-1, keepdim=True)], -1)).to(dtype),
+                            s2, r2))
+    if clusters:
+        K = clusters
+        # contiguous blocks along x, like a spectral clustering of a strip would give
+        lab = torch.div(torch.arange(N) // ny * K, nx, rounding_mode='floor').clamp(max=K - 1)
+        pos5 = torch.cat([world_pos, mesh_pos], -1)
+        cm = torch.stack([pos5[lab == c].mean(0) for c in range(K)])
+        nf = torch.stack([node_feat[lab == c].mean(0) for c in range(K)])
+        extra = torch.stack([torch.stack([(lab == c).sum().float(),
+                                          (pos5[lab == c][:, 3:] - cm[c, 3:]).norm(dim=-1).max(),
+                                          (pos5[lab == c][:, :3] - cm[c, :3]).norm(dim=-1).max()])
+                             for c in range(K)])
+        nodes.append(norm(torch.cat([nf, extra], -1)).to(dtype))
+        ids = torch.arange(N)
+        hyp = N + lab
+
+        def rel5(a, b):
+            d = a - b
+            return torch.cat([d[:, :3], d[:, :3].norm(dim=-1, keepdim=True), d[:, 3:],
+                              d[:, 3:].norm(dim=-1, keepdim=True)], -1)
+        down = EdgeSet('intra_cluster_to_mesh', norm(rel5(cm[lab], pos5)).to(dtype), hyp, ids)
+        up = EdgeSet('intra_cluster_to_cluster', norm(rel5(pos5, cm[lab])).to(dtype), ids, hyp)
+        a = torch.arange(K - 1)
+        cs, cr = torch.cat([a, a + 1]), torch.cat([a + 1, a])
+        if K > 3:                                        # one skip connection so degrees differ
+            cs, cr = torch.cat([cs, torch.tensor([0, K - 1])]), torch.cat([cr, torch.tensor([K - 1, 0])])
+        inter = EdgeSet('inter_cluster', norm(rel5(cm[cs], cm[cr])).to(dtype), N + cs, N + cr)
+        sets += [down, up, inter]
+    return MultiGraph(nodes, sets)
+
+
+def batch(graphs) -> MultiGraph:
+    """Disjoint union with the *correct* hyper-node id mapping: mesh rows of all graphs
+    first, then hyper rows of all graphs."""
+    B = len(graphs)
+    n_mesh = [g.node_features[0].shape[0] for g in graphs]
+    has_h = len(graphs[0].node_features) > 1
+    n_hyp = [g.node_features[1].shape[0] if has_h else 0 for g in graphs]
+    mesh_off = [sum(n_mesh[:i]) for i in range(B)]
+    hyp_off = [sum(n_mesh) + sum(n_hyp[:i]) for i in range(B)]
+    names = [e.name for e in graphs[0].edge_sets]
+    out = []
+    for k, name in enumerate(names):
+        fs, ss, rs = [], [], []
+        for i, g in enumerate(graphs):
+            e = g.edge_sets[k]
+
+            def remap(idx):
+                return torch.where(idx < n_mesh[i], idx + mesh_off[i], idx - n_mesh[i] + hyp_off[i])
+            fs.append(e.features); ss.append(remap(e.senders)); rs.append(remap(e.receivers))
+        out.append(EdgeSet(name, torch.cat(fs), torch.cat(ss), torch.cat(rs)))
+    nodes = [torch.cat([g.node_features[j] for g in graphs]) for j in range(len(graphs[0].node_features))]
+    return MultiGraph(nodes, out)

@@ -1,0 +1,190 @@
+"""Generate golden vectors by running the REFERENCE itself (imported from /root/reference) on CPU.
+
+Run in the build container only (the reference never travels):
+
+    cd /root/reference && PYTHONDONTWRITEBYTECODE=1 PYTHONHASHSEED=0 \
+      PYTHONPATH=/root/repo/tools/oracle_shims:/root/reference \
+      python /root/repo/tools/gen_golden.py --out /root/repo/tests/golden
+
+What is stored is data only: inputs, weights (reference key names), outputs, losses, gradients.
+The third-party torch_scatter wheel is replaced by tools/oracle_shims/torch_scatter (restated semantics).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from oracle import mgn_oracle as O            # only for init_state_dict / synthetic inputs (build-owned code)
+from tests import synth                        # build-owned synthetic graph generator
+
+from src.migration.meshgraphnet import MeshGraphNet          # noqa: E402  (the reference)
+from src.migration.normalizer import Normalizer              # noqa: E402
+from src.algorithms.MeshSimulator import MeshSimulator       # noqa: E402
+from src import util as ref_util                             # noqa: E402
+
+
+def to_ref_graph(g):
+    return ref_util.MultiGraph([x.clone() for x in g.node_features],
+                               [ref_util.EdgeSet(e.name, e.features.clone(), e.senders.clone(), e.receivers.clone())
+                                for e in g.edge_sets])
+
+
+def run_model(arch, agg, steps, edge_sets, graph, latent, seed, out_size=3, weights='reference'):
+    torch.manual_seed(seed)
+    model = MeshGraphNet(output_size=out_size, latent_size=latent, num_layers=2, message_passing_aggregator=agg,
+                         message_passing_steps=steps, architecture=arch, edge_sets=list(edge_sets))
+    with torch.no_grad():
+        model(to_ref_graph(graph))                      # materialise the lazy layers (reference init)
+    if weights != 'reference':
+        # deterministic build-owned init with reference key names, so the fixture need not store 1e6 floats
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = O.init_state_dict_like(shapes, seed)
+        model.load_state_dict(sd)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = to_ref_graph(graph)
+    nf = [x.requires_grad_(True) for x in g.node_features]
+    es = [e._replace(features=e.features.requires_grad_(True)) for e in g.edge_sets]
+    out = model(ref_util.MultiGraph(nf, es))
+    target = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed + 7))
+    mask = torch.ones(out.shape[0], dtype=torch.bool)
+    mask[:3] = False
+    loss = torch.nn.functional.mse_loss(target[mask], out[mask])
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+             for k, p in model.named_parameters()}   # unused params (e.g. last block's hyper update) -> 0
+    in_grads = {'node': [x.grad.detach().clone() for x in nf],
+                'edge': {e.name: (e.features.grad.detach().clone() if e.features.grad is not None else None)
+                         for e in es}}
+    return sd, out.detach().clone(), target, mask, loss.detach().clone(), grads, in_grads
+
+
+def digest(grads, seed):
+    """Compact, order-sensitive summary of large gradient tensors: 4 fixed random projections + norms."""
+    d = {}
+    for k, g in grads.items():
+        gen = torch.Generator().manual_seed(seed + (hash_name(k) % 100003))
+        R = torch.randn((4,) + tuple(g.shape), generator=gen, dtype=torch.float64)
+        d[k] = {'proj': (R * g.double()).flatten(1).sum(1), 'l2': g.double().norm(), 'sum': g.double().sum()}
+    return d
+
+
+def hash_name(s):
+    h = 0
+    for c in s:
+        h = (h * 131 + ord(c)) % (1 << 31)
+    return h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', required=True)
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(4)
+
+    # ---- G1: unsorted_segment_operation ---------------------------------------------------------------
+    gen = torch.Generator().manual_seed(1)
+    E, N, D = 97, 23, 128
+    ids = torch.randint(0, N, (E,), generator=gen)
+    ids[ids == 5] = 6                     # segment 5 empty
+    ids[ids == 22] = 0                    # last segment empty
+    data2 = torch.randn(E, D, generator=gen)
+    data2[10] = data2[3]                  # exact ties inside segments
+    ids[10] = ids[3]
+    data1 = torch.randn(E, generator=gen)
+    g1 = {'ids': ids, 'data2': data2, 'data1': data1, 'num_segments': N, 'out': {}}
+    for op in ('sum', 'mean', 'max', 'min'):
+        for nm, dat in (('2d', data2), ('1d', data1)):
+            x = dat.clone().requires_grad_(True)
+            y = ref_util.unsorted_segment_operation(x, ids, N, op)
+            w = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+            (y * w).sum().backward()
+            g1['out'][f'{op}_{nm}'] = {'y': y.detach().clone(), 'w': w, 'gx': x.grad.clone()}
+    torch.save(g1, os.path.join(a.out, 'g1_segment_ops.pt'))
+
+    # ---- G2-G4: model-level goldens ---------------------------------------------------------------------
+    set_order = list({'mesh_edges', 'world_edges'})      # iteration order under this PYTHONHASHSEED
+    set_order_h = list({'inter_cluster', 'inter_cluster_world'})
+    hyper_sets = ['mesh_edges', 'intra_cluster_to_mesh', 'intra_cluster_to_cluster', 'inter_cluster']
+    cases = [
+        # name, arch, agg, steps, edge_sets, graph kwargs, latent, weights
+        ('none_sum_L2_lat16', 'none', 'sum', 2, ['mesh_edges'], dict(nx=6, ny=5), 16, 'reference'),
+        ('none_pna_L2_lat16', 'none', 'pna', 2, ['mesh_edges'], dict(nx=6, ny=5), 16, 'reference'),
+        ('none_max_L1_lat16', 'none', 'max', 1, ['mesh_edges'], dict(nx=6, ny=5), 16, 'reference'),
+        ('none_min_L1_lat16', 'none', 'min', 1, ['mesh_edges'], dict(nx=6, ny=5), 16, 'reference'),
+        ('none_mean_L1_lat16', 'none', 'mean', 1, ['mesh_edges'], dict(nx=6, ny=5), 16, 'reference'),
+        ('none_pna_S2_L2_lat16', 'none', 'pna', 2, ['mesh_edges', 'balance'], dict(nx=6, ny=5, balance=11), 16,
+         'reference'),
+        ('multi_sum_L1_lat16', 'multi', 'sum', 1, ['mesh_edges'], dict(nx=6, ny=5), 16, 'reference'),
+        ('repeated_sum_L2_lat16', 'repeated', 'sum', 2, ['mesh_edges'], dict(nx=6, ny=5), 16, 'reference'),
+        ('hyper_pna_L2_lat16', 'hyper', 'pna', 2, hyper_sets, dict(nx=8, ny=8, clusters=4), 16, 'reference'),
+        ('hyper_sum_world_L1_lat16', 'hyper', 'sum', 1, hyper_sets + ['world_edges'],
+         dict(nx=8, ny=8, clusters=4, world=17), 16, 'reference'),
+        ('hetero_pna_L2_lat16', 'hetero', 'pna', 2, hyper_sets + ['world_edges'],
+         dict(nx=8, ny=8, clusters=4, world=17), 16, 'reference'),
+        ('multiscale_sum_L1_lat16', 'multiscale', 'sum', 1, hyper_sets, dict(nx=8, ny=8, clusters=4), 16,
+         'reference'),
+        # latent-128 goldens for the GPU parity tests: weights from the build-owned seeded init, grads as digests
+        ('none_sum_L2_lat128', 'none', 'sum', 2, ['mesh_edges'], dict(nx=10, ny=10), 128, 'seeded'),
+        ('none_pna_L1_lat128', 'none', 'pna', 1, ['mesh_edges'], dict(nx=10, ny=10), 128, 'seeded'),
+        ('hyper_pna_L1_lat128', 'hyper', 'pna', 1, hyper_sets, dict(nx=10, ny=10, clusters=5), 128, 'seeded'),
+        ('none_sum_L15_lat128', 'none', 'sum', 15, ['mesh_edges'], dict(nx=10, ny=10), 128, 'seeded'),
+    ]
+    for name, arch, agg, steps, sets, gkw, latent, wmode in cases:
+        seed = hash_name(name) % 1000
+        graph = synth.grid_graph(seed=seed, **gkw)
+        # an edge set the model does not register must be dropped by the encoder: add one to a few cases
+        if name.startswith('none_sum_L2'):
+            extra = O.EdgeSet('unregistered', torch.randn(5, 4), torch.zeros(5, dtype=torch.long),
+                              torch.ones(5, dtype=torch.long))
+            graph = O.MultiGraph(graph.node_features, list(graph.edge_sets) + [extra])
+        sd, out, target, mask, loss, grads, in_grads = run_model(arch, agg, steps, sets, graph, latent, seed,
+                                                                 weights=wmode)
+        fx = {'arch': arch, 'agg': agg, 'steps': steps, 'edge_sets': sets, 'latent': latent, 'seed': seed,
+              'graph_kwargs': gkw, 'set_order': set_order, 'set_order_hyper': set_order_h,
+              'graph': {'node_features': graph.node_features,
+                        'edge_sets': [(e.name, e.features, e.senders, e.receivers) for e in graph.edge_sets]},
+              'out': out, 'target': target, 'mask': mask, 'loss': loss, 'weights': wmode}
+        if wmode == 'reference':
+            fx['state_dict'] = sd
+            fx['grads'] = grads
+            fx['in_grads'] = in_grads
+        else:
+            fx['shapes'] = {k: tuple(v.shape) for k, v in sd.items()}
+            fx['grad_digest'] = digest(grads, seed)
+            fx['in_grads'] = in_grads
+        torch.save(fx, os.path.join(a.out, f'mgn_{name}.pt'))
+        print(name, 'loss', float(loss), 'out', tuple(out.shape), 'params', sum(v.numel() for v in sd.values()))
+
+    # ---- G6: MeshSimulator._get_batched index mapping ---------------------------------------------------
+    g6 = {}
+    for B in (1, 2, 3):
+        graphs = [synth.grid_graph(seed=40 + i, nx=3, ny=3, clusters=2) for i in range(B)]
+        data = [(to_ref_graph(g), {'x': torch.zeros(1)}) for g in graphs]
+        batched = MeshSimulator._get_batched(data, B)[0][0]
+        g6[B] = {'in': [{'n': [x.shape[0] for x in g.node_features],
+                         'sets': [(e.name, e.senders, e.receivers) for e in g.edge_sets]} for g in graphs],
+                 'out': [(e.name, e.senders, e.receivers) for e in batched.edge_sets],
+                 'n_out': [x.shape[0] for x in batched.node_features]}
+    torch.save(g6, os.path.join(a.out, 'g6_get_batched.pt'))
+
+    # ---- G7: Normalizer ---------------------------------------------------------------------------------
+    gen = torch.Generator().manual_seed(9)
+    nz = Normalizer(size=5, name='t')
+    xs = [torch.randn(n, 5, generator=gen) * 3 + 1 for n in (7, 13, 4)]
+    ys = [nz(x, True).clone() for x in xs]
+    y_eval = nz(xs[0], False).clone()
+    inv = nz.inverse(ys[0]).clone()
+    nz2 = Normalizer(size=2, name='u', max_accumulations=2)
+    zs = [torch.randn(6, 2, generator=gen) for _ in range(4)]
+    ws = [nz2(z).clone() for z in zs]
+    torch.save({'xs': xs, 'ys': ys, 'y_eval': y_eval, 'inv': inv, 'acc_sum': nz._acc_sum.clone(),
+                'acc_sum_sq': nz._acc_sum_squared.clone(), 'acc_count': nz._acc_count.clone(),
+                'zs': zs, 'ws': ws}, os.path.join(a.out, 'g7_normalizer.pt'))
+    print('done')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,1 @@
+"""Import-only stub (test tooling)."""
