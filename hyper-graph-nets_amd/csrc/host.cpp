@@ -1,0 +1,80 @@
+// Error reporting, version, and the optional HIP-event profiler of libhgn_mp.so.
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "hgn_host.h"
+
+namespace hgn {
+
+static thread_local char g_err[512] = "";
+
+int hgn_fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int hgn_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return HGN_E_LAUNCH;
+  }
+  return HGN_OK;
+}
+
+struct ProfRec { int kid; double units; hipEvent_t a, b; };
+static std::mutex g_mu;
+static bool g_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+
+ProfScope::ProfScope(int kernel_id, double units, hipStream_t s) : kid(kernel_id), stream(s), on(false), slot(-1) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_on) return;
+  ProfRec r;
+  r.kid = kernel_id; r.units = units;
+  if (!g_pool.empty()) { r.a = g_pool.back().first; r.b = g_pool.back().second; g_pool.pop_back(); }
+  else { if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return; }
+  hipEventRecord(r.a, stream);
+  g_recs.push_back(r);
+  slot = (int)g_recs.size() - 1;
+  on = true;
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (slot >= 0 && slot < (int)g_recs.size()) hipEventRecord(g_recs[slot].b, stream);
+}
+
+}  // namespace hgn
+
+using namespace hgn;
+
+extern "C" const char* hgn_last_error(void) { return g_err; }
+extern "C" int hgn_version(void) { return 100; }
+
+extern "C" int hgn_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_on = on != 0;
+  return HGN_OK;
+}
+extern "C" int hgn_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& r : g_recs) g_pool.push_back({r.a, r.b});
+  g_recs.clear();
+  return HGN_OK;
+}
+extern "C" int hgn_prof_collect(double* total_ms, int64_t* count, double* units) {
+  if (!total_ms || !count || !units) return hgn_fail(HGN_E_INVALID, "hgn_prof_collect: null output");
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < HGN_NUM_KERNEL_IDS; ++i) { total_ms[i] = 0; count[i] = 0; units[i] = 0; }
+  for (auto& r : g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return hgn_fail(HGN_E_LAUNCH, "hgn_prof_collect: event sync failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return hgn_fail(HGN_E_LAUNCH, "hgn_prof_collect: elapsed failed");
+    if (r.kid >= 0 && r.kid < HGN_NUM_KERNEL_IDS) { total_ms[r.kid] += ms; count[r.kid] += 1; units[r.kid] += r.units; }
+  }
+  return HGN_OK;
+}

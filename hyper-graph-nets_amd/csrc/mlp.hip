@@ -1,0 +1,304 @@
+// Fused 3-layer MLP kernels of the message-passing path (forward, data-gradient backward, single Linear).
+// See hgn_device.h for the register-chained transposed-MFMA formulation and include/hgn_mp.h for the ABI.
+#include "hgn_device.h"
+#include "hgn_host.h"
+
+namespace hgn {
+
+__device__ __forceinline__ void relu_inplace(f32x16 (&a)[4]) {
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[ob][s] = fmaxf(a[ob][s], 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward:  out = [res +] [LN]( W3 relu(W2 relu(z1) + b2) + b3 )
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG, 2) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
+  __shared__ float wlds[128 * LDW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  const float* wl_n = wlds + m * LDW + 4 * h;
+
+  f32x16 acc[4], b[4];
+  // ---- layer 1 ------------------------------------------------------------------------------------------
+  c_load(acc, a.b1, h);
+  for (int i = 0; i < a.n_add; ++i) c_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, h);
+  for (int si = 0; si < a.n_src; ++si) {
+    const hgn_src_t s = a.src[si];
+    const long srow = s.idx ? (long)s.idx[rc] : rc;
+    const bool vec = ((s.ld & 3) == 0) && ((s.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
+    for (int k0 = 0; k0 < s.K; k0 += 128) {
+      const int kw = min(128, s.K - k0);
+      const int ncb = (kw + 31) >> 5;
+      __syncthreads();
+      stage_weight(wlds, s.W + k0, a.ldw1, 128, kw, 128, 32 * ncb);
+      __syncthreads();
+      load_bfrag(b, s.x + srow * s.ld + k0, kw, h, vec);
+      mfma_stage<false>(acc, b, wl_n, 4, ncb);
+    }
+  }
+  relu_inplace(acc);
+  if (a.z1 && valid) c_store(acc, a.z1 + row * LAT, h);
+  // ---- layer 2 ------------------------------------------------------------------------------------------
+  __syncthreads();
+  stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
+  __syncthreads();
+  c_load(b, a.b2, h);
+  mfma_stage<false>(b, acc, wl_n, 4, 4);      // b now holds layer-2 pre-activations
+  relu_inplace(b);
+  if (a.z2 && valid) c_store(b, a.z2 + row * LAT, h);
+  // ---- layer 3 ------------------------------------------------------------------------------------------
+  const int nob = (a.out_w + 31) >> 5;
+  __syncthreads();
+  stage_weight(wlds, a.W3, LAT, a.out_w, 128, 32 * nob, 128);
+  __syncthreads();
+  if (a.out_w == LAT) c_load(acc, a.b3, h); else c_load_masked(acc, a.b3, h, a.out_w);
+  mfma_stage<false>(acc, b, wl_n, nob, 4);
+  // ---- LayerNorm (eps 1e-5, biased variance: torch.nn.LayerNorm) + residual -------------------------------
+  if (a.ln_g) {
+    const float mean = row_sum(acc) * (1.f / LAT);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { acc[ob][s] -= mean; b[ob][s] = acc[ob][s] * acc[ob][s]; }
+    const float var = row_sum(b) * (1.f / LAT);
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc[ob][s] *= rstd;
+    if (a.xhat && valid) c_store(acc, a.xhat + row * LAT, h);
+    if (a.rstd && valid && h == 0) a.rstd[row] = rstd;
+    HGN_FOR_C(ob, g) {
+      const int col = 32 * ob + 8 * g + 4 * h;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + col);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + col);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[ob][4 * g + u] = acc[ob][4 * g + u] * gm[u] + bt[u];
+    }
+  }
+  if (valid) {
+    if (a.out_w == LAT && (a.ld_out & 3) == 0) {
+      if (a.res) c_add(acc, a.res + row * a.ld_res, h);
+      c_store(acc, a.out + row * a.ld_out, h);
+    } else {
+      if (a.res) {
+        c_load_masked(b, a.res + row * a.ld_res, h, a.out_w);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int s = 0; s < 16; ++s) acc[ob][s] += b[ob][s];
+      }
+      c_store_masked(acc, a.out + row * a.ld_out, h, a.out_w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward (data gradients)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void relu_mask(f32x16 (&g)[4], const float* __restrict__ zrow, int h) {
+  HGN_FOR_C(ob, q) {
+    const f32x4 z = *reinterpret_cast<const f32x4*>(zrow + 32 * ob + 8 * q + 4 * h);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[ob][4 * q + u] = z[u] > 0.f ? g[ob][4 * q + u] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(WG, 2) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
+  __shared__ float wlds[128 * LDW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  const float* wl_t = wlds + 4 * h * LDW + m;
+
+  f32x16 g[4], t[4];
+  const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
+  if (vec_out) c_load(g, a.d_out + rc * a.ld_dout, h); else c_load_masked(g, a.d_out + rc * a.ld_dout, h, a.out_w);
+  if (a.ln_g) {
+    // y = xhat*gamma + beta ;  dz3 = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat))
+    c_load(t, a.xhat + rc * LAT, h);
+    HGN_FOR_C(ob, q) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 32 * ob + 8 * q + 4 * h);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[ob][4 * q + u] *= gm[u];
+    }
+    const float m1 = row_sum(g) * (1.f / LAT);
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      p0 += g[0][s] * t[0][s]; p1 += g[1][s] * t[1][s]; p2 += g[2][s] * t[2][s]; p3 += g[3][s] * t[3][s];
+    }
+    float pp = (p0 + p1) + (p2 + p3);
+    pp += __shfl_xor(pp, 32);
+    const float m2 = pp * (1.f / LAT);
+    const float r = a.rstd[rc];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) g[ob][s] = r * (g[ob][s] - m1 - t[ob][s] * m2);
+  }
+  if (a.dz3 && valid) c_store(g, a.dz3 + row * LAT, h);
+  // ---- dz2 = relu'(z2) * (W3^T dz3) ----------------------------------------------------------------------
+  const int ncb3 = (a.out_w + 31) >> 5;
+  __syncthreads();
+  stage_weight(wlds, a.W3, LAT, a.out_w, 128, 32 * ncb3, 128);
+  __syncthreads();
+  c_zero(t);
+  mfma_stage<true>(t, g, wl_t, 4, ncb3);
+  relu_mask(t, a.z2 + rc * LAT, h);
+  if (a.dz2 && valid) c_store(t, a.dz2 + row * LAT, h);
+  // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
+  __syncthreads();
+  stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
+  __syncthreads();
+  c_zero(g);
+  mfma_stage<true>(g, t, wl_t, 4, 4);
+  relu_mask(g, a.z1 + rc * LAT, h);
+  if (a.dz1 && valid) c_store(g, a.dz1 + row * LAT, h);
+  // ---- dx_src = dz1 * W1[:, cols]  (+ d_out for the residual source) ---------------------------------------
+  for (int di = 0; di < a.n_dx; ++di) {
+    const hgn_dx_t d = a.dx[di];
+    for (int k0 = 0; k0 < d.K; k0 += 128) {
+      const int kw = min(128, d.K - k0);
+      const int nob = (kw + 31) >> 5;
+      __syncthreads();
+      stage_weight(wlds, d.W + k0, a.ldw1, 128, kw, 128, 32 * nob);
+      __syncthreads();
+      c_zero(t);
+      mfma_stage<true>(t, g, wl_t, nob, 4);
+      if (valid) {
+        float* dst = d.dx + row * d.ld + k0;
+        if (kw == 128 && (d.ld & 3) == 0) {
+          if (d.residual) c_add(t, a.d_out + row * a.ld_dout, h);
+          c_store(t, dst, h);
+        } else {
+          c_store_masked(t, dst, h, kw);      // residual sources are always 128 wide (latent)
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// single Linear over 128-wide output blocks (node pre-projection of the split edge layer) and its dgrad
+// ---------------------------------------------------------------------------------------------------------
+struct LinArgs {
+  const float* x; long ldx; long M; const float* W[4]; int n_blocks; long ldw; float* out; long ld_out;
+};
+
+__global__ __launch_bounds__(WG, 2) void linear_fwd_kernel(const LinArgs a) {
+  __shared__ float wlds[128 * LDW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  f32x16 acc[4], b[4];
+  load_bfrag(b, a.x + rc * a.ldx, 128, h, true);
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    __syncthreads();
+    stage_weight(wlds, a.W[blk], a.ldw, 128, 128, 128, 128);
+    __syncthreads();
+    c_zero(acc);
+    mfma_stage<false>(acc, b, wlds + m * LDW + 4 * h, 4, 4);
+    if (valid) c_store(acc, a.out + row * a.ld_out + 128 * blk, h);
+  }
+}
+
+__global__ __launch_bounds__(WG, 2) void linear_bwd_kernel(const LinArgs a) {
+  // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]
+  __shared__ float wlds[128 * LDW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  f32x16 acc[4], b[4];
+  c_zero(acc);
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    __syncthreads();
+    stage_weight(wlds, a.W[blk], a.ldw, 128, 128, 128, 128);
+    __syncthreads();
+    load_bfrag(b, a.x + rc * a.ldx + 128 * blk, 128, h, true);
+    mfma_stage<true>(acc, b, wlds + 4 * h * LDW + m, 4, 4);
+  }
+  if (valid) c_store(acc, a.out + row * a.ld_out, h);
+}
+
+}  // namespace hgn
+
+using namespace hgn;
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
+  if (!a) return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: null args");
+  if (a->M == 0) return HGN_OK;
+  if (a->M < 0 || a->n_src < 0 || a->n_src > HGN_MAX_SRC || a->n_add < 0 || a->n_add > HGN_MAX_ADD)
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: bad counts");
+  if (a->out_w < 1 || a->out_w > 128 || (a->ln_g && a->out_w != 128) || (!a->ln_g != !a->ln_b))
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: bad out_w / LayerNorm");
+  if (!a->b1 || !a->W2 || !a->b2 || !a->W3 || !a->b3 || !a->out)
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: null weight/output pointer");
+  for (int i = 0; i < a->n_src; ++i)
+    if (!a->src[i].x || !a->src[i].W || a->src[i].K < 1) return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: bad source");
+  for (int i = 0; i < a->n_add; ++i)
+    if (!a->add[i].P || !a->add[i].idx || (a->add[i].ld & 3) || !aligned16(a->add[i].P))
+      return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: bad addend");
+  if (a->res && a->out_w == 128 && ((a->ld_res & 3) || !aligned16(a->res)))
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: residual must be 16-byte aligned");
+  const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+  const int kid = a->n_add ? 0 : 1;
+  ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  return hgn_check_launch("hgn_mlp_fwd");
+}
+
+extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
+  if (!a) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: null args");
+  if (a->M == 0) return HGN_OK;
+  if (a->M < 0 || a->n_dx < 0 || a->n_dx > HGN_MAX_SRC) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad counts");
+  if (a->out_w < 1 || a->out_w > 128 || (a->ln_g && (a->out_w != 128 || !a->xhat || !a->rstd)))
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad out_w / LayerNorm");
+  if (!a->d_out || !a->z1 || !a->z2 || !a->W2 || !a->W3) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: null pointer");
+  for (int i = 0; i < a->n_dx; ++i)
+    if (!a->dx[i].W || !a->dx[i].dx || a->dx[i].K < 1 || (a->dx[i].residual && (a->dx[i].K != 128 || a->out_w != 128)))
+      return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad dx request");
+  const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+  const int kid = (a->n_dx == 1 && a->dx[0].residual && a->dz1) ? 2 : 3;
+  ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  return hgn_check_launch("hgn_mlp_bwd");
+}
+
+static int linear_common(bool fwd, const float* x, int64_t ldx, int64_t M, const float* const* Wb, int nb, int64_t ldw,
+                         float* out, int64_t ld_out, void* stream) {
+  if (M == 0) return HGN_OK;
+  if (!x || !Wb || !out || M < 0 || nb < 1 || nb > 4 || (ldx & 3) || (ld_out & 3) || !aligned16(x) || !aligned16(out))
+    return hgn_fail(HGN_E_INVALID, "hgn_linear: bad argument");
+  LinArgs a;
+  a.x = x; a.ldx = ldx; a.M = M; a.n_blocks = nb; a.ldw = ldw; a.out = out; a.ld_out = ld_out;
+  for (int i = 0; i < 4; ++i) a.W[i] = i < nb ? Wb[i] : nullptr;
+  const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+  ProfScope ps(fwd ? 7 : 8, (double)M, (hipStream_t)stream);
+  if (fwd) hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(linear_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  return hgn_check_launch("hgn_linear");
+}
+
+extern "C" int hgn_linear_fwd(const float* x, int64_t ldx, int64_t M, const float* const* Wb, int nb, int64_t ldw,
+                              float* out, int64_t ld_out, void* stream) {
+  return linear_common(true, x, ldx, M, Wb, nb, ldw, out, ld_out, stream);
+}
+extern "C" int hgn_linear_bwd(const float* g, int64_t ldg, int64_t M, const float* const* Wb, int nb, int64_t ldw,
+                              float* dx, int64_t ld_dx, void* stream) {
+  return linear_common(false, g, ldg, M, Wb, nb, ldw, dx, ld_dx, stream);
+}

@@ -1,0 +1,224 @@
+// Weight / bias / LayerNorm-affine gradients of the fused MLPs, plus the flat Adam step.
+//
+// dW[j][k] = sum_i G[i][j] * A[i][k] contracts over ROWS (edges / nodes), so both MFMA operands are read with the
+// lane on the feature axis straight out of row-major LDS tiles (conflict-free ds_read_b32, no transposes):
+//   A-operand lane (m, h): G[2t+h][32*wave + m]      B-operand lane (n, h): A[2t+h][32*kb + n]
+// Each workgroup owns a contiguous chunk of rows and keeps its 32x128 slice-per-wave of dW in accumulators
+// across the whole chunk; chunk partials go to slabs that a second kernel adds in fixed order (deterministic,
+// no float atomics -- MI355X global float atomics run at ~1.3 TB/s and are order dependent).
+#include "hgn_device.h"
+#include "hgn_host.h"
+
+namespace hgn {
+
+constexpr int WT_ROWS = 32;                       // rows per LDS tile
+constexpr int SLAB = 128 * 128 + 128;             // floats per (task, chunk): dW partial + colsum partial
+
+struct WTaskDev {
+  int type; const float* A; long lda; int K; const int* idxA; const float* G; long ldg; float* slab;
+};
+struct WArgs { WTaskDev t[HGN_MAX_WTASK]; long M; long rows_per_chunk; int n_chunks; };
+
+__device__ __forceinline__ void wt_load_tile(float4 (&ra)[4], float4 (&rg)[4], const WTaskDev& t, long row0, long row_end,
+                                             bool vecA) {
+  // thread -> (row = tid>>3, 16-byte column group (tid&7) + 8*q)
+  const int r = threadIdx.x >> 3;
+  const long row = row0 + r;
+  const bool ok = row < row_end;
+  const long arow = ok ? (t.idxA ? (long)t.idxA[row] : row) : 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = ((threadIdx.x & 7) + 8 * q) * 4;
+    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      vg = *reinterpret_cast<const float4*>(t.G + row * t.ldg + c);
+      if (vecA) {
+        if (c < t.K) va = *reinterpret_cast<const float4*>(t.A + arow * t.lda + c);
+      } else {
+        const float* p = t.A + arow * t.lda;
+        va.x = c + 0 < t.K ? p[c + 0] : 0.f; va.y = c + 1 < t.K ? p[c + 1] : 0.f;
+        va.z = c + 2 < t.K ? p[c + 2] : 0.f; va.w = c + 3 < t.K ? p[c + 3] : 0.f;
+      }
+    }
+    ra[q] = va; rg[q] = vg;
+  }
+}
+
+__device__ __forceinline__ void wt_store_tile(float* __restrict__ As, float* __restrict__ Gs, const float4 (&ra)[4],
+                                              const float4 (&rg)[4]) {
+  const int r = threadIdx.x >> 3;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = ((threadIdx.x & 7) + 8 * q) * 4;
+    *reinterpret_cast<float4*>(As + r * 128 + c) = ra[q];
+    *reinterpret_cast<float4*>(Gs + r * 128 + c) = rg[q];
+  }
+}
+
+__global__ __launch_bounds__(WG, 2) void wgrad_kernel(const WArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][WT_ROWS * 128];   // [buf][A|G][32][128]  = 64 KB
+  const WTaskDev t = a.t[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const long row_beg = (long)blockIdx.x * a.rows_per_chunk;
+  const long row_end = min(a.M, row_beg + a.rows_per_chunk);
+  float* slab = t.slab + (long)blockIdx.x * SLAB;
+  const bool vecA = ((t.lda & 3) == 0) && ((t.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(t.A) & 15) == 0);
+  const int ncb = (t.K + 31) >> 5;
+  const int cs_col = threadIdx.x & 127, cs_half = threadIdx.x >> 7;
+
+  f32x16 acc[4];
+  c_zero(acc);
+  float cs0 = 0.f, cs1 = 0.f;       // column sums: type 0: sum G ; type 1: sum G*A (cs0) and sum G (cs1)
+  float4 ra[4], rg[4];
+  if (row_beg < row_end) {
+    wt_load_tile(ra, rg, t, row_beg, row_end, vecA);
+    wt_store_tile(lds[0][0], lds[0][1], ra, rg);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (long r0 = row_beg; r0 < row_end; r0 += WT_ROWS) {
+    const bool more = r0 + WT_ROWS < row_end;
+    if (more) wt_load_tile(ra, rg, t, r0 + WT_ROWS, row_end, vecA);      // in flight during the MFMAs below
+    const float* As = lds[buf][0];
+    const float* Gs = lds[buf][1];
+    if (t.type == 0) {
+#pragma unroll
+      for (int s = 0; s < WT_ROWS / 2; ++s) {
+        const float ga = Gs[(2 * s + h) * 128 + 32 * wave + m];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          if (kb < ncb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, As[(2 * s + h) * 128 + 32 * kb + m], acc[kb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cs0 += Gs[(16 * cs_half + r) * 128 + cs_col];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float g = Gs[(16 * cs_half + r) * 128 + cs_col];
+        cs0 += g * As[(16 * cs_half + r) * 128 + cs_col];
+        cs1 += g;
+      }
+    }
+    if (more) wt_store_tile(lds[buf ^ 1][0], lds[buf ^ 1][1], ra, rg);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // ---- write the chunk partial ---------------------------------------------------------------------------
+  if (t.type == 0) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(32 * wave + rho0(r) + 4 * h) * 128 + 32 * kb + m] = acc[kb][r];
+  }
+  float* red = &lds[0][0][0];
+  __syncthreads();
+  red[threadIdx.x] = cs0;
+  red[256 + threadIdx.x] = cs1;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    if (t.type == 0) slab[128 * 128 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
+    else {
+      slab[threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];                       // dgamma partial
+      slab[128 * 128 + threadIdx.x] = red[256 + threadIdx.x] + red[256 + 128 + threadIdx.x];   // dbeta partial
+    }
+  }
+}
+
+struct RTaskDev { int type; int K; int n_out; float* dW; long ldw; float* db; const float* slab; };
+struct RArgs { RTaskDev t[HGN_MAX_WTASK]; int n_chunks; };
+
+__global__ void wgrad_reduce_kernel(const RArgs a) {
+  const RTaskDev t = a.t[blockIdx.y];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= SLAB) return;
+  const bool is_bias = e >= 128 * 128;
+  const int j = is_bias ? e - 128 * 128 : e >> 7, k = e & 127;
+  if (t.type == 0) {
+    if (j >= t.n_out) return;
+    if (is_bias ? (t.db == nullptr) : (k >= t.K)) return;
+  } else {
+    if (!is_bias && e >= 128) return;
+  }
+  float s = 0.f;
+  for (int c = 0; c < a.n_chunks; ++c) s += t.slab[(long)c * SLAB + e];
+  if (t.type == 0) {
+    if (is_bias) t.db[j] = s; else t.dW[(long)j * t.ldw + k] = s;
+  } else {
+    if (is_bias) { if (t.db) t.db[j] = s; } else t.dW[e] = s;
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, float gscale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;          // torch.optim.Adam: (sqrt(v)/sqrt(bc2)) + eps
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+static int chunks_for(long M, int n_tasks) {
+  long c = (M + 63) / 64;
+  long cap = 768 / (n_tasks > 0 ? n_tasks : 1);
+  if (cap < 32) cap = 32;
+  if (c > cap) c = cap;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+
+}  // namespace hgn
+
+using namespace hgn;
+
+extern "C" int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes) {
+  if (!bytes || M < 0 || n_tasks < 0 || n_tasks > HGN_MAX_WTASK) return hgn_fail(HGN_E_INVALID, "hgn_wgrad_workspace_bytes: bad argument");
+  *bytes = (size_t)chunks_for(M, n_tasks) * (size_t)n_tasks * SLAB * sizeof(float) + 256;
+  return HGN_OK;
+}
+
+extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, void* workspace, size_t ws_bytes,
+                             void* stream) {
+  if (n_tasks == 0) return HGN_OK;
+  size_t need = 0;
+  if (!tasks || hgn_wgrad_workspace_bytes(M, n_tasks, &need) != HGN_OK || !workspace || ws_bytes < need)
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad tasks / workspace too small");
+  const int nch = chunks_for(M, n_tasks);
+  WArgs wa; RArgs ra;
+  wa.M = M; wa.n_chunks = nch; ra.n_chunks = nch;
+  long rpc = (M + nch - 1) / nch;
+  rpc = (rpc + WT_ROWS - 1) / WT_ROWS * WT_ROWS;
+  if (rpc < WT_ROWS) rpc = WT_ROWS;
+  wa.rows_per_chunk = rpc;
+  float* slab = (float*)workspace;
+  for (int i = 0; i < n_tasks; ++i) {
+    const hgn_wtask_t& t = tasks[i];
+    if (!t.A || !t.G || !t.dW || t.K < 1 || t.K > 128 || t.n_out < 1 || t.n_out > 128 || (t.ldg & 3) ||
+        ((uintptr_t)t.G & 15) || (t.type != 0 && t.type != 1))
+      return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad task");
+    wa.t[i] = {t.type, t.A, (long)t.lda, t.K, t.idxA, t.G, (long)t.ldg, slab + (size_t)i * nch * SLAB};
+    ra.t[i] = {t.type, t.K, t.n_out, t.dW, (long)t.ldw, t.db, slab + (size_t)i * nch * SLAB};
+  }
+  if (M == 0) {   // no rows: gradients are exactly zero; the kernel still writes zero slabs
+  }
+  ProfScope ps(4, (double)M * n_tasks, (hipStream_t)stream);
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch, (unsigned)n_tasks), dim3(WG), 0, (hipStream_t)stream, wa);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + 255) / 256, (unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, ra);
+  return hgn_check_launch("hgn_mlp_wgrad");
+}
+
+extern "C" int hgn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, int32_t step, float grad_scale, void* stream) {
+  if (n == 0) return HGN_OK;
+  if (!p || !g || !m || !v || n < 0 || step < 1) return hgn_fail(HGN_E_INVALID, "hgn_adam_step: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  ProfScope ps(9, (double)n, (hipStream_t)stream);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr,
+                     beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  return hgn_check_launch("hgn_adam_step");
+}

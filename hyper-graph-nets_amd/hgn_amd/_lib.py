@@ -1,0 +1,125 @@
+"""ctypes binding of libhgn_mp.so (C ABI: include/hgn_mp.h).
+
+The library is the product path: if it is missing or a symbol is absent this module raises -- there is no
+PyTorch/CPU fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhgn_mp.so')
+
+HGN_MAX_SRC = 8
+HGN_MAX_ADD = 2
+HGN_MAX_WTASK = 16
+NUM_KERNEL_IDS = 12
+OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
+KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
+                'linear_bwd', 'adam', 'csr', 'reserved']
+
+c_f32p = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+c_i32p = C.c_void_p
+
+
+class Src(C.Structure):
+    _fields_ = [('x', c_f32p), ('ld', C.c_int64), ('K', C.c_int32), ('idx', c_i32p), ('W', c_f32p)]
+
+
+class Add(C.Structure):
+    _fields_ = [('P', c_f32p), ('ld', C.c_int64), ('idx', c_i32p)]
+
+
+class MlpFwd(C.Structure):
+    _fields_ = [('M', C.c_int64), ('n_src', C.c_int32), ('src', Src * HGN_MAX_SRC), ('n_add', C.c_int32),
+                ('add', Add * HGN_MAX_ADD), ('ldw1', C.c_int64), ('b1', c_f32p), ('W2', c_f32p), ('b2', c_f32p),
+                ('W3', c_f32p), ('b3', c_f32p), ('out_w', C.c_int32), ('ln_g', c_f32p), ('ln_b', c_f32p),
+                ('res', c_f32p), ('ld_res', C.c_int64), ('out', c_f32p), ('ld_out', C.c_int64), ('z1', c_f32p),
+                ('z2', c_f32p), ('xhat', c_f32p), ('rstd', c_f32p)]
+
+
+class Dx(C.Structure):
+    _fields_ = [('W', c_f32p), ('K', C.c_int32), ('dx', c_f32p), ('ld', C.c_int64), ('residual', C.c_int32)]
+
+
+class MlpBwd(C.Structure):
+    _fields_ = [('M', C.c_int64), ('d_out', c_f32p), ('ld_dout', C.c_int64), ('out_w', C.c_int32), ('ln_g', c_f32p),
+                ('xhat', c_f32p), ('rstd', c_f32p), ('z2', c_f32p), ('z1', c_f32p), ('W3', c_f32p), ('W2', c_f32p),
+                ('ldw1', C.c_int64), ('dz3', c_f32p), ('dz2', c_f32p), ('dz1', c_f32p), ('n_dx', C.c_int32),
+                ('dx', Dx * HGN_MAX_SRC)]
+
+
+class WTask(C.Structure):
+    _fields_ = [('type', C.c_int32), ('A', c_f32p), ('lda', C.c_int64), ('K', C.c_int32), ('idxA', c_i32p),
+                ('G', c_f32p), ('ldg', C.c_int64), ('n_out', C.c_int32), ('dW', c_f32p), ('ldw', C.c_int64),
+                ('db', c_f32p)]
+
+
+_SIGS = {
+    'hgn_last_error': (C.c_char_p, []),
+    'hgn_version': (C.c_int, []),
+    'hgn_csr_workspace_bytes': (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
+    'hgn_csr_build': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_size_t, C.c_void_p]),
+    'hgn_narrow_gather_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'hgn_segment_reduce_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    'hgn_segment_reduce_bwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'hgn_mlp_fwd': (C.c_int, [C.POINTER(MlpFwd), C.c_void_p]),
+    'hgn_mlp_bwd': (C.c_int, [C.POINTER(MlpBwd), C.c_void_p]),
+    'hgn_wgrad_workspace_bytes': (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
+    'hgn_mlp_wgrad': (C.c_int, [C.POINTER(WTask), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'hgn_linear_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_int64,
+                                 C.c_void_p, C.c_int64, C.c_void_p]),
+    'hgn_linear_bwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_int64,
+                                 C.c_void_p, C.c_int64, C.c_void_p]),
+    'hgn_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    'hgn_prof_enable': (C.c_int, [C.c_int]),
+    'hgn_prof_reset': (C.c_int, []),
+    'hgn_prof_collect': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class HgnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HgnError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'(or `make -C hyper-graph-nets_amd/csrc`). There is no fallback path.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)          # AttributeError if the export is missing -> loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = lib().hgn_last_error().decode(errors='replace')
+        if rc == -3:
+            raise IndexError(f'{what}: {msg}')
+        raise HgnError(f'{what} failed (code {rc}): {msg}')
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise HgnError('the hgn_amd product path runs on an MI355X (HIP) device only; got a CPU tensor. '
+                       'There is no CPU fallback.')

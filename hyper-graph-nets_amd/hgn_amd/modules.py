@@ -1,0 +1,393 @@
+"""The reference's GNN core (src/migration/*.py) re-built on the HIP kernels, with the same class names, constructor
+signatures, module tree and ``state_dict`` keys, so that the reference's system models (src/model/flag.py:55-63,
+plate.py:59-67, cylinder.py:55-63) construct and call it unchanged.
+
+The module tree only *holds* parameters (real nn.LazyLinear / nn.LayerNorm objects, so lazy materialisation,
+default init, ``.to()``, ``parameters()`` before the first forward (MeshSimulator.py:110) and pickling behave as in
+the reference).  ``forward`` never calls those modules: it hands their tensors to the fused kernels.
+
+Inside the processor the graph is kept in an internal layout (``_Latent``): edge latents of every edge set are
+stored in receiver-sorted (CSR) order for the whole stack of blocks; they are permuted once in the encoder (a gather
+folded into the encoder MLP's load) and never permuted back, because MeshGraphNet decodes node rows only
+(meshgraphnet.py:50).  Block modules called stand-alone with a public MultiGraph convert in and out.
+"""
+import collections
+import functools
+from collections import OrderedDict
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Type
+
+import torch
+from torch import nn, Tensor
+
+from . import ops, topology
+from ._lib import HgnError
+from .util import EdgeSet, MultiGraph, device
+
+PNA = ('sum', 'mean', 'max', 'min')                       # graphnet.py:52-64
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# parameter holders
+# ----------------------------------------------------------------------------------------------------------------
+class LazyMLP(nn.Module):
+    """meshgraphnet.py:93-108 -- Linear/ReLU stack whose input width is discovered at first use."""
+
+    def __init__(self, output_sizes: List[int]):
+        super().__init__()
+        num_layers = len(output_sizes)
+        layers = OrderedDict()
+        for index, output_size in enumerate(output_sizes):
+            layers['linear_' + str(index)] = nn.LazyLinear(output_size)
+            if index < (num_layers - 1):
+                layers['relu_' + str(index)] = nn.ReLU()
+        self.layers = nn.Sequential(layers)
+
+    def forward(self, input: Tensor) -> Tensor:
+        return fused_apply(self, [input.to(device)])
+
+
+def _split(module: nn.Module) -> Tuple[LazyMLP, Optional[nn.LayerNorm]]:
+    if isinstance(module, LazyMLP):
+        return module, None
+    return module[0], module[1]
+
+
+def _linears(mlp: LazyMLP) -> List[nn.Module]:
+    return [m for n, m in mlp.layers.named_children() if n.startswith('linear_')]
+
+
+def materialize(module: nn.Module, in_features: int):
+    """Give the lazy layers their shapes exactly as a first reference forward would (same init, same RNG order)."""
+    mlp, _ = _split(module)
+    width = in_features
+    for lin in _linears(mlp):
+        if isinstance(lin.weight, nn.parameter.UninitializedParameter):
+            dev = lin.weight.device
+            with torch.no_grad():
+                lin(torch.empty(0, width, device=dev))           # runs LazyLinear's own materialisation hook
+        elif lin.weight.shape[1] != width:
+            raise HgnError(f'MLP expects {lin.weight.shape[1]} input features, got {width}')
+        width = lin.weight.shape[0]
+
+
+def weights_of(module: nn.Module, in_features: int) -> ops.MLPWeights:
+    materialize(module, in_features)
+    mlp, ln = _split(module)
+    lins = _linears(mlp)
+    if len(lins) != 3:
+        raise HgnError('the HIP path implements the reference setting num_layers=2 (three Linear layers per MLP)')
+    w = ops.MLPWeights(lins[0].weight, lins[0].bias, lins[1].weight, lins[1].bias, lins[2].weight, lins[2].bias,
+                       ln.weight if ln is not None else None, ln.bias if ln is not None else None)
+    return w
+
+
+def fused_apply(module: nn.Module, srcs: Sequence[Tensor], idxs=None, residual: int = -1) -> Tensor:
+    width = sum(s.shape[1] for s in srcs)
+    return ops.fused_mlp(srcs, weights_of(module, width), idxs, residual)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# internal graph layout
+# ----------------------------------------------------------------------------------------------------------------
+class _Latent:
+    __slots__ = ('nodes', 'edges', 'topo')
+
+    def __init__(self, nodes: List[Tensor], edges: 'OrderedDict[str, Tensor]', topo: Dict[str, topology.EdgeTopology]):
+        self.nodes, self.edges, self.topo = nodes, edges, topo
+
+    def h_all(self) -> Tensor:
+        return self.nodes[0] if len(self.nodes) == 1 else torch.cat(tuple(self.nodes), dim=0)
+
+    @property
+    def n_mesh(self):
+        return self.nodes[0].shape[0]
+
+
+def _num_rows(node_features) -> int:
+    return sum(x.shape[0] for x in node_features)
+
+
+def to_latent(graph: MultiGraph) -> _Latent:
+    """Public MultiGraph (edge rows in user order) -> internal layout (receiver-sorted rows)."""
+    nodes = [x.to(device) for x in graph.node_features]
+    n_tot = _num_rows(nodes)
+    edges, topo = OrderedDict(), {}
+    for es in graph.edge_sets:
+        t = topology.edge_topology(es.senders, es.receivers, n_tot, nodes[0].device)
+        topo[es.name] = t
+        edges[es.name] = es.features.to(device).index_select(0, t.r.perm.long())
+    return _Latent(nodes, edges, topo)
+
+
+def to_public(lat: _Latent, like: MultiGraph) -> MultiGraph:
+    by_name = {e.name: e for e in like.edge_sets}
+    sets = []
+    for name, feat in lat.edges.items():
+        t = lat.topo[name]
+        sets.append(by_name[name]._replace(features=feat.index_select(0, t.inverse_perm())))
+    return MultiGraph(lat.nodes, sets)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# blocks
+# ----------------------------------------------------------------------------------------------------------------
+class GraphNet(nn.Module):
+    """Multi-Edge Interaction Network with residual connections (graphnet.py:11-124)."""
+
+    def __init__(self, model_fn: Callable, output_size: int, message_passing_aggregator: str, edge_sets: List[str]):
+        super().__init__()
+        self.node_model_cross = model_fn(output_size)
+        self.edge_models = nn.ModuleDict({name: model_fn(output_size) for name in edge_sets})
+        self.message_passing_aggregator = message_passing_aggregator
+        # The reference iterates Python *sets* of names in HyperGraphNet/MultiScaleGraphNet (hypergraphnet.py:31,44), so
+        # the column order of those node-MLP inputs depends on PYTHONHASHSEED; here it is this fixed list.
+        self.set_order = ['mesh_edges', 'world_edges', 'inter_cluster', 'inter_cluster_world']
+
+    # -- stage primitives on the internal layout -----------------------------------------------------------------
+    def _ops(self) -> Tuple[str, ...]:
+        return PNA if self.message_passing_aggregator == 'pna' else (self.message_passing_aggregator,)
+
+    def _edge(self, lat: _Latent, feats: Tensor, name: str, h_all: Optional[Tensor] = None) -> Tensor:
+        h_all = lat.h_all() if h_all is None else h_all
+        return ops.edge_block(h_all, feats, lat.topo[name], weights_of(self.edge_models[name], 3 * ops.LAT))
+
+    def _aggregate(self, lat: _Latent, new_edges: 'OrderedDict[str, Tensor]', names: Sequence[str]) -> Optional[Tensor]:
+        names = [n for n in names if n in self.edge_models]                   # graphnet.py:43
+        if not names:
+            return None
+        csrs = [(None, lat.topo[n].r.rowptr, lat.topo[n].rcv) for n in names]
+        return ops.aggregate([new_edges[n] for n in names], csrs, self._ops())
+
+    def _node(self, lat: _Latent, agg: Optional[Tensor], model: nn.Module, which: int):
+        """nodes[which] += LN(MLP([h ; agg][rows of `which`]))   (graphnet.py:47-48,107-108,123-124)."""
+        n_mesh = lat.n_mesh
+        h = lat.nodes[which]
+        srcs = [h]
+        if agg is not None:
+            srcs.append(agg[:n_mesh] if which == 0 else agg[n_mesh:])
+        lat.nodes[which] = fused_apply(model, srcs, residual=0)
+
+    # -- GraphNet.forward (graphnet.py:72-84) --------------------------------------------------------------------
+    def _forward_latent(self, lat: _Latent) -> _Latent:
+        h_all = lat.h_all()
+        new_edges = OrderedDict()
+        for name, feats in lat.edges.items():
+            if name not in self.edge_models:
+                raise KeyError(name)                                           # graphnet.py:32
+            new_edges[name] = self._edge(lat, feats, name, h_all)
+        nodes = list(lat.nodes)
+        out = _Latent(nodes, new_edges, lat.topo)
+        self._update_nodes(out, new_edges)
+        return out
+
+    def _update_nodes(self, lat: _Latent, new_edges):
+        agg = self._aggregate(lat, new_edges, list(new_edges.keys()))
+        self._node(lat, agg, self.node_model_cross, 0)
+
+    def forward(self, graph, mask=None):
+        if isinstance(graph, _Latent):
+            return self._forward_latent(graph)
+        return to_public(self._forward_latent(to_latent(graph)), graph)
+
+    # -- helpers shared by the hierarchical blocks (graphnet.py:86-124) -----------------------------------------
+    def _edges_stage(self, lat: _Latent, src_edges, name: str, new_edges):
+        if name not in self.edge_models:                                      # graphnet.py:87-88
+            return
+        if name not in src_edges:
+            raise IndexError(f'edge set {name!r} is registered but missing from the graph')   # graphnet.py:90
+        new_edges[name] = self._edge(lat, src_edges[name], name)
+
+    def _pick(self, new_edges, pair):
+        names = [n for n in self.set_order if n in pair and n in self.edge_models]
+        return names
+
+
+class MultiGraphNet(GraphNet):
+    """multigraphnet.py:10-18 -- identical to GraphNet."""
+
+
+class RepeatedGraphNet(GraphNet):
+    """repeatedgraphnet.py:11-22 -- GraphNet.forward applied `repetitions` times with shared weights."""
+
+    def __init__(self, model_fn, output_size, message_passing_aggregator, edge_sets, repetitions=2):
+        super().__init__(model_fn, output_size, message_passing_aggregator, edge_sets)
+        self.repetitions = repetitions
+
+    def _forward_latent(self, lat):
+        for _ in range(self.repetitions):
+            lat = GraphNet._forward_latent(self, lat)
+        return lat
+
+
+class HeteroGraphNet(GraphNet):
+    """heterographnet.py:10-33 -- one aggregation over all sets feeding a mesh-row MLP and a hyper-row MLP."""
+
+    def __init__(self, model_fn, output_size, message_passing_aggregator, edge_sets):
+        super().__init__(model_fn, output_size, message_passing_aggregator, edge_sets)
+        self.hyper_node_model_cross = model_fn(output_size)
+
+    def _update_nodes(self, lat, new_edges):
+        agg = self._aggregate(lat, new_edges, list(new_edges.keys()))
+        old = list(lat.nodes)
+        self._node(lat, agg, self.node_model_cross, 0)
+        mesh_new = lat.nodes[0]
+        lat.nodes[0] = old[0]                       # both MLPs read the pre-update rows (heterographnet.py:29-32)
+        self._node(lat, agg, self.hyper_node_model_cross, 1)
+        lat.nodes[0] = mesh_new
+
+
+class HyperGraphNet(GraphNet):
+    """hypergraphnet.py:11-54 -- eight sequential stages, each seeing the node rows updated by the previous ones."""
+
+    def __init__(self, model_fn, output_size, message_passing_aggregator, edge_sets):
+        super().__init__(model_fn, output_size, message_passing_aggregator, edge_sets)
+        self.hyper_node_model_up = model_fn(output_size)
+        self.hyper_node_model_cross = model_fn(output_size)
+        self.node_model_down = model_fn(output_size)
+
+    def _cross_models(self):
+        return [self.hyper_node_model_cross]
+
+    def _forward_latent(self, lat):
+        src = lat.edges
+        lat = _Latent(list(lat.nodes), src, lat.topo)
+        new = OrderedDict()
+        E = functools.partial(self._edges_stage, lat, src)
+        E('mesh_edges', new); E('world_edges', new)
+        self._node(lat, self._aggregate(lat, new, self._pick(new, ('mesh_edges', 'world_edges'))), self.node_model_cross, 0)
+        E('intra_cluster_to_cluster', new)
+        self._node(lat, self._aggregate(lat, new, ['intra_cluster_to_cluster']), self.hyper_node_model_up, 1)
+        for model in self._cross_models():
+            E('inter_cluster', new); E('inter_cluster_world', new)
+            self._node(lat, self._aggregate(lat, new, self._pick(new, ('inter_cluster', 'inter_cluster_world'))), model, 1)
+        E('intra_cluster_to_mesh', new)
+        self._node(lat, self._aggregate(lat, new, ['intra_cluster_to_mesh']), self.node_model_down, 0)
+        self._tail(lat, src, new)
+        return _Latent(lat.nodes, new, lat.topo)
+
+    def _tail(self, lat, src, new):
+        pass
+
+
+class MultiScaleGraphNet(HyperGraphNet):
+    """multiscalegraphnet.py:10-63 -- up, 3 x inter-cluster, down, then a second mesh update from the INPUT edges."""
+
+    def __init__(self, model_fn, output_size, message_passing_aggregator, edge_sets):
+        GraphNet.__init__(self, model_fn, output_size, message_passing_aggregator, edge_sets)
+        self.hyper_node_model_up = model_fn(output_size)
+        self.hyper_node_models_cross = nn.ModuleList([model_fn(output_size) for _ in range(3)])
+        self.node_model_down = model_fn(output_size)
+
+    def _cross_models(self):
+        return list(self.hyper_node_models_cross)
+
+    def _tail(self, lat, src, new):
+        self._edges_stage(lat, src, 'mesh_edges', new)
+        self._edges_stage(lat, src, 'world_edges', new)
+        self._node(lat, self._aggregate(lat, new, self._pick(new, ('mesh_edges', 'world_edges'))), self.node_model_cross, 0)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# encoder / processor / decoder / model
+# ----------------------------------------------------------------------------------------------------------------
+class Encoder(nn.Module):
+    """encoder.py:9-47."""
+
+    def __init__(self, make_mlp: Callable, latent_size: int, edge_sets: List[str], hierarchical=True):
+        super().__init__()
+        self._make_mlp = make_mlp
+        self._latent_size = latent_size
+        self.node_model = self._make_mlp(latent_size)
+        self.edge_models = nn.ModuleDict({name: self._make_mlp(latent_size) for name in edge_sets})
+        self.hierarchical = hierarchical
+        if hierarchical:
+            self.hyper_node_model = self._make_mlp(latent_size)
+
+    def _encode(self, graph: MultiGraph) -> _Latent:
+        raw = [x.to(device) for x in graph.node_features]
+        nodes = [fused_apply(self.node_model, [raw[0]])]
+        if len(raw) > 1:
+            nodes.append(fused_apply(self.hyper_node_model if self.hierarchical else self.node_model, [raw[1]]))
+        n_tot = _num_rows(raw)
+        edges, topo = OrderedDict(), {}
+        for es in graph.edge_sets:
+            if es.name not in self.edge_models:                               # encoder.py:44-45: dropped
+                continue
+            t = topology.edge_topology(es.senders, es.receivers, n_tot, raw[0].device)
+            topo[es.name] = t
+            # the permutation into receiver-sorted order is the row-gather index of the encoder MLP's first load
+            edges[es.name] = fused_apply(self.edge_models[es.name], [es.features.to(device)], idxs=[t.r.perm])
+        return _Latent(nodes, edges, topo)
+
+    def forward(self, graph: MultiGraph) -> MultiGraph:
+        lat = self._encode(graph)
+        return to_public(lat, graph)
+
+
+class Processor(nn.Module):
+    """processor.py:10-28."""
+
+    def __init__(self, make_mlp: Callable, output_size: int, message_passing_steps: int, message_passing_aggregator: str,
+                 edge_sets: List[str], graphnet_block: Type[GraphNet]):
+        super().__init__()
+        blocks = []
+        for _ in range(message_passing_steps):
+            blocks.append(graphnet_block(model_fn=make_mlp, output_size=output_size,
+                                         message_passing_aggregator=message_passing_aggregator, edge_sets=edge_sets))
+        self.graphnet_blocks = nn.Sequential(*blocks)
+
+    def forward(self, latent_graph):
+        return self.graphnet_blocks(latent_graph)
+
+
+class Decoder(nn.Module):
+    """decoder.py:8-16."""
+
+    def __init__(self, make_mlp: Callable, output_size: int):
+        super().__init__()
+        self.model = make_mlp(output_size)
+
+    def forward(self, graph) -> Tensor:
+        return fused_apply(self.model, [graph.node_features])
+
+
+class MeshGraphNet(nn.Module):
+    """Encode-Process-Decode GraphNet model (meshgraphnet.py:21-89)."""
+
+    def __init__(self, output_size: int, latent_size: int, num_layers: int, message_passing_aggregator: str,
+                 message_passing_steps: int, architecture: str, edge_sets: List[str]):
+        super().__init__()
+        self._latent_size = latent_size
+        self._output_size = output_size
+        self._num_layers = num_layers
+        self._message_passing_steps = message_passing_steps
+        self._message_passing_aggregator = message_passing_aggregator
+        graphnet_block, hierarchical = self.get_architecture(architecture)
+        self.encoder = Encoder(make_mlp=self._make_mlp, latent_size=self._latent_size, hierarchical=hierarchical,
+                               edge_sets=edge_sets)
+        self.processor = Processor(make_mlp=self._make_mlp, output_size=self._latent_size,
+                                   message_passing_steps=self._message_passing_steps,
+                                   message_passing_aggregator=self._message_passing_aggregator, edge_sets=edge_sets,
+                                   graphnet_block=graphnet_block)
+        self.decoder = Decoder(make_mlp=functools.partial(self._make_mlp, layer_norm=False), output_size=self._output_size)
+
+    def forward(self, graph: MultiGraph) -> Tensor:
+        if self._latent_size != ops.LAT or self._num_layers != 2:
+            raise HgnError('the HIP path implements latent_size=128, num_layers=2 (hard-coded by the reference models: '
+                           'src/model/flag.py:57-58, plate.py:61-62, cylinder.py:57-58)')
+        lat = self.encoder._encode(graph)
+        lat = self.processor(lat)
+        return self.decoder(MultiGraph(lat.nodes[0], None))
+
+    def _make_mlp(self, output_size: int, layer_norm=True) -> nn.Module:
+        widths = [self._latent_size] * self._num_layers + [output_size]
+        network = LazyMLP(widths)
+        if layer_norm:
+            network = nn.Sequential(network, nn.LayerNorm(normalized_shape=widths[-1]))
+        return network
+
+    @staticmethod
+    def get_architecture(architecture: str) -> Tuple[Type[GraphNet], bool]:
+        table = {'hyper': (HyperGraphNet, True), 'multiscale': (MultiScaleGraphNet, True), 'hetero': (HeteroGraphNet, True),
+                 'multi': (MultiGraphNet, False), 'repeated': (RepeatedGraphNet, False)}
+        return table.get(architecture, (GraphNet, False))

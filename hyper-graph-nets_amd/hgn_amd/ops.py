@@ -1,0 +1,435 @@
+"""torch.autograd wrappers over the C ABI (include/hgn_mp.h).  Every arithmetic step of the message-passing path
+runs in libhgn_mp.so; torch supplies device memory, the current stream and the autograd graph only.
+
+Reference lines replaced (paths relative to the reference root):
+  EdgeBlockFn   GraphNet._update_edge_features           src/migration/graphnet.py:22-32
+  AggregateFn   GraphNet.aggregation / util.unsorted_segment_operation   graphnet.py:50-70, src/util.py:92-134
+  MLPFn         node updates graphnet.py:34-48,94-124; LazyMLP(+LayerNorm) meshgraphnet.py:53-60,93-108
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import OP_CODES
+
+LAT = 128
+_ws_cache = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    key = (device.type, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """2-D tensor whose rows are contiguous (row stride arbitrary) and 16-byte aligned; copies otherwise."""
+    if t.dim() != 2:
+        raise ValueError('expected a 2-D tensor')
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.shape[1] > 0 and t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0) if t.dim() > 1 else 1)
+
+
+class MLPWeights:
+    """The eight tensors of one reference `_make_mlp` module, in nn.Linear layout, plus static shape facts."""
+    __slots__ = ('w1', 'b1', 'w2', 'b2', 'w3', 'b3', 'ln_w', 'ln_b')
+
+    def __init__(self, w1, b1, w2, b2, w3, b3, ln_w=None, ln_b=None):
+        self.w1, self.b1, self.w2, self.b2, self.w3, self.b3, self.ln_w, self.ln_b = w1, b1, w2, b2, w3, b3, ln_w, ln_b
+
+    def tensors(self):
+        ts = [self.w1, self.b1, self.w2, self.b2, self.w3, self.b3]
+        if self.ln_w is not None:
+            ts += [self.ln_w, self.ln_b]
+        return ts
+
+    def check(self):
+        if self.w2.shape != (LAT, LAT) or self.w1.shape[0] != LAT or self.w3.shape[1] != LAT:
+            raise _lib.HgnError(f'the HIP path is built for latent_size=128, num_layers=2 (reference src/model/flag.py:57-58); '
+                                f'got weights {tuple(self.w1.shape)}, {tuple(self.w2.shape)}, {tuple(self.w3.shape)}')
+        for t in self.tensors():
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                raise _lib.HgnError('MLP weights must be contiguous fp32')
+
+
+def _fill_common_fwd(a: _lib.MlpFwd, w: MLPWeights, out, res, saves):
+    a.ldw1 = w.w1.shape[1]
+    a.b1 = w.b1.data_ptr()
+    a.W2 = w.w2.data_ptr(); a.b2 = w.b2.data_ptr()
+    a.W3 = w.w3.data_ptr(); a.b3 = w.b3.data_ptr()
+    a.out_w = w.w3.shape[0]
+    if w.ln_w is not None:
+        a.ln_g = w.ln_w.data_ptr(); a.ln_b = w.ln_b.data_ptr()
+    if res is not None:
+        a.res = res.data_ptr(); a.ld_res = _ld(res)
+    a.out = out.data_ptr(); a.ld_out = _ld(out)
+    if saves is not None:
+        z1, z2, xhat, rstd = saves
+        a.z1 = z1.data_ptr(); a.z2 = z2.data_ptr()
+        if xhat is not None:
+            a.xhat = xhat.data_ptr(); a.rstd = rstd.data_ptr()
+
+
+def _alloc_saves(M, has_ln, dev):
+    z1 = torch.empty(M, LAT, device=dev)
+    z2 = torch.empty(M, LAT, device=dev)
+    xhat = torch.empty(M, LAT, device=dev) if has_ln else None
+    rstd = torch.empty(M, device=dev) if has_ln else None
+    return z1, z2, xhat, rstd
+
+
+def _run_wgrad(tasks: List[_lib.WTask], M: int, dev):
+    L = _lib.lib()
+    for i in range(0, len(tasks), _lib.HGN_MAX_WTASK):
+        chunk = tasks[i:i + _lib.HGN_MAX_WTASK]
+        arr = (_lib.WTask * len(chunk))(*chunk)
+        nb = C.c_size_t(0)
+        _lib.check(L.hgn_wgrad_workspace_bytes(M, len(chunk), C.byref(nb)), 'hgn_wgrad_workspace_bytes')
+        ws = _workspace(dev, nb.value)
+        _lib.check(L.hgn_mlp_wgrad(arr, len(chunk), M, ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'hgn_mlp_wgrad')
+
+
+def _wtask(typ, A, lda, K, idxA, G, ldg, n_out, dW_ptr, ldw, db_ptr):
+    t = _lib.WTask()
+    t.type = typ; t.A = A; t.lda = lda; t.K = K; t.idxA = idxA; t.G = G; t.ldg = ldg
+    t.n_out = n_out; t.dW = dW_ptr; t.ldw = ldw; t.db = db_ptr
+    return t
+
+
+# ------------------------------------------------------------------------------------------------------------
+# generic fused MLP over concatenated sources
+# ------------------------------------------------------------------------------------------------------------
+class MLPFn(torch.autograd.Function):
+    """out = [src[residual] +] [LN](MLP(cat(src_0[idx_0], src_1[idx_1], ...)))   without materialising the cat."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        n_src, idxs, residual, has_ln, train = meta
+        srcs = [_rowmajor(t) for t in tensors[:n_src]]
+        wt = tensors[n_src:]
+        w = MLPWeights(*wt)
+        w.check()
+        dev = wt[0].device
+        for s in srcs:
+            _lib.require_gpu(s)
+        M = idxs[0].shape[0] if idxs[0] is not None else srcs[0].shape[0]
+        out_w = w.w3.shape[0]
+        out = torch.empty(M, out_w, device=dev)
+        a = _lib.MlpFwd()
+        a.M = M
+        a.n_src = n_src
+        col = 0
+        cols = []
+        for i, s in enumerate(srcs):
+            e = a.src[i]
+            e.x = s.data_ptr(); e.ld = _ld(s); e.K = s.shape[1]
+            e.idx = idxs[i].data_ptr() if idxs[i] is not None else None
+            e.W = w.w1.data_ptr() + 4 * col
+            cols.append(col)
+            col += s.shape[1]
+        if col != w.w1.shape[1]:
+            raise _lib.HgnError(f'MLP input width {col} does not match weight in_features {w.w1.shape[1]}')
+        saves = _alloc_saves(M, has_ln, dev) if train else None
+        res = srcs[residual] if residual >= 0 else None
+        _fill_common_fwd(a, w, out, res, saves)
+        if M > 0:
+            _lib.check(_lib.lib().hgn_mlp_fwd(C.byref(a), _lib.stream_ptr()), 'hgn_mlp_fwd')
+        if train:
+            ctx.meta = (n_src, idxs, residual, has_ln, cols, M)
+            ctx.saves = saves
+            ctx.save_for_backward(*srcs, *wt)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        n_src, idxs, residual, has_ln, cols, M = ctx.meta
+        saved = ctx.saved_tensors
+        srcs, wt = saved[:n_src], saved[n_src:]
+        w = MLPWeights(*wt)
+        z1, z2, xhat, rstd = ctx.saves
+        dev = d_out.device
+        d_out = _rowmajor(d_out)
+        L = _lib.lib()
+        out_w = w.w3.shape[0]
+        dz3 = torch.empty(M, LAT, device=dev)
+        dz2 = torch.empty(M, LAT, device=dev)
+        dz1 = torch.empty(M, LAT, device=dev)
+        b = _lib.MlpBwd()
+        b.M = M
+        b.d_out = d_out.data_ptr(); b.ld_dout = _ld(d_out); b.out_w = out_w
+        if has_ln:
+            b.ln_g = w.ln_w.data_ptr(); b.xhat = xhat.data_ptr(); b.rstd = rstd.data_ptr()
+        b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr()
+        b.W3 = w.w3.data_ptr(); b.W2 = w.w2.data_ptr(); b.ldw1 = w.w1.shape[1]
+        b.dz3 = dz3.data_ptr(); b.dz2 = dz2.data_ptr(); b.dz1 = dz1.data_ptr()
+        dxs = [None] * n_src
+        nd = 0
+        for i in range(n_src):
+            if ctx.needs_input_grad[1 + i]:
+                K = srcs[i].shape[1]
+                dx = torch.empty(M, K, device=dev)
+                d = b.dx[nd]
+                d.W = w.w1.data_ptr() + 4 * cols[i]; d.K = K; d.dx = dx.data_ptr(); d.ld = K
+                d.residual = 1 if i == residual else 0
+                dxs[i] = dx
+                nd += 1
+        b.n_dx = nd
+        if M > 0:
+            _lib.check(L.hgn_mlp_bwd(C.byref(b), _lib.stream_ptr()), 'hgn_mlp_bwd')
+        # ---- parameter gradients -------------------------------------------------------------------------------
+        dw1 = torch.empty_like(w.w1); db1 = torch.empty_like(w.b1)
+        dw2 = torch.empty_like(w.w2); db2 = torch.empty_like(w.b2)
+        dw3 = torch.empty_like(w.w3); db3 = torch.empty_like(w.b3)
+        tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, out_w, dw3.data_ptr(), LAT, db3.data_ptr()),
+                 _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr())]
+        first = True
+        ldw1 = w.w1.shape[1]
+        for i, s in enumerate(srcs):
+            K = s.shape[1]
+            for k0 in range(0, K, LAT):
+                kw = min(LAT, K - k0)
+                tasks.append(_wtask(0, s.data_ptr() + 4 * k0, _ld(s), kw, idxs[i].data_ptr() if idxs[i] is not None else None,
+                                    dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * (cols[i] + k0), ldw1,
+                                    db1.data_ptr() if first else None))
+                first = False
+        grads_w = [dw1, db1, dw2, db2, dw3, db3]
+        if has_ln:
+            dg = torch.empty_like(w.ln_w); dbt = torch.empty_like(w.ln_b)
+            tasks.append(_wtask(1, xhat.data_ptr(), LAT, LAT, None, d_out.data_ptr(), _ld(d_out), LAT, dg.data_ptr(), LAT,
+                                dbt.data_ptr()))
+            grads_w += [dg, dbt]
+        _run_wgrad(tasks, M, dev)
+        # ---- un-gather source gradients -----------------------------------------------------------------------
+        for i in range(n_src):
+            if dxs[i] is not None and idxs[i] is not None:
+                full = torch.zeros_like(srcs[i])
+                full.index_add_(0, idxs[i].long(), dxs[i])
+                dxs[i] = full
+        return (None, *dxs, *grads_w)
+
+
+def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequence[Optional[torch.Tensor]]] = None,
+              residual: int = -1) -> torch.Tensor:
+    idxs = tuple(idxs) if idxs is not None else (None,) * len(srcs)
+    wt = w.tensors()
+    train = torch.is_grad_enabled() and any(t.requires_grad for t in list(srcs) + wt)
+    meta = (len(srcs), idxs, residual, w.ln_w is not None, train)
+    return MLPFn.apply(meta, *srcs, *wt)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# edge block: split first layer  (h W_s^T)[snd] + (h W_r^T)[rcv] + e W_e^T
+# ------------------------------------------------------------------------------------------------------------
+class EdgeBlockFn(torch.autograd.Function):
+    """e' = e + LN(MLP([h[snd] ; h[rcv] ; e])) with e, e' in receiver-sorted order."""
+
+    @staticmethod
+    def forward(ctx, topo, train, h_all, e, *wt):
+        w = MLPWeights(*wt)
+        w.check()
+        if w.w1.shape[1] != 3 * LAT or w.ln_w is None:
+            raise _lib.HgnError('edge model must be Linear(384,128)...+LayerNorm')
+        h_all = _rowmajor(h_all)
+        e = _rowmajor(e)
+        _lib.require_gpu(e)
+        dev = e.device
+        L = _lib.lib()
+        E, N = topo.num_edges, topo.num_nodes
+        if e.shape[0] != E or h_all.shape[0] != N:
+            raise _lib.HgnError(f'edge block: got {e.shape[0]} edge rows / {h_all.shape[0]} node rows, topology has {E} / {N}')
+        P = torch.empty(N, 2 * LAT, device=dev)
+        wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
+        _lib.check(L.hgn_linear_fwd(h_all.data_ptr(), _ld(h_all), N, wb, 2, 3 * LAT, P.data_ptr(), 2 * LAT,
+                                    _lib.stream_ptr()), 'hgn_linear_fwd')
+        out = torch.empty(E, LAT, device=dev)
+        a = _lib.MlpFwd()
+        a.M = E
+        a.n_src = 1
+        s = a.src[0]
+        s.x = e.data_ptr(); s.ld = _ld(e); s.K = LAT; s.idx = None; s.W = w.w1.data_ptr() + 4 * 2 * LAT
+        a.n_add = 2
+        a.add[0].P = P.data_ptr(); a.add[0].ld = 2 * LAT; a.add[0].idx = topo.snd.data_ptr()
+        a.add[1].P = P.data_ptr() + 4 * LAT; a.add[1].ld = 2 * LAT; a.add[1].idx = topo.rcv.data_ptr()
+        saves = _alloc_saves(E, True, dev) if train else None
+        _fill_common_fwd(a, w, out, e, saves)
+        if E > 0:
+            _lib.check(L.hgn_mlp_fwd(C.byref(a), _lib.stream_ptr()), 'hgn_mlp_fwd')
+        if train:
+            ctx.topo = topo
+            ctx.saves = saves
+            ctx.save_for_backward(h_all, e, *wt)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        topo = ctx.topo
+        h_all, e, *wt = ctx.saved_tensors
+        w = MLPWeights(*wt)
+        z1, z2, xhat, rstd = ctx.saves
+        L = _lib.lib()
+        dev = d_out.device
+        d_out = _rowmajor(d_out)
+        E, N = topo.num_edges, topo.num_nodes
+        st = _lib.stream_ptr()
+        dz3 = torch.empty(E, LAT, device=dev)
+        dz2 = torch.empty(E, LAT, device=dev)
+        dz1 = torch.empty(E, LAT, device=dev)
+        de = torch.empty(E, LAT, device=dev)
+        b = _lib.MlpBwd()
+        b.M = E
+        b.d_out = d_out.data_ptr(); b.ld_dout = _ld(d_out); b.out_w = LAT
+        b.ln_g = w.ln_w.data_ptr(); b.xhat = xhat.data_ptr(); b.rstd = rstd.data_ptr()
+        b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr()
+        b.W3 = w.w3.data_ptr(); b.W2 = w.w2.data_ptr(); b.ldw1 = 3 * LAT
+        b.dz3 = dz3.data_ptr(); b.dz2 = dz2.data_ptr(); b.dz1 = dz1.data_ptr()
+        b.n_dx = 1
+        d = b.dx[0]
+        d.W = w.w1.data_ptr() + 4 * 2 * LAT; d.K = LAT; d.dx = de.data_ptr(); d.ld = LAT; d.residual = 1
+        if E > 0:
+            _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
+        dw1 = torch.empty_like(w.w1); db1 = torch.empty_like(w.b1)
+        dw2 = torch.empty_like(w.w2); db2 = torch.empty_like(w.b2)
+        dw3 = torch.empty_like(w.w3); db3 = torch.empty_like(w.b3)
+        dg = torch.empty_like(w.ln_w); dbt = torch.empty_like(w.ln_b)
+        tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, LAT, dw3.data_ptr(), LAT, db3.data_ptr()),
+                 _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr()),
+                 _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
+                        db1.data_ptr()),
+                 _wtask(1, xhat.data_ptr(), LAT, LAT, None, d_out.data_ptr(), _ld(d_out), LAT, dg.data_ptr(), LAT,
+                        dbt.data_ptr())]
+        _run_wgrad(tasks, E, dev)
+        # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]
+        dP = torch.empty(N, 2 * LAT, device=dev)
+        ops = (C.c_int32 * 1)(0)
+        _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N,
+                                            ops, 1, dP.data_ptr(), 2 * LAT, None, None, st), 'segment_reduce(senders)')
+        _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr(), N, ops, 1,
+                                            dP.data_ptr() + 4 * LAT, 2 * LAT, None, None, st), 'segment_reduce(receivers)')
+        tasks = [_wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr(), 2 * LAT, LAT, dw1.data_ptr(), 3 * LAT, None),
+                 _wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr() + 4 * LAT, 2 * LAT, LAT,
+                        dw1.data_ptr() + 4 * LAT, 3 * LAT, None)]
+        _run_wgrad(tasks, N, dev)
+        dh = None
+        if ctx.needs_input_grad[2]:
+            dh = torch.empty(N, LAT, device=dev)
+            wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
+            _lib.check(L.hgn_linear_bwd(dP.data_ptr(), 2 * LAT, N, wb, 2, 3 * LAT, dh.data_ptr(), LAT, st), 'hgn_linear_bwd')
+        return (None, None, dh, de, dw1, db1, dw2, db2, dw3, db3, dg, dbt)
+
+
+def edge_block(h_all: torch.Tensor, e_sorted: torch.Tensor, topo, w: MLPWeights) -> torch.Tensor:
+    wt = w.tensors()
+    train = torch.is_grad_enabled() and any(t.requires_grad for t in [h_all, e_sorted] + wt)
+    return EdgeBlockFn.apply(topo, train, h_all, e_sorted, *wt)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# aggregation
+# ------------------------------------------------------------------------------------------------------------
+def _ops_array(ops: Sequence[str]):
+    codes = []
+    for o in ops:
+        if o not in OP_CODES:
+            raise Exception('Invalid operation type!')           # src/util.py:132
+        codes.append(OP_CODES[o])
+    return (C.c_int32 * len(codes))(*codes), codes
+
+
+class AggregateFn(torch.autograd.Function):
+    """[N, n_sets * n_ops * D]: per edge set (sorted layout, perm=None, or user layout with its CSR perm), per op."""
+
+    @staticmethod
+    def forward(ctx, csrs, ops, train, *datas):
+        L = _lib.lib()
+        arr, codes = _ops_array(ops)
+        datas = [_rowmajor(d) for d in datas]
+        D = datas[0].shape[1]
+        dev = datas[0].device
+        _lib.require_gpu(datas[0])
+        N = csrs[0][1].shape[0] - 1
+        k = len(codes)
+        width = len(datas) * k * D
+        out = torch.empty(N, width, device=dev)
+        need_arg = train and any(c >= 2 for c in codes)
+        args = []
+        for i, (d, (perm, rowptr, seg)) in enumerate(zip(datas, csrs)):
+            amax = torch.empty(N, D, dtype=torch.int32, device=dev) if need_arg and 2 in codes else None
+            amin = torch.empty(N, D, dtype=torch.int32, device=dev) if need_arg and 3 in codes else None
+            _lib.check(L.hgn_segment_reduce_fwd(d.data_ptr(), _ld(d), D, perm.data_ptr() if perm is not None else None,
+                                                rowptr.data_ptr(), N, arr, k, out.data_ptr() + 4 * i * k * D, width,
+                                                amax.data_ptr() if amax is not None else None,
+                                                amin.data_ptr() if amin is not None else None, _lib.stream_ptr()),
+                       'hgn_segment_reduce_fwd')
+            args.append((amax, amin))
+        if train:
+            ctx.cfg = (csrs, ops, [tuple(d.shape) for d in datas], args, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        csrs, ops, shapes, args, width = ctx.cfg
+        L = _lib.lib()
+        arr, codes = _ops_array(ops)
+        k = len(codes)
+        d_out = _rowmajor(d_out)
+        dev = d_out.device
+        grads = []
+        for i, ((perm, rowptr, seg), shp, (amax, amin)) in enumerate(zip(csrs, shapes, args)):
+            if not ctx.needs_input_grad[3 + i]:
+                grads.append(None)
+                continue
+            E, D = shp
+            g = torch.empty(E, D, device=dev)
+            _lib.check(L.hgn_segment_reduce_bwd(d_out.data_ptr() + 4 * i * k * D, _ld(d_out), D,
+                                                perm.data_ptr() if perm is not None else None, seg.data_ptr(),
+                                                rowptr.data_ptr(), E, arr, k,
+                                                amax.data_ptr() if amax is not None else None,
+                                                amin.data_ptr() if amin is not None else None, None, g.data_ptr(), D,
+                                                _lib.stream_ptr()), 'hgn_segment_reduce_bwd')
+            grads.append(g)
+        return (None, None, None, *grads)
+
+
+def aggregate(datas: Sequence[torch.Tensor], csrs: Sequence[Tuple], ops: Sequence[str]) -> torch.Tensor:
+    """csrs[i] = (perm or None, rowptr, seg) for data i."""
+    train = torch.is_grad_enabled() and any(d.requires_grad for d in datas)
+    return AggregateFn.apply(tuple(csrs), tuple(ops), train, *datas)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# optimiser / profiler helpers
+# ------------------------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    for t in (p, g, m, v):
+        _lib.require_gpu(t)
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise _lib.HgnError('adam_step needs contiguous fp32 flat buffers')
+    _lib.check(_lib.lib().hgn_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2,
+                                        eps, step, grad_scale, _lib.stream_ptr()), 'hgn_adam_step')
+
+
+def prof_enable(on: bool):
+    _lib.check(_lib.lib().hgn_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    _lib.check(_lib.lib().hgn_prof_reset())
+
+
+def prof_collect():
+    n = _lib.NUM_KERNEL_IDS
+    ms = (C.c_double * n)(); cnt = (C.c_int64 * n)(); units = (C.c_double * n)()
+    _lib.check(_lib.lib().hgn_prof_collect(ms, cnt, units), 'hgn_prof_collect')
+    return {_lib.KERNEL_NAMES[i]: {'ms': ms[i], 'count': cnt[i], 'units': units[i]} for i in range(n) if cnt[i]}

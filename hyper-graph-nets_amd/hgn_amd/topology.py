@@ -1,0 +1,101 @@
+"""Per-topology CSR cache: receiver-sorted edge order (and the sender-sorted twin for the backward scatter).
+
+The reference rebuilds an [E, 128] int64 id broadcast on every aggregation call (src/util.py:107-110) and moves
+index tensors to the device per layer (graphnet.py:25-26).  Here the index work is done ONCE per edge-index
+tensor: a stable radix sort by receiver gives ``perm`` / ``rowptr``; all edge latents then live in that sorted
+order for the whole processor, so aggregation streams them and `h[receiver]` gathers are quasi-sequential.
+"""
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib
+
+
+class CSR:
+    """perm[j] = original position of sorted element j (stable), seg[j] = its segment id, rowptr[n..n+1] its row."""
+    __slots__ = ('perm', 'seg', 'rowptr', 'num_segments', 'num_items')
+
+    def __init__(self, ids: torch.Tensor, num_segments: int):
+        _lib.require_gpu(ids)
+        L = _lib.lib()
+        ids = ids.contiguous().to(torch.int64)
+        E = ids.numel()
+        dev = ids.device
+        nb = C.c_size_t(0)
+        _lib.check(L.hgn_csr_workspace_bytes(E, num_segments, C.byref(nb)), 'hgn_csr_workspace_bytes')
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+        self.perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+        self.seg = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+        self.rowptr = torch.empty(num_segments + 1, dtype=torch.int32, device=dev)
+        _lib.check(L.hgn_csr_build(ids.data_ptr(), E, num_segments, self.perm.data_ptr(), self.seg.data_ptr(),
+                                   self.rowptr.data_ptr(), ws.data_ptr(), nb.value, _lib.stream_ptr()),
+                   'hgn_csr_build')
+        self.num_segments = num_segments
+        self.num_items = E
+
+
+class EdgeTopology:
+    """Everything index-shaped the kernels need for one edge set over ``num_nodes`` (mesh + hyper) rows.
+
+    r   : CSR by receiver over the user's edge order   (perm = sorted position -> user position)
+    snd : senders in receiver-sorted order (int32);  rcv = r.seg
+    s   : CSR by sender over the *receiver-sorted* order (used only by the backward sender scatter)
+    """
+    __slots__ = ('r', 'snd', 'rcv', 's', 'num_nodes', 'num_edges', 'inv_perm', '__weakref__')
+
+    def __init__(self, senders: torch.Tensor, receivers: torch.Tensor, num_nodes: int, device):
+        L = _lib.lib()
+        senders = senders.to(device=device, dtype=torch.int64).contiguous()
+        receivers = receivers.to(device=device, dtype=torch.int64).contiguous()
+        if senders.shape != receivers.shape or senders.dim() != 1:
+            raise ValueError('senders / receivers must be 1-D tensors of equal length')
+        E = senders.numel()
+        self.num_nodes, self.num_edges = num_nodes, E
+        self.r = CSR(receivers, num_nodes)
+        self.rcv = self.r.seg
+        self.snd = torch.empty(max(E, 1), dtype=torch.int32, device=device)[:E]
+        _lib.check(L.hgn_narrow_gather_i64(senders.data_ptr(), self.r.perm.data_ptr(), E, self.snd.data_ptr(),
+                                           _lib.stream_ptr()), 'hgn_narrow_gather_i64')
+        self.s = CSR(self.snd, num_nodes)     # also range-checks the senders
+        self.inv_perm = None
+
+    def inverse_perm(self):
+        if self.inv_perm is None:
+            inv = torch.empty_like(self.r.perm, dtype=torch.int64)
+            inv[self.r.perm.long()] = torch.arange(self.num_edges, device=inv.device)
+            self.inv_perm = inv
+        return self.inv_perm
+
+
+_CACHE_ATTR = '_hgn_topology'
+
+
+def edge_topology(senders: torch.Tensor, receivers: torch.Tensor, num_nodes: int, device) -> EdgeTopology:
+    """Cached on the *receivers tensor object* (keyed by the identity/version of both index tensors), so a batch
+    that is reused for many steps -- the reference iterates the same batched graphs for a whole trajectory,
+    MeshSimulator.py:141-152 -- pays for the sort once."""
+    key = (id(senders), senders._version, receivers._version, num_nodes, str(device), senders.shape[0])
+    cached = getattr(receivers, _CACHE_ATTR, None)
+    if cached is not None and cached[0] == key and cached[2]() is senders:
+        return cached[1]
+    topo = EdgeTopology(senders, receivers, num_nodes, device)
+    try:
+        setattr(receivers, _CACHE_ATTR, (key, topo, weakref.ref(senders)))
+    except Exception:
+        pass
+    return topo
+
+
+def segment_csr(segment_ids: torch.Tensor, num_segments: int, device) -> CSR:
+    key = (segment_ids._version, num_segments, str(device), segment_ids.shape[0])
+    cached = getattr(segment_ids, '_hgn_csr', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    csr = CSR(segment_ids.to(device), num_segments)
+    try:
+        setattr(segment_ids, '_hgn_csr', (key, csr))
+    except Exception:
+        pass
+    return csr

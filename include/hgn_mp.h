@@ -1,0 +1,188 @@
+/* hgn_mp.h -- C ABI of libhgn_mp.so: the MI355X (gfx950) message-passing hot path of HyperGraphNets.
+ *
+ * The reference (CemOezcan/hyper-graph-nets) has NO native/FFI layer: its hot path is Python calling ATen and the
+ * third-party torch_scatter wheel.  Each entry point below therefore cites the reference *Python* code whose
+ * arithmetic it replaces (paths relative to the reference root); the Python host in
+ * hyper-graph-nets_amd/hgn_amd binds them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on failure (HGN_E_*); no exception crosses the ABI;
+ *    hgn_last_error() returns a thread-local message for the last failure;
+ *  - all pointers are DEVICE pointers unless marked host; fp32 data, int32 indices (int64 only where the
+ *    reference hands over int64 ids, i.e. hgn_csr_build / hgn_narrow_gather_i64);
+ *  - the library never allocates, frees or synchronises (except hgn_csr_build's range check, which is
+ *    topology preprocessing); the caller owns every buffer including workspaces; all work is enqueued on
+ *    the hipStream_t passed as `stream` (opaque void*); re-entrant, no global mutable state except the
+ *    optional profiler;
+ *  - latent width is fixed at 128 (reference: src/model/flag.py:57 `latent_size=128`), MLPs have two hidden
+ *    layers (flag.py:58 `num_layers=2`): Linear-ReLU-Linear-ReLU-Linear[-LayerNorm].
+ */
+#ifndef HGN_MP_H
+#define HGN_MP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGN_OK 0
+#define HGN_E_INVALID (-1)  /* bad argument (null pointer, bad size, unsupported width) */
+#define HGN_E_LAUNCH (-2)   /* HIP runtime / launch failure                               */
+#define HGN_E_RANGE (-3)    /* a segment id / node index outside [0, num_segments)        */
+
+#define HGN_OP_SUM 0
+#define HGN_OP_MEAN 1
+#define HGN_OP_MAX 2
+#define HGN_OP_MIN 3
+
+#define HGN_MAX_SRC 8
+#define HGN_MAX_ADD 2
+#define HGN_MAX_WTASK 16
+
+const char* hgn_last_error(void);
+int hgn_version(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Topology: receiver-sorted (CSR) view of an edge list.   Replaces the id broadcast
+ * `segment_ids.repeat_interleave(...)` of src/util.py:107-110 (half of the reference's CPU step time) and
+ * makes every later pass over edge latents a coalesced stream.
+ *   ids[E] int64 (as produced by src/util.py:66-67)  ->  perm[E]  (sorted position -> original edge, stable),
+ *   seg[E] (sorted ids), rowptr[N+1].
+ * ---------------------------------------------------------------------------------------------------- */
+int hgn_csr_workspace_bytes(int64_t num_edges, int64_t num_segments, size_t* bytes /*host*/);
+int hgn_csr_build(const int64_t* ids, int64_t num_edges, int64_t num_segments, int32_t* perm, int32_t* seg,
+                  int32_t* rowptr, void* workspace, size_t workspace_bytes, void* stream);
+/* dst[i] = (int32) src[perm ? perm[i] : i]   (reorders the *other* endpoint list into sorted order) */
+int hgn_narrow_gather_i64(const int64_t* src, const int32_t* perm, int64_t n, int32_t* dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * a2: util.unsorted_segment_operation (src/util.py:92-134) + GraphNet.aggregation (graphnet.py:50-70).
+ * One pass computes up to four aggregates (order given by ops[]) of data rows grouped by CSR row:
+ *   out[n][slot*D + d] = op_slot over j in [rowptr[n], rowptr[n+1]) of data[perm ? perm[j] : j][d]
+ * empty segment -> 0 for every op; mean = sum / max(count,1); max/min ties -> first element of the segment.
+ * argmax/argmin (int32 [N,D], CSR positions, -1 for empty) are written when non-null (needed by bwd).
+ * ---------------------------------------------------------------------------------------------------- */
+int hgn_segment_reduce_fwd(const float* data, int64_t ld_data, int D, const int32_t* perm, const int32_t* rowptr,
+                           int64_t num_segments, const int32_t* ops /*host*/, int n_ops, float* out,
+                           int64_t ld_out, int32_t* argmax, int32_t* argmin, void* stream);
+/* d_data[pos][d] = (base ? base[pos][d] : 0) + sum_slot dop_slot(...)   with pos = perm ? perm[j] : j */
+int hgn_segment_reduce_bwd(const float* d_out, int64_t ld_out, int D, const int32_t* perm, const int32_t* seg,
+                           const int32_t* rowptr, int64_t num_edges, const int32_t* ops /*host*/, int n_ops,
+                           const int32_t* argmax, const int32_t* argmin, const float* base, float* d_data,
+                           int64_t ld_data, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * a1/a3/a5: fused MLP  out = [res +] [LN](W3 relu(W2 relu(z1) + b2) + b3),
+ *   z1 = b1 + sum_src W1[:, src.col0 : src.col0+src.K] * x_src[idx_src ? idx_src[i] : i]
+ *           + sum_add P_add[idx_add[i]][col0 : col0+128]
+ * Replaces  _update_edge_features (graphnet.py:22-32: two index_select + cat + 3 Linear + LN + add),
+ *           _update_node_features / _update_hyper_node_features / _update_down (graphnet.py:34-48,94-124:
+ *           cat + 3 Linear + LN + add) and LazyMLP (meshgraphnet.py:93-108) for encoder / decoder.
+ * Weights are nn.Linear layout [out][in] addressed in place (pointer + leading dimension); nothing is
+ * repacked.  Saved activations (z1, z2 post-ReLU, xhat, rstd) are written when non-null (training).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x;      /* [rows, ld] source rows                                   */
+  int64_t ld;
+  int32_t K;           /* columns of this source (any K >= 1)                       */
+  const int32_t* idx;  /* optional row gather index [M]                             */
+  const float* W;      /* &W1[0][col0]: weight columns that multiply this source    */
+} hgn_src_t;
+
+typedef struct {
+  const float* P;      /* pre-projected rows [*, ld]; adds P[idx[i]][0..128)         */
+  int64_t ld;
+  const int32_t* idx;  /* required                                                   */
+} hgn_add_t;
+
+typedef struct {
+  int64_t M;                       /* rows                                            */
+  int32_t n_src;
+  hgn_src_t src[HGN_MAX_SRC];
+  int32_t n_add;
+  hgn_add_t add[HGN_MAX_ADD];
+  int64_t ldw1;                    /* leading dimension of W1 (= in_features)          */
+  const float* b1;
+  const float* W2; const float* b2;   /* [128][128], [128]                             */
+  const float* W3; const float* b3;   /* [out_w][128], [out_w]                         */
+  int32_t out_w;                   /* 1..128; must be 128 when LayerNorm is present    */
+  const float* ln_g; const float* ln_b;   /* nullable pair: no LayerNorm (decoder)      */
+  const float* res; int64_t ld_res;       /* nullable residual [M, out_w]               */
+  float* out; int64_t ld_out;
+  float* z1; float* z2; float* xhat; float* rstd;   /* nullable saves [M,128] x3, [M]   */
+} hgn_mlp_fwd_t;
+
+int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
+
+/* Backward data-gradient chain of the same MLP (LayerNorm bwd -> W3^T -> relu' -> W2^T -> relu' -> W1^T).
+ * Writes dz3, dz2, dz1 ([M,128], consumed by hgn_mlp_wgrad and, for the pre-projected addends, by the
+ * sender/receiver segment sums) and, per requested source, dx = dz1 * W1[:, cols] (+ d_out when `residual`). */
+typedef struct {
+  const float* W;      /* &W1[0][col0]                                               */
+  int32_t K;
+  float* dx;           /* [M, ld]                                                    */
+  int64_t ld;
+  int32_t residual;    /* 1: dx += d_out (the `res +` skip connection)                */
+} hgn_dx_t;
+
+typedef struct {
+  int64_t M;
+  const float* d_out; int64_t ld_dout; int32_t out_w;
+  const float* ln_g; const float* xhat; const float* rstd;    /* nullable triple        */
+  const float* z2; const float* z1;
+  const float* W3; const float* W2;
+  int64_t ldw1;
+  float* dz3; float* dz2; float* dz1;
+  int32_t n_dx;
+  hgn_dx_t dx[HGN_MAX_SRC];
+} hgn_mlp_bwd_t;
+
+int hgn_mlp_bwd(const hgn_mlp_bwd_t* args /*host*/, void* stream);
+
+/* Weight / bias / LayerNorm-affine gradients: a list of tasks reduced over all rows in one launch.
+ *   type 0:  dW[j][k] = sum_i G[i][j] * A[idxA ? idxA[i] : i][k]   (j < 128, k < K <= 128),  db[j] = sum_i G[i][j]
+ *   type 1:  dgamma[j] = sum_i G[i][j] * A[i][j],  dbeta[j] = sum_i G[i][j]        (A = xhat, G = d_out)
+ * Results overwrite dW/db (dgamma/dbeta).  Deterministic (per-chunk slabs + fixed-order reduction). */
+typedef struct {
+  int32_t type;
+  const float* A; int64_t lda; int32_t K; const int32_t* idxA;
+  const float* G; int64_t ldg;
+  int32_t n_out;        /* rows of dW to write (<=128)                                  */
+  float* dW; int64_t ldw;   /* type 0: &dW1[0][col0], leading dim; type 1: dgamma        */
+  float* db;                /* nullable; type 1: dbeta                                   */
+} hgn_wtask_t;
+
+int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes /*host*/);
+int hgn_mlp_wgrad(const hgn_wtask_t* tasks /*host*/, int n_tasks, int64_t M, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* Single Linear without bias over 128-wide blocks:  out[:, 128*b : 128*b+128] = x * Wb^T  (node pre-projection
+ * of the split edge layer:  [h W_s^T | h W_r^T], W_s = W1[:, 0:128], W_r = W1[:, 128:256], graphnet.py:28-30)
+ * and its data gradient  dx = sum_b g[:, 128*b : ...] * Wb. */
+int hgn_linear_fwd(const float* x, int64_t ldx, int64_t M, const float* const* Wblocks /*host array*/,
+                   int n_blocks, int64_t ldw, float* out, int64_t ld_out, void* stream);
+int hgn_linear_bwd(const float* g, int64_t ldg, int64_t M, const float* const* Wblocks /*host array*/,
+                   int n_blocks, int64_t ldw, float* dx, int64_t ld_dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Optimiser step on a flat parameter buffer (torch.optim.Adam semantics, MeshSimulator.py:110), and helpers.
+ * ---------------------------------------------------------------------------------------------------- */
+int hgn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int32_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line).
+ * kernel ids: 0 mlp_fwd(edge) 1 mlp_fwd(other) 2 mlp_bwd(edge) 3 mlp_bwd(other) 4 wgrad 5 seg_fwd 6 seg_bwd
+ *             7 linear_fwd 8 linear_bwd 9 adam 10 csr
+ * ---------------------------------------------------------------------------------------------------- */
+#define HGN_NUM_KERNEL_IDS 12
+int hgn_prof_enable(int on);
+int hgn_prof_reset(void);
+int hgn_prof_collect(double* total_ms /*host [HGN_NUM_KERNEL_IDS]*/, int64_t* count /*host*/,
+                     double* units /*host: rows processed*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

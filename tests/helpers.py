@@ -1,0 +1,72 @@
+"""Shared helpers of the parity tests: run the HIP path and the CPU oracle on identical inputs."""
+import os
+
+import torch
+
+from oracle import mgn_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a-b| / max(|b|_inf, tiny): the '1e-5 relative fp32' metric of BASELINE.json, on the tensor's own scale."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    if a.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def graph_from_fixture(fx):
+    return O.MultiGraph([x.clone() for x in fx['graph']['node_features']],
+                        [O.EdgeSet(n, f.clone(), s.clone(), r.clone()) for n, f, s, r in fx['graph']['edge_sets']])
+
+
+def oracle_run(sd, graph, arch, agg, target, mask, set_order=None, dtype=torch.float64):
+    """fp64 oracle forward + masked-MSE + all gradients (the error budget reference)."""
+    sd = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+    nf = [x.detach().clone().to(dtype).requires_grad_(True) for x in graph.node_features]
+    es = [O.EdgeSet(e.name, e.features.detach().clone().to(dtype).requires_grad_(True), e.senders, e.receivers)
+          for e in graph.edge_sets]
+    out = O.mesh_graph_net(sd, O.MultiGraph(nf, es), arch, agg, set_order=set_order)
+    loss = O.masked_mse(out, target.to(dtype), mask)
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
+    in_grads = {'node': [x.grad for x in nf], 'edge': {e.name: e.features.grad for e in es}}
+    return out.detach(), loss.detach(), grads, in_grads
+
+
+def hip_model(arch, agg, steps, edge_sets, sd, out_size=3, set_order=None):
+    import hgn_amd
+    model = hgn_amd.MeshGraphNet(output_size=out_size, latent_size=128, num_layers=2, message_passing_aggregator=agg,
+                                 message_passing_steps=steps, architecture=arch, edge_sets=list(edge_sets)).to('cuda')
+    missing = model.load_state_dict({k: v.to('cuda') for k, v in sd.items()}, strict=True)
+    if set_order is not None:
+        for blk in model.processor.graphnet_blocks:
+            blk.set_order = list(set_order)
+    return model
+
+
+def hip_run(model, graph, target, mask, index_device='cuda'):
+    import hgn_amd
+    nf = [x.detach().clone().cuda().requires_grad_(True) for x in graph.node_features]
+    es = [hgn_amd.EdgeSet(e.name, e.features.detach().clone().cuda().requires_grad_(True),
+                          e.senders.to(index_device), e.receivers.to(index_device)) for e in graph.edge_sets]
+    model.zero_grad(set_to_none=True)
+    out = model(hgn_amd.MultiGraph(nf, es))
+    loss = torch.nn.functional.mse_loss(target.cuda()[mask.cuda()], out[mask.cuda()])
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+             for k, p in model.named_parameters()}
+    in_grads = {'node': [x.grad for x in nf], 'edge': {e.name: e.features.grad for e in es}}
+    return out.detach(), loss.detach(), grads, in_grads
+
+
+def digest(grads, seed):
+    d = {}
+    for k, g in grads.items():
+        gen = torch.Generator().manual_seed(seed + (O._name_hash(k) % 100003))
+        R = torch.randn((4,) + tuple(g.shape), generator=gen, dtype=torch.float64)
+        gg = g.detach().double().cpu()
+        d[k] = {'proj': (R * gg).flatten(1).sum(1), 'l2': gg.norm(), 'sum': gg.sum()}
+    return d
