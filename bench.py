@@ -1,0 +1,233 @@
+"""Headline benchmark: processed edges/sec (fwd+bwd) on flag_simple-shape meshes (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full training step on this rank's batch of synthetic flag_simple-shape graphs: forward of the 15-layer
+MeshGraphNet (architecture none, latent 128, sum aggregation), masked-MSE loss, backward, gradient all-reduce (N>1)
+and the Adam update.  `value` = (graphs on all ranks x edges per graph) / step time, inputs resident in HBM.
+Rank 0 prints ONE JSON line; it also carries `roofline` (dominant kernel, timed live with HIP events on the launch
+stream) and, at N=1, `cpu_baseline` (the CPU oracle = port of the reference path, timed on this box's host cores on a
+bounded sample: one graph, full depth).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'hyper-graph-nets_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def log(*a):
+    print('[bench]', *a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='graphs per GPU (weak scaling: fixed per-GPU work)')
+    ap.add_argument('--layers', type=int, default=15)
+    ap.add_argument('--agg', default='sum')
+    ap.add_argument('--arch', default='none')
+    ap.add_argument('--nx', type=int, default=40)
+    ap.add_argument('--ny', type=int, default=40)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='do not record per-kernel HIP events in the timed region')
+    return ap.parse_args()
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: min(affinity, cgroup quota, 16 = one GPU's share of the box)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(args, graph1):
+    """The oracle (CPU port of the reference op sequence) on ONE flag_simple-shape graph at full depth, fwd+loss+bwd."""
+    from oracle import mgn_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sets = [e.name for e in graph1.edge_sets]
+    shapes = O.param_shapes(args.arch, args.agg, args.layers, sets, graph1.node_features[0].shape[1],
+                            {e.name: e.features.shape[1] for e in graph1.edge_sets},
+                            graph1.node_features[1].shape[1] if len(graph1.node_features) > 1 else 0, 3, 128)
+    sd = {k: v.requires_grad_(True) for k, v in O.init_state_dict_like(shapes, 0).items()}
+    N = graph1.node_features[0].shape[0]
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(0))
+    mask = torch.ones(N, dtype=torch.bool); mask[:3] = False
+    g = O.MultiGraph(list(graph1.node_features), [O.EdgeSet(*e) for e in graph1.edge_sets])
+    E = sum(e.senders.shape[0] for e in graph1.edge_sets)
+
+    def one():
+        for v in sd.values():
+            v.grad = None
+        out = O.mesh_graph_net(sd, g, args.arch, args.agg)
+        O.masked_mse(out, target, mask).backward()
+    log(f'cpu baseline: {cores} threads')
+    one()
+    iters, t0 = 0, time.perf_counter()
+    while iters < 2 or (time.perf_counter() - t0 < 12.0 and iters < 10):
+        one(); iters += 1
+        log(f'cpu baseline iter {iters}: {time.perf_counter() - t0:.1f} s')
+    dt = (time.perf_counter() - t0) / iters
+    return {'value': E / dt, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 graph ({N} nodes, {E} edges), L={args.layers}, {args.agg}, fwd+loss+bwd, {iters} iters, '
+                      f'{dt:.3f} s/iter, torch {torch.__version__} CPU fp32'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import hgn_amd
+    from hgn_amd import ops, synthetic, parallel, _lib
+    _lib.lib()
+
+    # ---- this rank's shard of the global batch: graphs {g : g mod world == rank}, each with its own seed ----------
+    B = args.batch
+    gids = parallel.shard_indices(B * world, rank, world)
+    graphs = [synthetic.grid_graph(seed=1000 + g, nx=args.nx, ny=args.ny) for g in gids[:min(len(gids), 4)]]
+    while len(graphs) < len(gids):                       # reuse topologies, fresh features (host generation is slow)
+        src = graphs[len(graphs) % 4]
+        gen = torch.Generator().manual_seed(2000 + gids[len(graphs)])
+        graphs.append(synthetic.MultiGraph([torch.randn(x.shape, generator=gen) for x in src.node_features],
+                                           [synthetic.EdgeSet(e.name, torch.randn(e.features.shape, generator=gen), e.senders,
+                                                              e.receivers) for e in src.edge_sets]))
+    big = synthetic.batch(graphs)
+    graph = hgn_amd.MultiGraph([x.to(dev) for x in big.node_features],
+                               [hgn_amd.EdgeSet(e.name, e.features.to(dev), e.senders.to(dev), e.receivers.to(dev))
+                                for e in big.edge_sets])
+    N_nodes = graph.node_features[0].shape[0]
+    E_rank = sum(e.senders.shape[0] for e in graph.edge_sets)
+    E_graph = E_rank // len(gids)
+    target = torch.randn(N_nodes, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
+    node_type = torch.zeros(N_nodes, dtype=torch.bool)
+    per = N_nodes // len(gids)
+    for i in range(len(gids)):
+        node_type[i * per:i * per + 3] = True            # 3 HANDLE nodes per graph are masked out of the loss
+    mask = (~node_type).to(dev)
+
+    torch.manual_seed(0)
+    sets = [e.name for e in graph.edge_sets]
+    model = hgn_amd.MeshGraphNet(output_size=3, latent_size=128, num_layers=2, message_passing_aggregator=args.agg,
+                                 message_passing_steps=args.layers, architecture=args.arch, edge_sets=sets).to(dev)
+    log(f'rank {rank}: batch built: {N_nodes} nodes, {E_rank} edges')
+    with torch.no_grad():
+        model(graph)                                     # materialise lazy layers, build + cache the CSR topology
+    torch.cuda.synchronize()
+    log('first forward done')
+    trainer = parallel.DataParallelTrainer(model, lr=1e-4)
+    n_params = trainer.fp.numel
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(graph, target, mask)
+        if i == 0:
+            torch.cuda.synchronize(); log('first training step done')
+    barrier()
+    log('warmup done')
+    prof = not args.no_prof
+    if prof:
+        ops.prof_reset(); ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(graph, target, mask)
+    barrier()
+    dt = time.perf_counter() - t0
+    log(f'timed region done: {dt:.3f} s for {args.steps} steps')
+    if prof:
+        ops.prof_enable(False)
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    ms_per_step = dt / args.steps * 1e3
+    value = E_rank * world * args.steps / dt
+
+    if rank == 0:
+        res = {'metric': 'processed edges/sec (fwd+bwd) on flag_simple mesh', 'value': value, 'unit': 'edges/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'flag_simple-shape MeshGraphNets baseline: architecture {args.arch}, '
+                                      f'{args.layers} MP layers, latent 128, aggregation {args.agg}, 1xMI355X config; '
+                                      f'{args.nx}x{args.ny} triangulated grid per graph ({per} nodes, {E_graph} directed '
+                                      f'edges); full training step fwd+loss+bwd+allreduce+Adam',
+                          'graphs_per_gpu': B, 'global_batch': B * world, 'edges_per_step': E_rank * world,
+                          'params': n_params, 'parallelism': f'dp{world}', 'loss': float(loss)}}
+        if prof:
+            k = ops.prof_collect()
+            log('profile collected')
+            dom = max(k.items(), key=lambda kv: kv[1]['ms'])
+            kernels = {n: {'ms_per_launch': v['ms'] / v['count'], 'launches_per_step': v['count'] / args.steps,
+                           'share_of_step': v['ms'] / args.steps / ms_per_step} for n, v in k.items()}
+            res['kernels'] = kernels
+            name, v = dom
+            t_launch = v['ms'] / v['count'] * 1e-3
+            rows = v['units'] / v['count']
+            if name.startswith('mlp') or name in ('wgrad', 'wgrad_node', 'linear_fwd', 'linear_bwd'):
+                # flop actually required from this launch per row (three 128x128 products; wgrad: one per task-row);
+                # the reference formulation's 163 840 flop/edge splits between this launch and the node pre-projection
+                per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1}.get(name, 3) * 2 * 128 * 128
+                ach = per_row * rows / t_launch / 1e12
+                res['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
+                                   'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                                   'rows_per_launch': rows, 'ms_per_launch': t_launch * 1e3,
+                                   'flop_per_row': per_row}
+            s = k.get('seg_fwd')
+            if s:
+                # aggregation launches of the forward pass: N_nodes rows each (the backward's sender/receiver sums
+                # share the kernel id and have the same bytes).  Algorithmic bytes, sum: 4*D*E + 4*(N+1) + 4*D*N
+                bytes_launch = 4 * 128 * E_rank + 4 * (N_nodes + 1) + 4 * 128 * N_nodes
+                t = s['ms'] / s['count'] * 1e-3
+                ach = bytes_launch / t / 1e9
+                res['roofline_aggregation'] = {'kernel': 'seg_fwd', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
+                                               'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
+                                               'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args, synthetic.grid_graph(seed=1000, nx=args.nx, ny=args.ny))
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

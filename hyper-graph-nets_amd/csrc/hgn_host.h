@@ -6,7 +6,8 @@
 namespace hgn {
 
 int hgn_fail(int code, const char* msg);          // records msg (thread-local) and returns code
-int hgn_check_launch(const char* what);           // hipGetLastError() -> HGN_OK / HGN_E_LAUNCH
+int hgn_check_launch(const char* what);
+extern thread_local int g_prof_tag;           // hipGetLastError() -> HGN_OK / HGN_E_LAUNCH
 
 // Records a HIP event pair around the launches issued in its scope when profiling is enabled.
 struct ProfScope {

@@ -8,6 +8,7 @@
 namespace hgn {
 
 static thread_local char g_err[512] = "";
+thread_local int g_prof_tag = 0;
 
 int hgn_fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -60,6 +61,7 @@ extern "C" int hgn_prof_enable(int on) {
   g_on = on != 0;
   return HGN_OK;
 }
+extern "C" int hgn_prof_tag(int tag) { g_prof_tag = tag; return HGN_OK; }
 extern "C" int hgn_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& r : g_recs) g_pool.push_back({r.a, r.b});

@@ -205,7 +205,7 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   }
   if (M == 0) {   // no rows: gradients are exactly zero; the kernel still writes zero slabs
   }
-  ProfScope ps(4, (double)M * n_tasks, (hipStream_t)stream);
+  ProfScope ps(g_prof_tag == 1 ? 11 : 4, (double)M * n_tasks, (hipStream_t)stream);
   hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch, (unsigned)n_tasks), dim3(WG), 0, (hipStream_t)stream, wa);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + 255) / 256, (unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, ra);
   return hgn_check_launch("hgn_mlp_wgrad");

@@ -15,7 +15,7 @@ HGN_MAX_WTASK = 16
 NUM_KERNEL_IDS = 12
 OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
 KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
-                'linear_bwd', 'adam', 'csr', 'reserved']
+                'linear_bwd', 'adam', 'csr', 'wgrad_node']
 
 c_f32p = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 c_i32p = C.c_void_p
@@ -78,6 +78,7 @@ _SIGS = {
     'hgn_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
     'hgn_prof_enable': (C.c_int, [C.c_int]),
+    'hgn_prof_tag': (C.c_int, [C.c_int]),
     'hgn_prof_reset': (C.c_int, []),
     'hgn_prof_collect': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

@@ -90,8 +90,9 @@ def _alloc_saves(M, has_ln, dev):
     return z1, z2, xhat, rstd
 
 
-def _run_wgrad(tasks: List[_lib.WTask], M: int, dev):
+def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False):
     L = _lib.lib()
+    L.hgn_prof_tag(0 if edge_level else 1)
     for i in range(0, len(tasks), _lib.HGN_MAX_WTASK):
         chunk = tasks[i:i + _lib.HGN_MAX_WTASK]
         arr = (_lib.WTask * len(chunk))(*chunk)
@@ -309,7 +310,7 @@ class EdgeBlockFn(torch.autograd.Function):
                         db1.data_ptr()),
                  _wtask(1, xhat.data_ptr(), LAT, LAT, None, d_out.data_ptr(), _ld(d_out), LAT, dg.data_ptr(), LAT,
                         dbt.data_ptr())]
-        _run_wgrad(tasks, E, dev)
+        _run_wgrad(tasks, E, dev, edge_level=True)
         # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]
         dP = torch.empty(N, 2 * LAT, device=dev)
         ops = (C.c_int32 * 1)(0)

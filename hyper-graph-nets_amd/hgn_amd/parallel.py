@@ -34,27 +34,28 @@ class FlatParams:
             if isinstance(p, nn.parameter.UninitializedParameter):
                 raise RuntimeError('materialise the lazy layers (run one forward) before flattening')
         self.params = params
-        total = sum(p.numel() for p in params)
-        dev = params[0].device
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
+        # every parameter starts on a 16-byte boundary: the kernels read biases / LayerNorm affine vectors as float4
+        self.offsets = []
+        total = 0
         for p in params:
+            self.offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        dev = params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, off in zip(params, self.offsets):
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
-            off += n
         self.numel = total
 
     def zero_grad(self):
         self.grad.zero_()
-        off = 0
-        for p in self.params:                      # autograd may have replaced .grad (e.g. after set_to_none)
+        for p, off in zip(self.params, self.offsets):     # autograd may have replaced .grad (e.g. after set_to_none)
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + n].view(p.shape)
-            off += n
 
 
 def _torch_adam(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):

@@ -233,7 +233,7 @@ def test_model_vs_reference_golden(path):
     # The golden gradients are the reference's own fp32 numbers; through 15 layers those carry up to ~3e-3 relative
     # rounding noise on the earliest weights (measured against fp64).  So the HIP gradients are required to be at
     # least as close to exact (fp64 oracle) arithmetic as the reference's are, with 5e-5 as the floor.
-    _, _, grads64, _ = H.oracle_run(sd, graph, fx['arch'], fx['agg'], fx['target'], fx['mask'], set_order=order)
+    _, _, grads64, ing64 = H.oracle_run(sd, graph, fx['arch'], fx['agg'], fx['target'], fx['mask'], set_order=order)
     dg, d64 = H.digest(grads, fx['seed']), H.digest(grads64, fx['seed'])
     for k, ref in fx['grad_digest'].items():
         floor = 5e-5 * float(ref['l2']) * (grads[k].numel() ** 0.5) + 1e-9
@@ -242,8 +242,8 @@ def test_model_vs_reference_golden(path):
         assert ours <= max(floor, 1.5 * ref_noise), (k, ours, ref_noise)
         assert float((dg[k]['proj'] - ref['proj']).abs().max()) <= max(floor, 2.5 * ref_noise), k
         assert abs(float(dg[k]['l2'] - ref['l2'])) <= 1e-4 * float(ref['l2']) + 2.5 * abs(float(ref['l2'] - d64[k]['l2'])) + 1e-9, k
-    for x, gref in zip(in_grads['node'], fx['in_grads']['node']):
-        assert H.rel_err(x, gref) <= 5e-5
+    for x, gref, g64 in zip(in_grads['node'], fx['in_grads']['node'], ing64['node']):
+        assert H.rel_err(x, g64) <= max(5e-5, 1.5 * H.rel_err(gref, g64))
 
 
 CASES = [

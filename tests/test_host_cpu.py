@@ -1,0 +1,226 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/hgn_mp.h declares, argument
+validation answers with status codes (no compute), the module tree / state_dict contract, loud failure without a GPU,
+and the data-parallel host logic over gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import mgn_oracle as O
+from tests import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_match_header():
+    from hgn_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'hgn_mp.h')).read()
+    declared = set(re.findall(r'^\s*(?:const\s+char\s*\*|int)\s+(hgn_\w+)\s*\(', header, flags=re.M))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hgn_version() >= 100
+
+
+def test_abi_struct_sizes_match_header_layout():
+    """ctypes mirrors of the C structs: sizes follow the header's field lists under the x86-64 SysV ABI."""
+    from hgn_amd import _lib
+    assert C.sizeof(_lib.Src) == 40 and C.sizeof(_lib.Add) == 24 and C.sizeof(_lib.Dx) == 40
+    assert C.sizeof(_lib.WTask) == 88
+    assert C.sizeof(_lib.MlpFwd) == 8 + 8 + 8 * 40 + 8 + 2 * 24 + 8 * 6 + 8 + 8 * 2 + 8 * 2 + 8 * 2 + 8 * 4
+    assert C.sizeof(_lib.MlpBwd) == 8 + 8 + 8 + 8 + 8 * 7 + 8 + 8 * 3 + 8 + 8 * 40
+
+
+def test_abi_argument_validation_without_gpu():
+    from hgn_amd import _lib
+    lib = _lib.lib()
+    nb = C.c_size_t(0)
+    assert lib.hgn_csr_workspace_bytes(1000, 10, C.byref(nb)) == 0 and nb.value > 8000
+    assert lib.hgn_csr_workspace_bytes(-1, 10, C.byref(nb)) == -1
+    assert lib.hgn_wgrad_workspace_bytes(100000, 4, C.byref(nb)) == 0 and nb.value > 0
+    assert lib.hgn_wgrad_workspace_bytes(10, 99, C.byref(nb)) == -1
+    a = _lib.MlpFwd()
+    a.M = 5
+    a.out_w = 500
+    assert lib.hgn_mlp_fwd(C.byref(a), None) == -1
+    assert b'out_w' in lib.hgn_last_error()
+    ops = (C.c_int32 * 1)(7)
+    assert lib.hgn_segment_reduce_fwd(None, 128, 128, None, None, 4, ops, 1, None, 128, None, None, None) == -1
+    assert b'Invalid operation type' in lib.hgn_last_error()
+    with pytest.raises(_lib.HgnError):
+        _lib.check(-1, 'x')
+    with pytest.raises(IndexError):
+        _lib.check(-3, 'x')
+
+
+def test_module_tree_matches_reference_state_dict_keys():
+    import hgn_amd
+    sets = ['mesh_edges', 'intra_cluster_to_mesh', 'intra_cluster_to_cluster', 'inter_cluster']
+    for arch, agg in (('none', 'sum'), ('hyper', 'pna'), ('hetero', 'pna'), ('multiscale', 'sum'), ('repeated', 'max'),
+                      ('multi', 'min')):
+        use = sets if arch in ('hyper', 'hetero', 'multiscale') else ['mesh_edges']
+        shapes = O.param_shapes(arch, agg, 2, use, 5, {n: 7 for n in use}, 8, 3, 128)
+        m = hgn_amd.MeshGraphNet(3, 128, 2, agg, 2, arch, use)
+        assert all(isinstance(p, torch.nn.parameter.UninitializedParameter) for n, p in m.named_parameters()
+                   if n.endswith('linear_0.weight'))
+        m.load_state_dict(O.init_state_dict_like(shapes, 0), strict=True)        # reference key names, lazy shapes
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dict(shapes)
+    # golden key names come from the reference itself
+    fx = torch.load(os.path.join(ROOT, 'tests', 'golden', 'mgn_hyper_pna_L1_lat128.pt'))
+    m = hgn_amd.MeshGraphNet(3, 128, 2, 'pna', 1, 'hyper', fx['edge_sets'])
+    m.load_state_dict(O.init_state_dict_like(fx['shapes'], 0), strict=True)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import hgn_amd
+    from hgn_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    g = synth.grid_graph(nx=4, ny=4)
+    m = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges'])
+    with pytest.raises(_lib.HgnError, match='no CPU fallback'):
+        m(hgn_amd.MultiGraph(g.node_features, g.edge_sets))
+    with pytest.raises(_lib.HgnError):
+        hgn_amd.unsorted_segment_operation(torch.randn(4, 128), torch.tensor([0, 1, 1, 0]), 2, 'sum')
+    with pytest.raises(_lib.HgnError, match='latent_size=128'):
+        hgn_amd.MeshGraphNet(3, 64, 2, 'sum', 1, 'none', ['mesh_edges'])(hgn_amd.MultiGraph(g.node_features, g.edge_sets))
+
+
+def test_no_product_import_of_oracle():
+    pkg = os.path.join(ROOT, 'hyper-graph-nets_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('# oracle', ''), f'{f} mentions the oracle'
+
+
+def test_normalizer_matches_golden_on_cpu():
+    """Normalizer is host-side element-wise torch code (not a kernel): checked against the reference's G7 vectors."""
+    from hgn_amd.normalizer import Normalizer
+    fx = torch.load(os.path.join(ROOT, 'tests', 'golden', 'g7_normalizer.pt'))
+    nz = Normalizer(5, 't')
+    dev = nz._acc_sum.device
+    for x, y in zip(fx['xs'], fx['ys']):
+        torch.testing.assert_close(nz(x.to(dev), True).cpu(), y, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(nz(fx['xs'][0].to(dev), False).cpu(), fx['y_eval'], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(nz.inverse(fx['ys'][0].to(dev)).cpu(), fx['inv'], rtol=1e-6, atol=1e-6)
+    assert 'acc' not in ''.join(nz.state_dict().keys())            # statistics are not buffers (reference semantics)
+    nz2 = Normalizer(2, 'u', max_accumulations=2)
+    for z, w in zip(fx['zs'], fx['ws']):
+        torch.testing.assert_close(nz2(z.to(dev)).cpu(), w, rtol=1e-6, atol=1e-6)
+
+
+def test_triangles_to_edges_and_batcher():
+    from hgn_amd import util, synthetic
+    faces = synthetic.grid_triangles(4, 3)
+    e = util.triangles_to_edges(faces)
+    s, r = e['two_way_connectivity']
+    assert s.dtype == torch.int64 and s.shape == r.shape
+    pairs = set(zip(s.tolist(), r.tolist()))
+    assert all((b, a) in pairs for a, b in pairs) and len(pairs) == s.shape[0]
+    s2, r2 = synthetic.two_way_edges(faces)
+    assert torch.equal(s, s2) and torch.equal(r, r2)
+    # batching: correct hyper mapping equals the oracle's non-compat mapping
+    gs = [synthetic.grid_graph(seed=i, nx=3, ny=3, clusters=2) for i in range(3)]
+    a = synthetic.batch(gs)
+    b = O.batch_graphs([O.MultiGraph(g.node_features, [O.EdgeSet(*e) for e in g.edge_sets]) for g in gs])
+    for ea, eb in zip(a.edge_sets, b.edge_sets):
+        assert torch.equal(ea.senders, eb.senders) and torch.equal(ea.receivers, eb.receivers)
+
+
+# -------------------------------------------------------------------------------------------------------------
+# data-parallel host logic on gloo, world_size 2: the model is a stand-in (the CPU oracle wrapped as nn.Module) because
+# the product kernels need the GPU; what is tested is sharding, global-mean loss scaling, the single flat all-reduce,
+# the flat Adam bookkeeping and normaliser-statistic reduction.
+# -------------------------------------------------------------------------------------------------------------
+class _OracleNet(torch.nn.Module):
+    def __init__(self, sd):
+        super().__init__()
+        self.keys = list(sd.keys())
+        self.ps = torch.nn.ParameterList([torch.nn.Parameter(v.clone()) for v in sd.values()])
+
+    def forward(self, graph):
+        sd = dict(zip(self.keys, self.ps))
+        return O.mesh_graph_net(sd, graph, 'none', 'sum')
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hgn_amd import parallel, synthetic
+    from hgn_amd.normalizer import Normalizer
+    torch.set_num_threads(1)
+    graphs = [synthetic.grid_graph(seed=10 + i, nx=4, ny=4) for i in range(4)]
+    shapes = O.param_shapes('none', 'sum', 1, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 16)
+    sd = O.init_state_dict_like(shapes, 3 + rank)                 # different per rank: broadcast must fix it
+    model = _OracleNet(sd)
+    tr = parallel.DataParallelTrainer(model, lr=1e-2, adam_fn=parallel._torch_adam)
+    mine = parallel.shard_indices(4, rank, world)
+    g = synthetic.batch([graphs[i] for i in mine])
+    gen = torch.Generator().manual_seed(0)
+    targets = torch.randn(4, 16, 3, generator=gen)
+    masks = torch.ones(4, 16, dtype=torch.bool)
+    masks[0, :5] = False                                           # unequal mask counts across ranks
+    target = torch.cat([targets[i] for i in mine])
+    mask = torch.cat([masks[i] for i in mine])
+    losses = [float(tr.step(O.MultiGraph(g.node_features, [O.EdgeSet(*e) for e in g.edge_sets]), target, mask))
+              for _ in range(3)]
+    nz = Normalizer(3, 'n')
+    parallel.attach_normalizer_sync([nz])
+    y = nz(targets[mine[0]] * (rank + 1.0))
+    if rank == 0:
+        torch.save({'flat': tr.fp.flat.clone(), 'losses': losses, 'acc_sum': nz._acc_sum, 'acc_count': nz._acc_count,
+                    'y': y}, out)
+    flat0 = tr.fp.flat.clone()
+    dist.broadcast(flat0, src=0)
+    assert torch.equal(flat0, tr.fp.flat), 'replicas diverged'
+    dist.destroy_process_group()
+
+
+def test_data_parallel_equals_single_process_on_concatenated_batch(tmp_path):
+    from hgn_amd import parallel, synthetic
+    port = 29500 + (os.getpid() % 2000)
+    out = str(tmp_path / 'dp.pt')
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    # single process on the whole batch, reference semantics: mean over all NORMAL nodes (flag.py:150-152)
+    graphs = [synthetic.grid_graph(seed=10 + i, nx=4, ny=4) for i in range(4)]
+    shapes = O.param_shapes('none', 'sum', 1, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 16)
+    model = _OracleNet(O.init_state_dict_like(shapes, 3))          # rank 0's weights
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    order = parallel.shard_indices(4, 0, 2) + parallel.shard_indices(4, 1, 2)
+    g = synthetic.batch([graphs[i] for i in order])
+    gen = torch.Generator().manual_seed(0)
+    targets = torch.randn(4, 16, 3, generator=gen)
+    masks = torch.ones(4, 16, dtype=torch.bool)
+    masks[0, :5] = False
+    target = torch.cat([targets[i] for i in order])
+    mask = torch.cat([masks[i] for i in order])
+    for step in range(3):
+        opt.zero_grad()
+        outp = model(O.MultiGraph(g.node_features, [O.EdgeSet(*e) for e in g.edge_sets]))
+        loss = O.masked_mse(outp, target, mask)
+        loss.backward()
+        opt.step()
+    flat = torch.cat([torch.nn.functional.pad(p.detach().reshape(-1), (0, (-p.numel()) % 4)) for p in model.parameters()])
+    torch.testing.assert_close(res['flat'], flat, rtol=2e-5, atol=2e-6)
+    # normaliser: both ranks accumulated the union of the two inputs
+    both = torch.cat([targets[0] * 1.0, targets[1] * 2.0])
+    torch.testing.assert_close(res['acc_sum'], both.sum(0), rtol=1e-5, atol=1e-5)
+    assert float(res['acc_count']) == 32.0
+
+
+def test_shard_indices_partition():
+    from hgn_amd import parallel
+    for n, w in ((8, 8), (21, 8), (3, 2), (64, 4)):
+        parts = [parallel.shard_indices(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
