@@ -5,6 +5,19 @@
 
 namespace hgn {
 
+// Diagnostic builds only (-DHGN_STAMP, tools/stamp_build.sh): per-wave s_memtime stamps into a side buffer that no
+// other code reads.  The shipped library is built without it and contains no stamp instruction.
+#ifdef HGN_STAMP
+__device__ unsigned long long* g_stamps = nullptr;
+#define STAMP(i)                                                                                                   \
+  do {                                                                                                             \
+    if (g_stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                                  \
+      g_stamps[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();           \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 __device__ __forceinline__ void relu_inplace(f32x16 (&a)[4]) {
 #pragma unroll
   for (int ob = 0; ob < 4; ++ob)
@@ -16,18 +29,19 @@ __device__ __forceinline__ void relu_inplace(f32x16 (&a)[4]) {
 // forward:  out = [res +] [LN]( W3 relu(W2 relu(z1) + b2) + b3 )
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG, 2) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
-  __shared__ float wlds[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
   const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
   const bool valid = row < a.M;
   const long rc = valid ? row : a.M - 1;
-  const float* wl_n = wlds + m * LDW + 4 * h;
 
   f32x16 acc[4], b[4];
+  STAMP(0);
   // ---- layer 1 ------------------------------------------------------------------------------------------
-  c_load(acc, a.b1, h);
-  for (int i = 0; i < a.n_add; ++i) c_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, h);
+  // Order inside every stage: barrier (LDS free) -> weight DMA in flight -> this wave's global loads in flight ->
+  // one __syncthreads() (vmcnt(0) covers DMA, loads and the previous stage's stores together) -> MFMAs.
+  bool first = true;
   for (int si = 0; si < a.n_src; ++si) {
     const hgn_src_t s = a.src[si];
     const long srow = s.idx ? (long)s.idx[rc] : rc;
@@ -35,30 +49,45 @@ __global__ __launch_bounds__(WG, 2) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
     for (int k0 = 0; k0 < s.K; k0 += 128) {
       const int kw = min(128, s.K - k0);
       const int ncb = (kw + 31) >> 5;
-      __syncthreads();
+      wg_barrier_lds();
       stage_weight(wlds, s.W + k0, a.ldw1, 128, kw, 128, 32 * ncb);
-      __syncthreads();
+      STAMP(1);
       load_bfrag(b, s.x + srow * s.ld + k0, kw, h, vec);
-      mfma_stage<false>(acc, b, wl_n, 4, ncb);
+      if (first) {
+        c_load(acc, a.b1, h);
+        for (int i = 0; i < a.n_add; ++i) c_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, h);
+        first = false;
+      }
+      __syncthreads();
+      STAMP(2);
+      mfma_stage<false>(acc, b, wlds, 4, ncb);
+      STAMP(3);
     }
   }
+  if (first) c_load(acc, a.b1, h);
   relu_inplace(acc);
   if (a.z1 && valid) c_store(acc, a.z1 + row * LAT, h);
   // ---- layer 2 ------------------------------------------------------------------------------------------
-  __syncthreads();
+  wg_barrier_lds();
+  STAMP(4);
   stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
-  __syncthreads();
   c_load(b, a.b2, h);
-  mfma_stage<false>(b, acc, wl_n, 4, 4);      // b now holds layer-2 pre-activations
+  __syncthreads();
+  STAMP(5);
+  mfma_stage<false>(b, acc, wlds, 4, 4);      // b now holds layer-2 pre-activations
+  STAMP(6);
   relu_inplace(b);
   if (a.z2 && valid) c_store(b, a.z2 + row * LAT, h);
   // ---- layer 3 ------------------------------------------------------------------------------------------
   const int nob = (a.out_w + 31) >> 5;
-  __syncthreads();
+  wg_barrier_lds();
+  STAMP(7);
   stage_weight(wlds, a.W3, LAT, a.out_w, 128, 32 * nob, 128);
-  __syncthreads();
   if (a.out_w == LAT) c_load(acc, a.b3, h); else c_load_masked(acc, a.b3, h, a.out_w);
-  mfma_stage<false>(acc, b, wl_n, nob, 4);
+  __syncthreads();
+  STAMP(8);
+  mfma_stage<false>(acc, b, wlds, nob, 4);
+  STAMP(9);
   // ---- LayerNorm (eps 1e-5, biased variance: torch.nn.LayerNorm) + residual -------------------------------
   if (a.ln_g) {
     const float mean = row_sum(acc) * (1.f / LAT);
@@ -97,6 +126,7 @@ __global__ __launch_bounds__(WG, 2) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
       c_store_masked(acc, a.out + row * a.ld_out, h, a.out_w);
     }
   }
+  STAMP(10);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -111,15 +141,15 @@ __device__ __forceinline__ void relu_mask(f32x16 (&g)[4], const float* __restric
 }
 
 __global__ __launch_bounds__(WG, 2) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
-  __shared__ float wlds[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
   const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
   const bool valid = row < a.M;
   const long rc = valid ? row : a.M - 1;
-  const float* wl_t = wlds + 4 * h * LDW + m;
 
   f32x16 g[4], t[4];
+  stage_weight(wlds, a.W3, LAT, a.out_w, 128, 32 * ((a.out_w + 31) >> 5), 128);     // DMA flies under the LayerNorm backward
   const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
   if (vec_out) c_load(g, a.d_out + rc * a.ld_dout, h); else c_load_masked(g, a.d_out + rc * a.ld_dout, h, a.out_w);
   if (a.ln_g) {
@@ -149,18 +179,16 @@ __global__ __launch_bounds__(WG, 2) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
   // ---- dz2 = relu'(z2) * (W3^T dz3) ----------------------------------------------------------------------
   const int ncb3 = (a.out_w + 31) >> 5;
   __syncthreads();
-  stage_weight(wlds, a.W3, LAT, a.out_w, 128, 32 * ncb3, 128);
-  __syncthreads();
   c_zero(t);
-  mfma_stage<true>(t, g, wl_t, 4, ncb3);
+  mfma_stage<true>(t, g, wlds, 4, ncb3);
   relu_mask(t, a.z2 + rc * LAT, h);
   if (a.dz2 && valid) c_store(t, a.dz2 + row * LAT, h);
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
-  __syncthreads();
+  wg_barrier_lds();
   stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
   __syncthreads();
   c_zero(g);
-  mfma_stage<true>(g, t, wl_t, 4, 4);
+  mfma_stage<true>(g, t, wlds, 4, 4);
   relu_mask(g, a.z1 + rc * LAT, h);
   if (a.dz1 && valid) c_store(g, a.dz1 + row * LAT, h);
   // ---- dx_src = dz1 * W1[:, cols]  (+ d_out for the residual source) ---------------------------------------
@@ -169,11 +197,11 @@ __global__ __launch_bounds__(WG, 2) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
     for (int k0 = 0; k0 < d.K; k0 += 128) {
       const int kw = min(128, d.K - k0);
       const int nob = (kw + 31) >> 5;
-      __syncthreads();
+      wg_barrier_lds();
       stage_weight(wlds, d.W + k0, a.ldw1, 128, kw, 128, 32 * nob);
       __syncthreads();
       c_zero(t);
-      mfma_stage<true>(t, g, wl_t, nob, 4);
+      mfma_stage<true>(t, g, wlds, nob, 4);
       if (valid) {
         float* dst = d.dx + row * d.ld + k0;
         if (kw == 128 && (d.ld & 3) == 0) {
@@ -195,7 +223,7 @@ struct LinArgs {
 };
 
 __global__ __launch_bounds__(WG, 2) void linear_fwd_kernel(const LinArgs a) {
-  __shared__ float wlds[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
   const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
@@ -204,18 +232,18 @@ __global__ __launch_bounds__(WG, 2) void linear_fwd_kernel(const LinArgs a) {
   f32x16 acc[4], b[4];
   load_bfrag(b, a.x + rc * a.ldx, 128, h, true);
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    __syncthreads();
+    wg_barrier_lds();
     stage_weight(wlds, a.W[blk], a.ldw, 128, 128, 128, 128);
     __syncthreads();
     c_zero(acc);
-    mfma_stage<false>(acc, b, wlds + m * LDW + 4 * h, 4, 4);
+    mfma_stage<false>(acc, b, wlds, 4, 4);
     if (valid) c_store(acc, a.out + row * a.ld_out + 128 * blk, h);
   }
 }
 
 __global__ __launch_bounds__(WG, 2) void linear_bwd_kernel(const LinArgs a) {
   // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]
-  __shared__ float wlds[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
   const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
@@ -224,11 +252,11 @@ __global__ __launch_bounds__(WG, 2) void linear_bwd_kernel(const LinArgs a) {
   f32x16 acc[4], b[4];
   c_zero(acc);
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    __syncthreads();
+    wg_barrier_lds();
     stage_weight(wlds, a.W[blk], a.ldw, 128, 128, 128, 128);
-    __syncthreads();
     load_bfrag(b, a.x + rc * a.ldx + 128 * blk, 128, h, true);
-    mfma_stage<true>(acc, b, wlds + 4 * h * LDW + m, 4, 4);
+    __syncthreads();
+    mfma_stage<true>(acc, b, wlds, 4, 4);
   }
   if (valid) c_store(acc, a.out + row * a.ld_out, h);
 }
@@ -238,6 +266,12 @@ __global__ __launch_bounds__(WG, 2) void linear_bwd_kernel(const LinArgs a) {
 using namespace hgn;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#ifdef HGN_STAMP
+extern "C" int hgn_debug_set_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(hgn::g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   if (!a) return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: null args");

@@ -17,7 +17,7 @@ constexpr int SLAB = 128 * 128 + 128;             // floats per (task, chunk): d
 struct WTaskDev {
   int type; const float* A; long lda; int K; const int* idxA; const float* G; long ldg; float* slab;
 };
-struct WArgs { WTaskDev t[HGN_MAX_WTASK]; long M; long rows_per_chunk; int n_chunks; };
+struct WArgs { WTaskDev t[HGN_MAX_WTASK]; long M; long rows_per_chunk; int n_chunks; int task0; };
 
 __device__ __forceinline__ void wt_load_tile(float4 (&ra)[4], float4 (&rg)[4], const WTaskDev& t, long row0, long row_end,
                                              bool vecA) {
@@ -57,7 +57,7 @@ __device__ __forceinline__ void wt_store_tile(float* __restrict__ As, float* __r
 
 __global__ __launch_bounds__(WG, 2) void wgrad_kernel(const WArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][WT_ROWS * 128];   // [buf][A|G][32][128]  = 64 KB
-  const WTaskDev t = a.t[blockIdx.y];
+  const WTaskDev t = a.t[a.task0 + blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
   const long row_beg = (long)blockIdx.x * a.rows_per_chunk;
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(WG, 2) void wgrad_kernel(const WArgs a) {
   }
 }
 
-struct RTaskDev { int type; int K; int n_out; float* dW; long ldw; float* db; const float* slab; };
-struct RArgs { RTaskDev t[HGN_MAX_WTASK]; int n_chunks; };
+struct RTaskDev { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; };
+struct RArgs { RTaskDev t[HGN_MAX_WTASK]; };
 
 __global__ void wgrad_reduce_kernel(const RArgs a) {
   const RTaskDev t = a.t[blockIdx.y];
@@ -140,13 +140,20 @@ __global__ void wgrad_reduce_kernel(const RArgs a) {
   } else {
     if (!is_bias && e >= 128) return;
   }
-  float s = 0.f;
-  for (int c = 0; c < a.n_chunks; ++c) s += t.slab[(long)c * SLAB + e];
-  if (t.type == 0) {
-    if (is_bias) t.db[j] = s; else t.dW[(long)j * t.ldw + k] = s;
-  } else {
-    if (is_bias) { if (t.db) t.db[j] = s; } else t.dW[e] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* p = t.slab + e;
+  int c = 0;
+  for (; c + 4 <= t.n_chunks; c += 4) {                      // four independent loads in flight per thread
+    s0 += p[(long)(c + 0) * SLAB]; s1 += p[(long)(c + 1) * SLAB];
+    s2 += p[(long)(c + 2) * SLAB]; s3 += p[(long)(c + 3) * SLAB];
   }
+  for (; c < t.n_chunks; ++c) s0 += p[(long)c * SLAB];
+  const float s = (s0 + s1) + (s2 + s3);
+  float* dst;
+  if (t.type == 0) dst = is_bias ? t.db + j : t.dW + (long)j * t.ldw + k;
+  else dst = is_bias ? t.db + j : t.dW + e;
+  if (t.type != 0 && is_bias && !t.db) return;
+  *dst = t.acc ? *dst + s : s;
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -162,11 +169,18 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[i] -= (lr / bc1) * (mi / denom);
 }
 
-static int chunks_for(long M, int n_tasks) {
-  long c = (M + 63) / 64;
-  long cap = 768 / (n_tasks > 0 ? n_tasks : 1);
-  if (cap < 32) cap = 32;
-  if (c > cap) c = cap;
+// Chunk counts: the MFMA tasks (type 0) get one full round of workgroups (2 per CU x 256 CUs) split evenly over the
+// tasks; the LayerNorm-affine tasks (type 1: no MFMA, pure streaming) are launched separately with many small chunks.
+static int chunks_mfma(long M, int n_tasks) {
+  long c = 512 / (n_tasks > 0 ? n_tasks : 1);
+  const long by_rows = (M + 63) / 64;
+  if (c > by_rows) c = by_rows;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+static int chunks_ln(long M) {
+  long c = (M + 255) / 256;
+  if (c > 1024) c = 1024;
   if (c < 1) c = 1;
   return (int)c;
 }
@@ -177,7 +191,10 @@ using namespace hgn;
 
 extern "C" int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes) {
   if (!bytes || M < 0 || n_tasks < 0 || n_tasks > HGN_MAX_WTASK) return hgn_fail(HGN_E_INVALID, "hgn_wgrad_workspace_bytes: bad argument");
-  *bytes = (size_t)chunks_for(M, n_tasks) * (size_t)n_tasks * SLAB * sizeof(float) + 256;
+  // MFMA tasks share 512 chunks in total, LN tasks use up to 1024 small ones each
+  size_t mf = (size_t)512 * SLAB * sizeof(float);
+  size_t ln = (size_t)chunks_ln(M) * SLAB * sizeof(float) * (size_t)n_tasks;
+  *bytes = mf + ln + 256;
   return HGN_OK;
 }
 
@@ -187,26 +204,40 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   size_t need = 0;
   if (!tasks || hgn_wgrad_workspace_bytes(M, n_tasks, &need) != HGN_OK || !workspace || ws_bytes < need)
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad tasks / workspace too small");
-  const int nch = chunks_for(M, n_tasks);
+  // order: type-0 tasks first, then type-1
+  int order[HGN_MAX_WTASK], n0 = 0, n1 = 0;
+  for (int i = 0; i < n_tasks; ++i) if (tasks[i].type == 0) order[n0++] = i;
+  for (int i = 0; i < n_tasks; ++i) if (tasks[i].type == 1) order[n0 + n1++] = i;
+  if (n0 + n1 != n_tasks) return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad task type");
+  const int nch0 = chunks_mfma(M, n0), nch1 = chunks_ln(M);
   WArgs wa; RArgs ra;
-  wa.M = M; wa.n_chunks = nch; ra.n_chunks = nch;
-  long rpc = (M + nch - 1) / nch;
-  rpc = (rpc + WT_ROWS - 1) / WT_ROWS * WT_ROWS;
-  if (rpc < WT_ROWS) rpc = WT_ROWS;
-  wa.rows_per_chunk = rpc;
+  wa.M = M;
   float* slab = (float*)workspace;
-  for (int i = 0; i < n_tasks; ++i) {
-    const hgn_wtask_t& t = tasks[i];
+  size_t off = 0;
+  for (int q = 0; q < n_tasks; ++q) {
+    const hgn_wtask_t& t = tasks[order[q]];
     if (!t.A || !t.G || !t.dW || t.K < 1 || t.K > 128 || t.n_out < 1 || t.n_out > 128 || (t.ldg & 3) ||
-        ((uintptr_t)t.G & 15) || (t.type != 0 && t.type != 1))
+        ((uintptr_t)t.G & 15))
       return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad task");
-    wa.t[i] = {t.type, t.A, (long)t.lda, t.K, t.idxA, t.G, (long)t.ldg, slab + (size_t)i * nch * SLAB};
-    ra.t[i] = {t.type, t.K, t.n_out, t.dW, (long)t.ldw, t.db, slab + (size_t)i * nch * SLAB};
+    const int nch = q < n0 ? nch0 : nch1;
+    wa.t[q] = {t.type, t.A, (long)t.lda, t.K, t.idxA, t.G, (long)t.ldg, slab + off};
+    ra.t[q] = {t.type, t.K, t.n_out, t.accumulate ? 1 : 0, nch, t.dW, (long)t.ldw, t.db, slab + off};
+    off += (size_t)nch * SLAB;
   }
-  if (M == 0) {   // no rows: gradients are exactly zero; the kernel still writes zero slabs
+  auto rows_per = [&](int nch) {
+    long rpc = (M + nch - 1) / nch;
+    rpc = (rpc + WT_ROWS - 1) / WT_ROWS * WT_ROWS;
+    return rpc < WT_ROWS ? (long)WT_ROWS : rpc;
+  };
+  ProfScope ps(g_prof_tag == 1 ? 11 : 4, (double)M * n0, (hipStream_t)stream);
+  if (n0) {
+    wa.n_chunks = nch0; wa.rows_per_chunk = rows_per(nch0); wa.task0 = 0;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch0, (unsigned)n0), dim3(WG), 0, (hipStream_t)stream, wa);
   }
-  ProfScope ps(g_prof_tag == 1 ? 11 : 4, (double)M * n_tasks, (hipStream_t)stream);
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch, (unsigned)n_tasks), dim3(WG), 0, (hipStream_t)stream, wa);
+  if (n1) {
+    wa.n_chunks = nch1; wa.rows_per_chunk = rows_per(nch1); wa.task0 = n0;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch1, (unsigned)n1), dim3(WG), 0, (hipStream_t)stream, wa);
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + 255) / 256, (unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, ra);
   return hgn_check_launch("hgn_mlp_wgrad");
 }

@@ -51,7 +51,7 @@ class MlpBwd(C.Structure):
 class WTask(C.Structure):
     _fields_ = [('type', C.c_int32), ('A', c_f32p), ('lda', C.c_int64), ('K', C.c_int32), ('idxA', c_i32p),
                 ('G', c_f32p), ('ldg', C.c_int64), ('n_out', C.c_int32), ('dW', c_f32p), ('ldw', C.c_int64),
-                ('db', c_f32p)]
+                ('db', c_f32p), ('accumulate', C.c_int32)]
 
 
 _SIGS = {

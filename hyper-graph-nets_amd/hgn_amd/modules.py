@@ -147,42 +147,32 @@ class GraphNet(nn.Module):
     def _ops(self) -> Tuple[str, ...]:
         return PNA if self.message_passing_aggregator == 'pna' else (self.message_passing_aggregator,)
 
-    def _edge(self, lat: _Latent, feats: Tensor, name: str, h_all: Optional[Tensor] = None) -> Tensor:
+    def _edge(self, lat: _Latent, feats: Tensor, name: str, h_all: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        """-> (updated edge latents, their aggregates over receivers [N_tot, k*128]); one autograd node for both."""
         h_all = lat.h_all() if h_all is None else h_all
-        return ops.edge_block(h_all, feats, lat.topo[name], weights_of(self.edge_models[name], 3 * ops.LAT))
+        return ops.edge_block(h_all, feats, lat.topo[name], weights_of(self.edge_models[name], 3 * ops.LAT), self._ops())
 
-    def _aggregate(self, lat: _Latent, new_edges: 'OrderedDict[str, Tensor]', names: Sequence[str]) -> Optional[Tensor]:
-        names = [n for n in names if n in self.edge_models]                   # graphnet.py:43
-        if not names:
-            return None
-        csrs = [(None, lat.topo[n].r.rowptr, lat.topo[n].rcv) for n in names]
-        return ops.aggregate([new_edges[n] for n in names], csrs, self._ops())
-
-    def _node(self, lat: _Latent, agg: Optional[Tensor], model: nn.Module, which: int):
-        """nodes[which] += LN(MLP([h ; agg][rows of `which`]))   (graphnet.py:47-48,107-108,123-124)."""
+    def _node(self, lat: _Latent, aggs: Sequence[Tensor], model: nn.Module, which: int):
+        """nodes[which] += LN(MLP([h ; agg_1 ; agg_2 ...][rows of `which`]))   (graphnet.py:47-48,107-108,123-124).
+        The concatenation is never materialised: every aggregate is its own K-segment of the first Linear."""
         n_mesh = lat.n_mesh
-        h = lat.nodes[which]
-        srcs = [h]
-        if agg is not None:
-            srcs.append(agg[:n_mesh] if which == 0 else agg[n_mesh:])
+        srcs = [lat.nodes[which]] + [(a[:n_mesh] if which == 0 else a[n_mesh:]) for a in aggs]
         lat.nodes[which] = fused_apply(model, srcs, residual=0)
 
     # -- GraphNet.forward (graphnet.py:72-84) --------------------------------------------------------------------
     def _forward_latent(self, lat: _Latent) -> _Latent:
         h_all = lat.h_all()
-        new_edges = OrderedDict()
+        new_edges, aggs = OrderedDict(), OrderedDict()
         for name, feats in lat.edges.items():
             if name not in self.edge_models:
                 raise KeyError(name)                                           # graphnet.py:32
-            new_edges[name] = self._edge(lat, feats, name, h_all)
-        nodes = list(lat.nodes)
-        out = _Latent(nodes, new_edges, lat.topo)
-        self._update_nodes(out, new_edges)
+            new_edges[name], aggs[name] = self._edge(lat, feats, name, h_all)
+        out = _Latent(list(lat.nodes), new_edges, lat.topo)
+        self._update_nodes(out, aggs)
         return out
 
-    def _update_nodes(self, lat: _Latent, new_edges):
-        agg = self._aggregate(lat, new_edges, list(new_edges.keys()))
-        self._node(lat, agg, self.node_model_cross, 0)
+    def _update_nodes(self, lat: _Latent, aggs):
+        self._node(lat, list(aggs.values()), self.node_model_cross, 0)       # graph order (graphnet.py:43)
 
     def forward(self, graph, mask=None):
         if isinstance(graph, _Latent):
@@ -190,16 +180,15 @@ class GraphNet(nn.Module):
         return to_public(self._forward_latent(to_latent(graph)), graph)
 
     # -- helpers shared by the hierarchical blocks (graphnet.py:86-124) -----------------------------------------
-    def _edges_stage(self, lat: _Latent, src_edges, name: str, new_edges):
+    def _edges_stage(self, lat: _Latent, src_edges, name: str, new_edges, aggs):
         if name not in self.edge_models:                                      # graphnet.py:87-88
             return
         if name not in src_edges:
             raise IndexError(f'edge set {name!r} is registered but missing from the graph')   # graphnet.py:90
-        new_edges[name] = self._edge(lat, src_edges[name], name)
+        new_edges[name], aggs[name] = self._edge(lat, src_edges[name], name)
 
-    def _pick(self, new_edges, pair):
-        names = [n for n in self.set_order if n in pair and n in self.edge_models]
-        return names
+    def _pick(self, aggs, pair):
+        return [aggs[n] for n in self.set_order if n in pair and n in self.edge_models]
 
 
 class MultiGraphNet(GraphNet):
@@ -226,14 +215,10 @@ class HeteroGraphNet(GraphNet):
         super().__init__(model_fn, output_size, message_passing_aggregator, edge_sets)
         self.hyper_node_model_cross = model_fn(output_size)
 
-    def _update_nodes(self, lat, new_edges):
-        agg = self._aggregate(lat, new_edges, list(new_edges.keys()))
-        old = list(lat.nodes)
-        self._node(lat, agg, self.node_model_cross, 0)
-        mesh_new = lat.nodes[0]
-        lat.nodes[0] = old[0]                       # both MLPs read the pre-update rows (heterographnet.py:29-32)
-        self._node(lat, agg, self.hyper_node_model_cross, 1)
-        lat.nodes[0] = mesh_new
+    def _update_nodes(self, lat, aggs):
+        al = list(aggs.values())
+        self._node(lat, al, self.node_model_cross, 0)         # rows of one kind never feed the other kind's MLP input,
+        self._node(lat, al, self.hyper_node_model_cross, 1)   # so the two updates commute (heterographnet.py:29-32)
 
 
 class HyperGraphNet(GraphNet):
@@ -251,21 +236,21 @@ class HyperGraphNet(GraphNet):
     def _forward_latent(self, lat):
         src = lat.edges
         lat = _Latent(list(lat.nodes), src, lat.topo)
-        new = OrderedDict()
+        new, aggs = OrderedDict(), {}
         E = functools.partial(self._edges_stage, lat, src)
-        E('mesh_edges', new); E('world_edges', new)
-        self._node(lat, self._aggregate(lat, new, self._pick(new, ('mesh_edges', 'world_edges'))), self.node_model_cross, 0)
-        E('intra_cluster_to_cluster', new)
-        self._node(lat, self._aggregate(lat, new, ['intra_cluster_to_cluster']), self.hyper_node_model_up, 1)
+        E('mesh_edges', new, aggs); E('world_edges', new, aggs)
+        self._node(lat, self._pick(aggs, ('mesh_edges', 'world_edges')), self.node_model_cross, 0)
+        E('intra_cluster_to_cluster', new, aggs)
+        self._node(lat, [aggs['intra_cluster_to_cluster']], self.hyper_node_model_up, 1)
         for model in self._cross_models():
-            E('inter_cluster', new); E('inter_cluster_world', new)
-            self._node(lat, self._aggregate(lat, new, self._pick(new, ('inter_cluster', 'inter_cluster_world'))), model, 1)
-        E('intra_cluster_to_mesh', new)
-        self._node(lat, self._aggregate(lat, new, ['intra_cluster_to_mesh']), self.node_model_down, 0)
-        self._tail(lat, src, new)
+            E('inter_cluster', new, aggs); E('inter_cluster_world', new, aggs)
+            self._node(lat, self._pick(aggs, ('inter_cluster', 'inter_cluster_world')), model, 1)
+        E('intra_cluster_to_mesh', new, aggs)
+        self._node(lat, [aggs['intra_cluster_to_mesh']], self.node_model_down, 0)
+        self._tail(lat, src, new, aggs)
         return _Latent(lat.nodes, new, lat.topo)
 
-    def _tail(self, lat, src, new):
+    def _tail(self, lat, src, new, aggs):
         pass
 
 
@@ -281,10 +266,10 @@ class MultiScaleGraphNet(HyperGraphNet):
     def _cross_models(self):
         return list(self.hyper_node_models_cross)
 
-    def _tail(self, lat, src, new):
-        self._edges_stage(lat, src, 'mesh_edges', new)
-        self._edges_stage(lat, src, 'world_edges', new)
-        self._node(lat, self._aggregate(lat, new, self._pick(new, ('mesh_edges', 'world_edges'))), self.node_model_cross, 0)
+    def _tail(self, lat, src, new, aggs):
+        self._edges_stage(lat, src, 'mesh_edges', new, aggs)
+        self._edges_stage(lat, src, 'world_edges', new, aggs)
+        self._node(lat, self._pick(aggs, ('mesh_edges', 'world_edges')), self.node_model_cross, 0)
 
 
 # ----------------------------------------------------------------------------------------------------------------

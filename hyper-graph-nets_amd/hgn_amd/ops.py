@@ -102,8 +102,28 @@ def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False):
         _lib.check(L.hgn_mlp_wgrad(arr, len(chunk), M, ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'hgn_mlp_wgrad')
 
 
-def _wtask(typ, A, lda, K, idxA, G, ldg, n_out, dW_ptr, ldw, db_ptr):
+def _grad_targets(wt):
+    """Flat-gradient mode (parallel.FlatParams): a parameter tagged with ``_hgn_grad`` receives its gradient by
+    ACCUMULATION straight into that buffer (zeroed once per step) and autograd gets None for it -- no per-parameter
+    add kernels.  Untagged parameters get a fresh tensor returned to autograd."""
+    return [getattr(t, '_hgn_grad', None) for t in wt]
+
+
+def _grad_bufs(wt, targets):
+    """-> (buffers to write, accumulate flags, values to return to autograd)"""
+    bufs, accs, rets = [], [], []
+    for t, tg in zip(wt, targets):
+        if tg is not None:
+            bufs.append(tg); accs.append(1); rets.append(None)
+        else:
+            b = torch.empty_like(t)
+            bufs.append(b); accs.append(0); rets.append(b)
+    return bufs, accs, rets
+
+
+def _wtask(typ, A, lda, K, idxA, G, ldg, n_out, dW_ptr, ldw, db_ptr, acc=0):
     t = _lib.WTask()
+    t.accumulate = acc
     t.type = typ; t.A = A; t.lda = lda; t.K = K; t.idxA = idxA; t.G = G; t.ldg = ldg
     t.n_out = n_out; t.dW = dW_ptr; t.ldw = ldw; t.db = db_ptr
     return t
@@ -150,6 +170,7 @@ class MLPFn(torch.autograd.Function):
         if train:
             ctx.meta = (n_src, idxs, residual, has_ln, cols, M)
             ctx.saves = saves
+            ctx.targets = _grad_targets(wt)
             ctx.save_for_backward(*srcs, *wt)
         return out
 
@@ -190,11 +211,10 @@ class MLPFn(torch.autograd.Function):
         if M > 0:
             _lib.check(L.hgn_mlp_bwd(C.byref(b), _lib.stream_ptr()), 'hgn_mlp_bwd')
         # ---- parameter gradients -------------------------------------------------------------------------------
-        dw1 = torch.empty_like(w.w1); db1 = torch.empty_like(w.b1)
-        dw2 = torch.empty_like(w.w2); db2 = torch.empty_like(w.b2)
-        dw3 = torch.empty_like(w.w3); db3 = torch.empty_like(w.b3)
-        tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, out_w, dw3.data_ptr(), LAT, db3.data_ptr()),
-                 _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr())]
+        bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
+        dw1, db1, dw2, db2, dw3, db3 = bufs[:6]
+        tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, out_w, dw3.data_ptr(), LAT, db3.data_ptr(), accs[4]),
+                 _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2])]
         first = True
         ldw1 = w.w1.shape[1]
         for i, s in enumerate(srcs):
@@ -203,14 +223,11 @@ class MLPFn(torch.autograd.Function):
                 kw = min(LAT, K - k0)
                 tasks.append(_wtask(0, s.data_ptr() + 4 * k0, _ld(s), kw, idxs[i].data_ptr() if idxs[i] is not None else None,
                                     dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * (cols[i] + k0), ldw1,
-                                    db1.data_ptr() if first else None))
+                                    db1.data_ptr() if first else None, accs[0]))
                 first = False
-        grads_w = [dw1, db1, dw2, db2, dw3, db3]
         if has_ln:
-            dg = torch.empty_like(w.ln_w); dbt = torch.empty_like(w.ln_b)
-            tasks.append(_wtask(1, xhat.data_ptr(), LAT, LAT, None, d_out.data_ptr(), _ld(d_out), LAT, dg.data_ptr(), LAT,
-                                dbt.data_ptr()))
-            grads_w += [dg, dbt]
+            tasks.append(_wtask(1, xhat.data_ptr(), LAT, LAT, None, d_out.data_ptr(), _ld(d_out), LAT, bufs[6].data_ptr(), LAT,
+                                bufs[7].data_ptr(), accs[6]))
         _run_wgrad(tasks, M, dev)
         # ---- un-gather source gradients -----------------------------------------------------------------------
         for i in range(n_src):
@@ -234,10 +251,12 @@ def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequen
 # edge block: split first layer  (h W_s^T)[snd] + (h W_r^T)[rcv] + e W_e^T
 # ------------------------------------------------------------------------------------------------------------
 class EdgeBlockFn(torch.autograd.Function):
-    """e' = e + LN(MLP([h[snd] ; h[rcv] ; e])) with e, e' in receiver-sorted order."""
+    """e' = e + LN(MLP([h[snd] ; h[rcv] ; e])) with e, e' in receiver-sorted order, optionally followed IN THE SAME
+    autograd node by the aggregation of e' over receivers (so that the backward adds d(e') and the scattered d(agg)
+    inside the segment-reduce kernel instead of in a separate pass)."""
 
     @staticmethod
-    def forward(ctx, topo, train, h_all, e, *wt):
+    def forward(ctx, topo, train, agg_ops, h_all, e, *wt):
         w = MLPWeights(*wt)
         w.check()
         if w.w1.shape[1] != 3 * LAT or w.ln_w is None:
@@ -247,13 +266,13 @@ class EdgeBlockFn(torch.autograd.Function):
         _lib.require_gpu(e)
         dev = e.device
         L = _lib.lib()
+        st = _lib.stream_ptr()
         E, N = topo.num_edges, topo.num_nodes
         if e.shape[0] != E or h_all.shape[0] != N:
             raise _lib.HgnError(f'edge block: got {e.shape[0]} edge rows / {h_all.shape[0]} node rows, topology has {E} / {N}')
         P = torch.empty(N, 2 * LAT, device=dev)
         wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
-        _lib.check(L.hgn_linear_fwd(h_all.data_ptr(), _ld(h_all), N, wb, 2, 3 * LAT, P.data_ptr(), 2 * LAT,
-                                    _lib.stream_ptr()), 'hgn_linear_fwd')
+        _lib.check(L.hgn_linear_fwd(h_all.data_ptr(), _ld(h_all), N, wb, 2, 3 * LAT, P.data_ptr(), 2 * LAT, st), 'hgn_linear_fwd')
         out = torch.empty(E, LAT, device=dev)
         a = _lib.MlpFwd()
         a.M = E
@@ -266,24 +285,55 @@ class EdgeBlockFn(torch.autograd.Function):
         saves = _alloc_saves(E, True, dev) if train else None
         _fill_common_fwd(a, w, out, e, saves)
         if E > 0:
-            _lib.check(L.hgn_mlp_fwd(C.byref(a), _lib.stream_ptr()), 'hgn_mlp_fwd')
+            _lib.check(L.hgn_mlp_fwd(C.byref(a), st), 'hgn_mlp_fwd')
+        agg, amax, amin = None, None, None
+        if agg_ops is not None:
+            arr, codes = _ops_array(agg_ops)
+            k = len(codes)
+            agg = torch.empty(N, k * LAT, device=dev)
+            if train and 2 in codes:
+                amax = torch.empty(N, LAT, dtype=torch.int32, device=dev)
+            if train and 3 in codes:
+                amin = torch.empty(N, LAT, dtype=torch.int32, device=dev)
+            _lib.check(L.hgn_segment_reduce_fwd(out.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr(), N, arr, k,
+                                                agg.data_ptr(), k * LAT, amax.data_ptr() if amax is not None else None,
+                                                amin.data_ptr() if amin is not None else None, st), 'hgn_segment_reduce_fwd')
         if train:
+            ctx.set_materialize_grads(False)
             ctx.topo = topo
             ctx.saves = saves
+            ctx.agg = (agg_ops, amax, amin)
+            ctx.targets = _grad_targets(wt)
             ctx.save_for_backward(h_all, e, *wt)
-        return out
+        return (out, agg) if agg_ops is not None else out
 
     @staticmethod
-    def backward(ctx, d_out):
+    def backward(ctx, d_out, d_agg=None):
         topo = ctx.topo
         h_all, e, *wt = ctx.saved_tensors
         w = MLPWeights(*wt)
         z1, z2, xhat, rstd = ctx.saves
+        agg_ops, amax, amin = ctx.agg
         L = _lib.lib()
-        dev = d_out.device
-        d_out = _rowmajor(d_out)
         E, N = topo.num_edges, topo.num_nodes
         st = _lib.stream_ptr()
+        if d_out is None and d_agg is None:
+            return (None,) * (5 + len(wt))
+        dev = (d_out if d_out is not None else d_agg).device
+        if d_out is not None:
+            d_out = _rowmajor(d_out)
+        if d_agg is not None:
+            # dE = d(e') + scatter of d(agg) back to the edges, fused in the segment-reduce backward
+            d_agg = _rowmajor(d_agg)
+            arr, codes = _ops_array(agg_ops)
+            dE = torch.empty(E, LAT, device=dev)
+            _lib.check(L.hgn_segment_reduce_bwd(d_agg.data_ptr(), _ld(d_agg), LAT, None, topo.rcv.data_ptr(),
+                                                topo.r.rowptr.data_ptr(), E, arr, len(codes),
+                                                amax.data_ptr() if amax is not None else None,
+                                                amin.data_ptr() if amin is not None else None,
+                                                d_out.data_ptr() if d_out is not None else None, dE.data_ptr(), LAT, st),
+                       'hgn_segment_reduce_bwd')
+            d_out = dE
         dz3 = torch.empty(E, LAT, device=dev)
         dz2 = torch.empty(E, LAT, device=dev)
         dz1 = torch.empty(E, LAT, device=dev)
@@ -300,16 +350,14 @@ class EdgeBlockFn(torch.autograd.Function):
         d.W = w.w1.data_ptr() + 4 * 2 * LAT; d.K = LAT; d.dx = de.data_ptr(); d.ld = LAT; d.residual = 1
         if E > 0:
             _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
-        dw1 = torch.empty_like(w.w1); db1 = torch.empty_like(w.b1)
-        dw2 = torch.empty_like(w.w2); db2 = torch.empty_like(w.b2)
-        dw3 = torch.empty_like(w.w3); db3 = torch.empty_like(w.b3)
-        dg = torch.empty_like(w.ln_w); dbt = torch.empty_like(w.ln_b)
-        tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, LAT, dw3.data_ptr(), LAT, db3.data_ptr()),
-                 _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr()),
+        bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
+        dw1, db1, dw2, db2, dw3, db3, dg, dbt = bufs
+        tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, LAT, dw3.data_ptr(), LAT, db3.data_ptr(), accs[4]),
+                 _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2]),
                  _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
-                        db1.data_ptr()),
+                        db1.data_ptr(), accs[0]),
                  _wtask(1, xhat.data_ptr(), LAT, LAT, None, d_out.data_ptr(), _ld(d_out), LAT, dg.data_ptr(), LAT,
-                        dbt.data_ptr())]
+                        dbt.data_ptr(), accs[6])]
         _run_wgrad(tasks, E, dev, edge_level=True)
         # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]
         dP = torch.empty(N, 2 * LAT, device=dev)
@@ -318,22 +366,24 @@ class EdgeBlockFn(torch.autograd.Function):
                                             ops, 1, dP.data_ptr(), 2 * LAT, None, None, st), 'segment_reduce(senders)')
         _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr(), N, ops, 1,
                                             dP.data_ptr() + 4 * LAT, 2 * LAT, None, None, st), 'segment_reduce(receivers)')
-        tasks = [_wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr(), 2 * LAT, LAT, dw1.data_ptr(), 3 * LAT, None),
+        tasks = [_wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr(), 2 * LAT, LAT, dw1.data_ptr(), 3 * LAT, None,
+                        accs[0]),
                  _wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr() + 4 * LAT, 2 * LAT, LAT,
-                        dw1.data_ptr() + 4 * LAT, 3 * LAT, None)]
+                        dw1.data_ptr() + 4 * LAT, 3 * LAT, None, accs[0])]
         _run_wgrad(tasks, N, dev)
         dh = None
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[3]:
             dh = torch.empty(N, LAT, device=dev)
             wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
             _lib.check(L.hgn_linear_bwd(dP.data_ptr(), 2 * LAT, N, wb, 2, 3 * LAT, dh.data_ptr(), LAT, st), 'hgn_linear_bwd')
-        return (None, None, dh, de, dw1, db1, dw2, db2, dw3, db3, dg, dbt)
+        return (None, None, None, dh, de, *grads_w)
 
 
-def edge_block(h_all: torch.Tensor, e_sorted: torch.Tensor, topo, w: MLPWeights) -> torch.Tensor:
+def edge_block(h_all: torch.Tensor, e_sorted: torch.Tensor, topo, w: MLPWeights, agg_ops=None):
+    """-> e'   or, with ``agg_ops`` (e.g. ('sum',) or the four PNA ops),  (e', agg[N, len(ops)*128])."""
     wt = w.tensors()
     train = torch.is_grad_enabled() and any(t.requires_grad for t in [h_all, e_sorted] + wt)
-    return EdgeBlockFn.apply(topo, train, h_all, e_sorted, *wt)
+    return EdgeBlockFn.apply(topo, train, tuple(agg_ops) if agg_ops is not None else None, h_all, e_sorted, *wt)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -48,6 +48,7 @@ class FlatParams:
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+            p._hgn_grad = p.grad          # the kernels accumulate straight into this view (ops._grad_targets)
         self.numel = total
 
     def zero_grad(self):

@@ -143,7 +143,9 @@ int hgn_mlp_bwd(const hgn_mlp_bwd_t* args /*host*/, void* stream);
 /* Weight / bias / LayerNorm-affine gradients: a list of tasks reduced over all rows in one launch.
  *   type 0:  dW[j][k] = sum_i G[i][j] * A[idxA ? idxA[i] : i][k]   (j < 128, k < K <= 128),  db[j] = sum_i G[i][j]
  *   type 1:  dgamma[j] = sum_i G[i][j] * A[i][j],  dbeta[j] = sum_i G[i][j]        (A = xhat, G = d_out)
- * Results overwrite dW/db (dgamma/dbeta).  Deterministic (per-chunk slabs + fixed-order reduction). */
+ * Results overwrite dW/db (dgamma/dbeta), or are ADDED to them when `accumulate` is set (gradient buffers shared by
+ * several uses of one module, or a flat gradient buffer zeroed once per step).  Deterministic (per-chunk slabs +
+ * fixed-order reduction). */
 typedef struct {
   int32_t type;
   const float* A; int64_t lda; int32_t K; const int32_t* idxA;
@@ -151,6 +153,7 @@ typedef struct {
   int32_t n_out;        /* rows of dW to write (<=128)                                  */
   float* dW; int64_t ldw;   /* type 0: &dW1[0][col0], leading dim; type 1: dgamma        */
   float* db;                /* nullable; type 1: dbeta                                   */
+  int32_t accumulate;       /* 0: dW = result, 1: dW += result                           */
 } hgn_wtask_t;
 
 int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes /*host*/);
