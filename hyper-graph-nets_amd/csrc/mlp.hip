@@ -9,38 +9,40 @@ namespace hgn {
 // other code reads.  The shipped library is built without it and contains no stamp instruction.
 #ifdef HGN_STAMP
 __device__ unsigned long long* g_stamps = nullptr;
+__device__ int g_flags = 0;     // ablations: 1 skip MFMA, 2 skip stores, 4 skip gathers, 8 skip row loads, 16 skip DMA, 32 skip barriers
 #define STAMP(i)                                                                                                   \
   do {                                                                                                             \
     if (g_stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                                  \
-      g_stamps[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();           \
+      g_stamps[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();           \
   } while (0)
+#define ABL(bit) (g_flags & (bit))
 #else
 #define STAMP(i)
+#define ABL(bit) false
 #endif
 
-__device__ __forceinline__ void relu_inplace(f32x16 (&a)[4]) {
+__device__ __forceinline__ void relu_inplace(Act& a) {
+  HGN_FOR_B(fb)
 #pragma unroll
-  for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) a[ob][s] = fmaxf(a[ob][s], 0.f);
+  for (int u = 0; u < 4; ++u) a.v[fb][u] = fmaxf(a.v[fb][u], 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // forward:  out = [res +] [LN]( W3 relu(W2 relu(z1) + b2) + b3 )
+// Order inside every stage: barrier (LDS free) -> weight DMA in flight -> this wave's global loads in flight ->
+// one __syncthreads() (vmcnt(0) covers DMA, loads and the previous stage's stores together) -> MFMAs.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG, 2) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
+__global__ __launch_bounds__(WG, 4) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
   __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = lane & 31, h = lane >> 5;
-  const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
+  const int n = lane & 15, kq = lane >> 4;
+  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
   const bool valid = row < a.M;
   const long rc = valid ? row : a.M - 1;
 
-  f32x16 acc[4], b[4];
+  Act acc, b;
   STAMP(0);
   // ---- layer 1 ------------------------------------------------------------------------------------------
-  // Order inside every stage: barrier (LDS free) -> weight DMA in flight -> this wave's global loads in flight ->
-  // one __syncthreads() (vmcnt(0) covers DMA, loads and the previous stage's stores together) -> MFMAs.
   bool first = true;
   for (int si = 0; si < a.n_src; ++si) {
     const hgn_src_t s = a.src[si];
@@ -48,82 +50,76 @@ __global__ __launch_bounds__(WG, 2) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
     const bool vec = ((s.ld & 3) == 0) && ((s.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
     for (int k0 = 0; k0 < s.K; k0 += 128) {
       const int kw = min(128, s.K - k0);
-      const int ncb = (kw + 31) >> 5;
-      wg_barrier_lds();
-      stage_weight(wlds, s.W + k0, a.ldw1, 128, kw, 128, 32 * ncb);
+      const int ncb = (kw + 15) >> 4;
+      if (!ABL(32)) wg_barrier_lds();
+      if (!ABL(16)) stage_weight(wlds, s.W + k0, a.ldw1, 128, kw, 128, 16 * ncb);
       STAMP(1);
-      load_bfrag(b, s.x + srow * s.ld + k0, kw, h, vec);
+      const float* xr = s.x + srow * s.ld + k0;
+      if (ABL(8)) t_zero(b);
+      else if (vec) { if (kw == 128) t_load(b, xr, kq); else t_load_w(b, xr, kq, kw); } else t_load_masked(b, xr, kq, kw);
       if (first) {
-        c_load(acc, a.b1, h);
-        for (int i = 0; i < a.n_add; ++i) c_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, h);
+        t_load(acc, a.b1, kq);
+        if (!ABL(4)) for (int i = 0; i < a.n_add; ++i) t_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, kq);
         first = false;
       }
-      __syncthreads();
+      if (!ABL(32)) __syncthreads();
       STAMP(2);
-      mfma_stage<false>(acc, b, wlds, 4, ncb);
+      if (!ABL(1)) mfma_stage<false>(acc, b, wlds, NB, ncb);
       STAMP(3);
     }
   }
-  if (first) c_load(acc, a.b1, h);
+  if (first) t_load(acc, a.b1, kq);
   relu_inplace(acc);
-  if (a.z1 && valid) c_store(acc, a.z1 + row * LAT, h);
+  if (a.z1 && valid && !ABL(2)) t_store(acc, a.z1 + row * LAT, kq);
   // ---- layer 2 ------------------------------------------------------------------------------------------
-  wg_barrier_lds();
+  if (!ABL(32)) wg_barrier_lds();
   STAMP(4);
-  stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
-  c_load(b, a.b2, h);
-  __syncthreads();
+  if (!ABL(16)) stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
+  t_load(b, a.b2, kq);
+  if (!ABL(32)) __syncthreads();
   STAMP(5);
-  mfma_stage<false>(b, acc, wlds, 4, 4);      // b now holds layer-2 pre-activations
+  if (!ABL(1)) mfma_stage<false>(b, acc, wlds, NB, NB);      // b now holds layer-2 pre-activations
   STAMP(6);
   relu_inplace(b);
-  if (a.z2 && valid) c_store(b, a.z2 + row * LAT, h);
+  if (a.z2 && valid && !ABL(2)) t_store(b, a.z2 + row * LAT, kq);
   // ---- layer 3 ------------------------------------------------------------------------------------------
-  const int nob = (a.out_w + 31) >> 5;
-  wg_barrier_lds();
+  const int nob = (a.out_w + 15) >> 4;
+  if (!ABL(32)) wg_barrier_lds();
   STAMP(7);
-  stage_weight(wlds, a.W3, LAT, a.out_w, 128, 32 * nob, 128);
-  if (a.out_w == LAT) c_load(acc, a.b3, h); else c_load_masked(acc, a.b3, h, a.out_w);
-  __syncthreads();
+  if (!ABL(16)) stage_weight(wlds, a.W3, LAT, a.out_w, 128, 16 * nob, 128);
+  if (a.out_w == LAT) t_load(acc, a.b3, kq); else t_load_masked(acc, a.b3, kq, a.out_w);
+  if (!ABL(32)) __syncthreads();
   STAMP(8);
-  mfma_stage<false>(acc, b, wlds, nob, 4);
+  if (!ABL(1)) mfma_stage<false>(acc, b, wlds, nob, NB);
   STAMP(9);
   // ---- LayerNorm (eps 1e-5, biased variance: torch.nn.LayerNorm) + residual -------------------------------
   if (a.ln_g) {
     const float mean = row_sum(acc) * (1.f / LAT);
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-      for (int s = 0; s < 16; ++s) { acc[ob][s] -= mean; b[ob][s] = acc[ob][s] * acc[ob][s]; }
+    HGN_FOR_B(fb) {
+      acc.v[fb] -= mean;
+      b.v[fb] = acc.v[fb] * acc.v[fb];
+    }
     const float var = row_sum(b) * (1.f / LAT);
     const float rstd = 1.f / sqrtf(var + 1e-5f);
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-      for (int s = 0; s < 16; ++s) acc[ob][s] *= rstd;
-    if (a.xhat && valid) c_store(acc, a.xhat + row * LAT, h);
-    if (a.rstd && valid && h == 0) a.rstd[row] = rstd;
-    HGN_FOR_C(ob, g) {
-      const int col = 32 * ob + 8 * g + 4 * h;
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + col);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + col);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[ob][4 * g + u] = acc[ob][4 * g + u] * gm[u] + bt[u];
+    HGN_FOR_B(fb) acc.v[fb] *= rstd;
+    if (a.xhat && valid && !ABL(2)) t_store(acc, a.xhat + row * LAT, kq);
+    if (a.rstd && valid && kq == 0) a.rstd[row] = rstd;
+    HGN_FOR_B(fb) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 16 * fb + 4 * kq);
+      acc.v[fb] = acc.v[fb] * gm + bt;
     }
   }
   if (valid) {
     if (a.out_w == LAT && (a.ld_out & 3) == 0) {
-      if (a.res) c_add(acc, a.res + row * a.ld_res, h);
-      c_store(acc, a.out + row * a.ld_out, h);
+      if (a.res && !ABL(8)) t_add(acc, a.res + row * a.ld_res, kq);
+      if (!ABL(2) || (n == 0 && kq == 0)) t_store(acc, a.out + row * a.ld_out, kq);
     } else {
       if (a.res) {
-        c_load_masked(b, a.res + row * a.ld_res, h, a.out_w);
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-          for (int s = 0; s < 16; ++s) acc[ob][s] += b[ob][s];
+        t_load_masked(b, a.res + row * a.ld_res, kq, a.out_w);
+        HGN_FOR_B(fb) acc.v[fb] += b.v[fb];
       }
-      c_store_masked(acc, a.out + row * a.ld_out, h, a.out_w);
+      t_store_masked(acc, a.out + row * a.ld_out, kq, a.out_w);
     }
   }
   STAMP(10);
@@ -132,83 +128,71 @@ __global__ __launch_bounds__(WG, 2) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
 // ---------------------------------------------------------------------------------------------------------
 // backward (data gradients)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void relu_mask(f32x16 (&g)[4], const float* __restrict__ zrow, int h) {
-  HGN_FOR_C(ob, q) {
-    const f32x4 z = *reinterpret_cast<const f32x4*>(zrow + 32 * ob + 8 * q + 4 * h);
+__device__ __forceinline__ void relu_mask(Act& g, const float* __restrict__ zrow, int kq) {
+  HGN_FOR_B(fb) {
+    const f32x4 z = *reinterpret_cast<const f32x4*>(zrow + 16 * fb + 4 * kq);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) g[ob][4 * q + u] = z[u] > 0.f ? g[ob][4 * q + u] : 0.f;
+    for (int u = 0; u < 4; ++u) g.v[fb][u] = z[u] > 0.f ? g.v[fb][u] : 0.f;
   }
 }
 
-__global__ __launch_bounds__(WG, 2) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
+__global__ __launch_bounds__(WG, 4) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
   __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = lane & 31, h = lane >> 5;
-  const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
+  const int n = lane & 15, kq = lane >> 4;
+  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
   const bool valid = row < a.M;
   const long rc = valid ? row : a.M - 1;
 
-  f32x16 g[4], t[4];
-  stage_weight(wlds, a.W3, LAT, a.out_w, 128, 32 * ((a.out_w + 31) >> 5), 128);     // DMA flies under the LayerNorm backward
+  Act g, t;
+  const int ncb3 = (a.out_w + 15) >> 4;
+  stage_weight(wlds, a.W3, LAT, a.out_w, 128, 16 * ncb3, 128);     // DMA flies under the LayerNorm backward
   const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
-  if (vec_out) c_load(g, a.d_out + rc * a.ld_dout, h); else c_load_masked(g, a.d_out + rc * a.ld_dout, h, a.out_w);
+  if (vec_out) t_load(g, a.d_out + rc * a.ld_dout, kq); else t_load_masked(g, a.d_out + rc * a.ld_dout, kq, a.out_w);
   if (a.ln_g) {
     // y = xhat*gamma + beta ;  dz3 = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat))
-    c_load(t, a.xhat + rc * LAT, h);
-    HGN_FOR_C(ob, q) {
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 32 * ob + 8 * q + 4 * h);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) g[ob][4 * q + u] *= gm[u];
-    }
+    t_load(t, a.xhat + rc * LAT, kq);
+    HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
     const float m1 = row_sum(g) * (1.f / LAT);
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      p0 += g[0][s] * t[0][s]; p1 += g[1][s] * t[1][s]; p2 += g[2][s] * t[2][s]; p3 += g[3][s] * t[3][s];
-    }
-    float pp = (p0 + p1) + (p2 + p3);
-    pp += __shfl_xor(pp, 32);
-    const float m2 = pp * (1.f / LAT);
+    Act p;
+    HGN_FOR_B(fb) p.v[fb] = g.v[fb] * t.v[fb];
+    const float m2 = row_sum(p) * (1.f / LAT);
     const float r = a.rstd[rc];
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-      for (int s = 0; s < 16; ++s) g[ob][s] = r * (g[ob][s] - m1 - t[ob][s] * m2);
+    HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
   }
-  if (a.dz3 && valid) c_store(g, a.dz3 + row * LAT, h);
+  if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
   // ---- dz2 = relu'(z2) * (W3^T dz3) ----------------------------------------------------------------------
-  const int ncb3 = (a.out_w + 31) >> 5;
   __syncthreads();
-  c_zero(t);
-  mfma_stage<true>(t, g, wlds, 4, ncb3);
-  relu_mask(t, a.z2 + rc * LAT, h);
-  if (a.dz2 && valid) c_store(t, a.dz2 + row * LAT, h);
+  t_zero(t);
+  mfma_stage<true>(t, g, wlds, NB, ncb3);
+  relu_mask(t, a.z2 + rc * LAT, kq);
+  if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
   wg_barrier_lds();
   stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
   __syncthreads();
-  c_zero(g);
-  mfma_stage<true>(g, t, wlds, 4, 4);
-  relu_mask(g, a.z1 + rc * LAT, h);
-  if (a.dz1 && valid) c_store(g, a.dz1 + row * LAT, h);
+  t_zero(g);
+  mfma_stage<true>(g, t, wlds, NB, NB);
+  relu_mask(g, a.z1 + rc * LAT, kq);
+  if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
   // ---- dx_src = dz1 * W1[:, cols]  (+ d_out for the residual source) ---------------------------------------
   for (int di = 0; di < a.n_dx; ++di) {
     const hgn_dx_t d = a.dx[di];
     for (int k0 = 0; k0 < d.K; k0 += 128) {
       const int kw = min(128, d.K - k0);
-      const int nob = (kw + 31) >> 5;
+      const int nob = (kw + 15) >> 4;
       wg_barrier_lds();
-      stage_weight(wlds, d.W + k0, a.ldw1, 128, kw, 128, 32 * nob);
+      stage_weight(wlds, d.W + k0, a.ldw1, 128, kw, 128, 16 * nob);
       __syncthreads();
-      c_zero(t);
-      mfma_stage<true>(t, g, wlds, nob, 4);
+      t_zero(t);
+      mfma_stage<true>(t, g, wlds, nob, NB);
       if (valid) {
         float* dst = d.dx + row * d.ld + k0;
         if (kw == 128 && (d.ld & 3) == 0) {
-          if (d.residual) c_add(t, a.d_out + row * a.ld_dout, h);
-          c_store(t, dst, h);
+          if (d.residual) t_add(t, a.d_out + row * a.ld_dout, kq);
+          t_store(t, dst, kq);
         } else {
-          c_store_masked(t, dst, h, kw);      // residual sources are always 128 wide (latent)
+          t_store_masked(t, dst, kq, kw);      // residual sources are always 128 wide (latent)
         }
       }
     }
@@ -222,43 +206,43 @@ struct LinArgs {
   const float* x; long ldx; long M; const float* W[4]; int n_blocks; long ldw; float* out; long ld_out;
 };
 
-__global__ __launch_bounds__(WG, 2) void linear_fwd_kernel(const LinArgs a) {
+__global__ __launch_bounds__(WG, 4) void linear_fwd_kernel(const LinArgs a) {
   __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = lane & 31, h = lane >> 5;
-  const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
+  const int n = lane & 15, kq = lane >> 4;
+  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
   const bool valid = row < a.M;
   const long rc = valid ? row : a.M - 1;
-  f32x16 acc[4], b[4];
-  load_bfrag(b, a.x + rc * a.ldx, 128, h, true);
+  Act acc, b;
+  t_load(b, a.x + rc * a.ldx, kq);
   for (int blk = 0; blk < a.n_blocks; ++blk) {
     wg_barrier_lds();
     stage_weight(wlds, a.W[blk], a.ldw, 128, 128, 128, 128);
     __syncthreads();
-    c_zero(acc);
-    mfma_stage<false>(acc, b, wlds, 4, 4);
-    if (valid) c_store(acc, a.out + row * a.ld_out + 128 * blk, h);
+    t_zero(acc);
+    mfma_stage<false>(acc, b, wlds, NB, NB);
+    if (valid) t_store(acc, a.out + row * a.ld_out + 128 * blk, kq);
   }
 }
 
-__global__ __launch_bounds__(WG, 2) void linear_bwd_kernel(const LinArgs a) {
+__global__ __launch_bounds__(WG, 4) void linear_bwd_kernel(const LinArgs a) {
   // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]
   __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = lane & 31, h = lane >> 5;
-  const long row = (long)blockIdx.x * TILE_ROWS + wave * 32 + m;
+  const int n = lane & 15, kq = lane >> 4;
+  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
   const bool valid = row < a.M;
   const long rc = valid ? row : a.M - 1;
-  f32x16 acc[4], b[4];
-  c_zero(acc);
+  Act acc, b;
+  t_zero(acc);
   for (int blk = 0; blk < a.n_blocks; ++blk) {
     wg_barrier_lds();
     stage_weight(wlds, a.W[blk], a.ldw, 128, 128, 128, 128);
-    load_bfrag(b, a.x + rc * a.ldx + 128 * blk, 128, h, true);
+    t_load(b, a.x + rc * a.ldx + 128 * blk, kq);
     __syncthreads();
-    mfma_stage<true>(acc, b, wlds, 4, 4);
+    mfma_stage<true>(acc, b, wlds, NB, NB);
   }
-  if (valid) c_store(acc, a.out + row * a.ld_out, h);
+  if (valid) t_store(acc, a.out + row * a.ld_out, kq);
 }
 
 }  // namespace hgn
@@ -268,6 +252,9 @@ using namespace hgn;
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #ifdef HGN_STAMP
+extern "C" int hgn_debug_set_flags(int f) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(hgn::g_flags), &f, sizeof(f)) == hipSuccess ? 0 : -2;
+}
 extern "C" int hgn_debug_set_stamps(void* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(hgn::g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -2;
 }

@@ -6,10 +6,15 @@
 // Each workgroup owns a contiguous chunk of rows and keeps its 32x128 slice-per-wave of dW in accumulators
 // across the whole chunk; chunk partials go to slabs that a second kernel adds in fixed order (deterministic,
 // no float atomics -- MI355X global float atomics run at ~1.3 TB/s and are order dependent).
-#include "hgn_device.h"
+#include <hip/hip_runtime.h>
 #include "hgn_host.h"
 
 namespace hgn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int WGW = 256;                          // 4 waves: wave w owns dW rows [32w, 32w+32)
+// row of a 32x32 MFMA C/D tile held by register r of lane half h:  rho0(r) + 4*h
+__device__ __forceinline__ constexpr int rho0(int r) { return (r & 3) + 8 * (r >> 2); }
 
 constexpr int WT_ROWS = 32;                       // rows per LDS tile
 constexpr int SLAB = 128 * 128 + 128;             // floats per (task, chunk): dW partial + colsum partial
@@ -55,7 +60,7 @@ __device__ __forceinline__ void wt_store_tile(float* __restrict__ As, float* __r
   }
 }
 
-__global__ __launch_bounds__(WG, 2) void wgrad_kernel(const WArgs a) {
+__global__ __launch_bounds__(WGW, 2) void wgrad_kernel(const WArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][WT_ROWS * 128];   // [buf][A|G][32][128]  = 64 KB
   const WTaskDev t = a.t[a.task0 + blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,7 +73,10 @@ __global__ __launch_bounds__(WG, 2) void wgrad_kernel(const WArgs a) {
   const int cs_col = threadIdx.x & 127, cs_half = threadIdx.x >> 7;
 
   f32x16 acc[4];
-  c_zero(acc);
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
   float cs0 = 0.f, cs1 = 0.f;       // column sums: type 0: sum G ; type 1: sum G*A (cs0) and sum G (cs1)
   float4 ra[4], rg[4];
   if (row_beg < row_end) {
@@ -232,11 +240,11 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   ProfScope ps(g_prof_tag == 1 ? 11 : 4, (double)M * n0, (hipStream_t)stream);
   if (n0) {
     wa.n_chunks = nch0; wa.rows_per_chunk = rows_per(nch0); wa.task0 = 0;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch0, (unsigned)n0), dim3(WG), 0, (hipStream_t)stream, wa);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch0, (unsigned)n0), dim3(WGW), 0, (hipStream_t)stream, wa);
   }
   if (n1) {
     wa.n_chunks = nch1; wa.rows_per_chunk = rows_per(nch1); wa.task0 = n0;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch1, (unsigned)n1), dim3(WG), 0, (hipStream_t)stream, wa);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch1, (unsigned)n1), dim3(WGW), 0, (hipStream_t)stream, wa);
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + 255) / 256, (unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, ra);
   return hgn_check_launch("hgn_mlp_wgrad");

@@ -277,13 +277,22 @@ def test_model_vs_oracle(arch, agg, steps, sets, gkw, index_device):
     if arch == 'hetero':
         nsn = {'node_model_cross': len(sets), 'hyper_node_model_cross': len(sets)}
     shapes = O.param_shapes(arch, agg, steps, sets, graph.node_features[0].shape[1], edge_in, hyper_in, 3, 128, nsn)
-    sd = O.init_state_dict_like(shapes, seed=11)
     N = graph.node_features[0].shape[0]
     gen = torch.Generator().manual_seed(1)
     target = torch.randn(N, 3, generator=gen)
     mask = torch.ones(N, dtype=torch.bool); mask[:3] = False
     order = ['mesh_edges', 'world_edges', 'inter_cluster', 'inter_cluster_world']
-    out_o, loss_o, grads_o, ing_o = H.oracle_run(sd, graph, arch, agg, target, mask, set_order=order)
+    # max/min route a gradient to ONE arg element: when the two best candidates of some segment differ by less than
+    # fp32 rounding, which one wins is implementation dependent (the fp32 and fp64 oracles themselves then disagree
+    # by ~1e-2).  Such ill-conditioned instances say nothing about parity: pick the first well-conditioned seed.
+    for wseed in range(11, 20):
+        sd = O.init_state_dict_like(shapes, seed=wseed)
+        out_o, loss_o, grads_o, ing_o = H.oracle_run(sd, graph, arch, agg, target, mask, set_order=order)
+        if agg not in ('pna', 'max', 'min'):
+            break
+        g32 = H.oracle_run(sd, graph, arch, agg, target, mask, set_order=order, dtype=torch.float32)[2]
+        if max(H.rel_err(g32[k], grads_o[k]) for k in grads_o if float(grads_o[k].abs().max()) > 0) < 1e-5:
+            break
     model = H.hip_model(arch, agg, steps, sets, sd, set_order=order)
     out, loss, grads, ing = H.hip_run(model, graph, target, mask, index_device=index_device)
     assert H.rel_err(out, out_o) <= TOL_OUT
