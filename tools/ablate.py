@@ -5,7 +5,7 @@ for p in (ROOT, os.path.join(ROOT, 'hyper-graph-nets_amd')):
     sys.path.insert(0, p)
 import torch
 from hgn_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'gpurun_out', 'libhgn_mp_stamp.so')
+_lib.LIB_PATH = os.path.join(ROOT, 'tools', '_build', 'libhgn_mp_stamp.so')
 from hgn_amd import ops, topology, synthetic, modules
 import hgn_amd
 L = _lib.lib()

@@ -5,7 +5,7 @@ for p in (ROOT, os.path.join(ROOT, 'hyper-graph-nets_amd')):
     sys.path.insert(0, p)
 import torch
 from hgn_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'gpurun_out', 'libhgn_mp_stamp.so')
+_lib.LIB_PATH = os.path.join(ROOT, 'tools', '_build', 'libhgn_mp_stamp.so')
 from hgn_amd import ops, topology, synthetic, modules
 import hgn_amd
 L = _lib.lib()
@@ -21,12 +21,12 @@ h = torch.randn(N, 128, device=dev, requires_grad=True)
 e = torch.randn(E, 128, device=dev, requires_grad=True)
 y = ops.edge_block(h, e, topo, w)          # warm
 torch.cuda.synchronize()
-st = torch.zeros(4096 * 4 * 16, dtype=torch.int64, device=dev)
+st = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device=dev)
 assert L.hgn_debug_set_stamps(st.data_ptr()) == 0
 y = ops.edge_block(h, e, topo, w)
 torch.cuda.synchronize()
 L.hgn_debug_set_stamps(None)
-s = st.view(4096, 4, 16).cpu().double()
+s = st.view(4096, 8, 16).cpu().double()
 names = ['start->pre-bfrag(b1+gathers+DMA+sync)', 'bfrag loads wait', 'stage1 MFMA', 'relu+store z1+sync', 'DMA W2+sync', 'stage2 MFMA',
          'relu+store z2+sync', 'DMA W3+sync', 'stage3 MFMA', 'LN+stores']
 d = s[:, :, 1:11] - s[:, :, 0:10]
