@@ -133,6 +133,89 @@ __global__ __launch_bounds__(WGW, 2) void wgrad_kernel(const WArgs a) {
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// LDS-DMA pipelined variant for the common case (both operands 128 wide, 16-byte aligned rows, no gather): row tiles of
+// A and G go global -> LDS by global_load_lds_dwordx4 (no VGPRs) into a 4-slot ring, three tiles in flight per workgroup
+// behind COUNTED vmcnt waits and raw s_barrier (a __syncthreads() would drain the ring: it carries vmcnt(0)).  All LDS is
+// one array (a second __shared__ object makes hipcc wait vmcnt(0) before every ds_read).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int DT = 16;       // rows per ring slot
+constexpr int NS = 4;        // ring slots
+
+__device__ __forceinline__ void wg_dma_issue(float* __restrict__ slotA, float* __restrict__ slotG, const WTaskDev& t,
+                                             long tile_row0, long M) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (unsigned q = 0; q < 2; ++q) {
+    const unsigned i = wave * 2 + q;                       // 8 wave-instructions of 1 KiB cover the 16x128 tile
+    long gr = tile_row0 + 2 * i + (lane >> 5);
+    gr = gr < M ? gr : M - 1;                              // clamp (rows past the chunk end are masked in the MFMA loop)
+    const unsigned c = 4 * (lane & 31);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.A + gr * t.lda + c),
+                                     (__attribute__((address_space(3))) void*)(slotA + i * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.G + gr * t.ldg + c),
+                                     (__attribute__((address_space(3))) void*)(slotG + i * 256), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(WGW, 2) void wgrad_dma_kernel(const WArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[NS * 2 * DT * 128];      // [slot][A|G][16][128] = 64 KB
+  const WTaskDev t = a.t[a.task0 + blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const long row_beg = (long)blockIdx.x * a.rows_per_chunk;
+  const long row_end = min(a.M, row_beg + a.rows_per_chunk);
+  float* slab = t.slab + (long)blockIdx.x * SLAB;
+  const int ntiles = row_beg < row_end ? (int)((row_end - row_beg + DT - 1) / DT) : 0;
+  const int cs_col = threadIdx.x & 127, cs_half = threadIdx.x >> 7;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+  float cs0 = 0.f;
+  for (int j = 0; j < NS - 1 && j < ntiles; ++j)
+    wg_dma_issue(lds + (j * 2) * DT * 128, lds + (j * 2 + 1) * DT * 128, t, row_beg + (long)j * DT, a.M);
+  for (int it = 0; it < ntiles; ++it) {
+    const int younger = min(NS - 2, ntiles - 1 - it);        // tiles issued after tile `it` by this wave (4 DMAs each)
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // tile `it` landed for every wave; slot (it-1)%NS is free
+    if (it + NS - 1 < ntiles) {
+      const int sl = (it + NS - 1) % NS;
+      wg_dma_issue(lds + (sl * 2) * DT * 128, lds + (sl * 2 + 1) * DT * 128, t, row_beg + (long)(it + NS - 1) * DT, a.M);
+    }
+    const float* As = lds + ((it % NS) * 2) * DT * 128;
+    const float* Gs = As + DT * 128;
+    const long r0 = row_beg + (long)it * DT;
+    const bool partial = r0 + DT > row_end;
+#pragma unroll
+    for (int s = 0; s < DT / 2; ++s) {
+      float ga = Gs[(2 * s + h) * 128 + 32 * wave + m];
+      if (partial && r0 + 2 * s + h >= row_end) ga = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, As[(2 * s + h) * 128 + 32 * kb + m], acc[kb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < DT / 2; ++r) {
+      const int rr = (DT / 2) * cs_half + r;
+      const float g = Gs[rr * 128 + cs_col];
+      cs0 += (partial && r0 + rr >= row_end) ? 0.f : g;
+    }
+  }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(32 * wave + rho0(r) + 4 * h) * 128 + 32 * kb + m] = acc[kb][r];
+  __builtin_amdgcn_s_barrier();
+  lds[threadIdx.x] = cs0;
+  __syncthreads();
+  if (threadIdx.x < 128) slab[128 * 128 + threadIdx.x] = lds[threadIdx.x] + lds[128 + threadIdx.x];
+}
+
 struct RTaskDev { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; };
 struct RArgs { RTaskDev t[HGN_MAX_WTASK]; };
 
@@ -212,10 +295,15 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   size_t need = 0;
   if (!tasks || hgn_wgrad_workspace_bytes(M, n_tasks, &need) != HGN_OK || !workspace || ws_bytes < need)
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad tasks / workspace too small");
-  // order: type-0 tasks first, then type-1
-  int order[HGN_MAX_WTASK], n0 = 0, n1 = 0;
-  for (int i = 0; i < n_tasks; ++i) if (tasks[i].type == 0) order[n0++] = i;
-  for (int i = 0; i < n_tasks; ++i) if (tasks[i].type == 1) order[n0 + n1++] = i;
+  // order: DMA-eligible GEMM tasks, other GEMM tasks, then LayerNorm-affine tasks
+  auto dma_ok = [](const hgn_wtask_t& t) {
+    return t.type == 0 && t.K == 128 && !t.idxA && (t.lda & 3) == 0 && ((uintptr_t)t.A & 15) == 0;
+  };
+  int order[HGN_MAX_WTASK], nd = 0, ng = 0, n1 = 0;
+  for (int i = 0; i < n_tasks; ++i) if (dma_ok(tasks[i])) order[nd++] = i;
+  for (int i = 0; i < n_tasks; ++i) if (tasks[i].type == 0 && !dma_ok(tasks[i])) order[nd + ng++] = i;
+  for (int i = 0; i < n_tasks; ++i) if (tasks[i].type == 1) order[nd + ng + n1++] = i;
+  const int n0 = nd + ng;
   if (n0 + n1 != n_tasks) return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad task type");
   const int nch0 = chunks_mfma(M, n0), nch1 = chunks_ln(M);
   WArgs wa; RArgs ra;
@@ -232,18 +320,22 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
     ra.t[q] = {t.type, t.K, t.n_out, t.accumulate ? 1 : 0, nch, t.dW, (long)t.ldw, t.db, slab + off};
     off += (size_t)nch * SLAB;
   }
-  auto rows_per = [&](int nch) {
+  auto rows_per = [&](int nch, int mult) {
     long rpc = (M + nch - 1) / nch;
-    rpc = (rpc + WT_ROWS - 1) / WT_ROWS * WT_ROWS;
-    return rpc < WT_ROWS ? (long)WT_ROWS : rpc;
+    rpc = (rpc + mult - 1) / mult * mult;
+    return rpc < mult ? (long)mult : rpc;
   };
   ProfScope ps(g_prof_tag == 1 ? 11 : 4, (double)M * n0, (hipStream_t)stream);
-  if (n0) {
-    wa.n_chunks = nch0; wa.rows_per_chunk = rows_per(nch0); wa.task0 = 0;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch0, (unsigned)n0), dim3(WGW), 0, (hipStream_t)stream, wa);
+  if (nd) {
+    wa.n_chunks = nch0; wa.rows_per_chunk = rows_per(nch0, DT); wa.task0 = 0;
+    hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+  }
+  if (ng) {
+    wa.n_chunks = nch0; wa.rows_per_chunk = rows_per(nch0, WT_ROWS); wa.task0 = nd;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch0, (unsigned)ng), dim3(WGW), 0, (hipStream_t)stream, wa);
   }
   if (n1) {
-    wa.n_chunks = nch1; wa.rows_per_chunk = rows_per(nch1); wa.task0 = n0;
+    wa.n_chunks = nch1; wa.rows_per_chunk = rows_per(nch1, WT_ROWS); wa.task0 = n0;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch1, (unsigned)n1), dim3(WGW), 0, (hipStream_t)stream, wa);
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + 255) / 256, (unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, ra);
