@@ -13,9 +13,10 @@
 //                         feature 16*fb + 4*(lane>>4) + r).
 // Because the C/D map equals the k-order in which B is fed, the output of one layer is the B operand of the next with
 // no LDS round trip and no shuffle: activations never leave the register file between the three Linear layers,
-// LayerNorm and the residual.  LDS holds only weights (one 128x128 block, 64 KB, shared by the 8 waves of a
-// workgroup).  A wave needs 32 + 32 activation registers, so four waves fit per SIMD (<= 128 VGPRs): while one wave
-// streams its rows in or out, three others keep the matrix pipe fed.
+// LayerNorm and the residual.  LDS holds only weights, HALF a 128x128 block at a time (32 KB: 64 contraction columns in the
+// forward form, 64 contraction rows in the transposed form), shared by the 4 waves of a 64-row workgroup.  A wave needs
+// 32 + 32 activation registers (<= 128 VGPRs), so a CU holds FOUR independent workgroups (16 waves, 4 per SIMD, 128 KB
+// LDS): while some stream their rows in or out or wait for a weight DMA, the others keep the matrix pipe fed.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,93 +29,132 @@ constexpr int LAT = 128;         // latent width (reference hard-codes 128: src/
 constexpr int LDW = 128;         // LDS row stride of a staged weight block (unpadded; 16-B groups XOR-swizzled by row)
 constexpr int NB = 8;            // 16-feature blocks per latent row
 constexpr int WAVE_ROWS = 16;    // rows per wave
-constexpr int WG = 512;          // 8 waves
-constexpr int TILE_ROWS = 128;   // rows per workgroup
-
-// LDS image of a weight block: element (r, c) lives at float index  r*128 + (((c>>2) ^ (r&31)) << 2) + (c&3).
-__device__ __forceinline__ int wswz(int r, int c) { return r * LDW + ((((c >> 2) ^ (r & 31)) << 2) | (c & 3)); }
+constexpr int WG = 256;          // 4 waves
+constexpr int TILE_ROWS = 64;    // rows per workgroup
+constexpr int HALF = 64;         // contraction indices per staged half block
+constexpr int WLDS_FLOATS = 64 * 128;   // 32 KB
 
 struct Act { f32x4 v[NB]; };     // one wave-row tile of activations: v[fb][r] = feature 16*fb + 4*kq + r of row n
 
-// One contraction stage:  acc[ob] += Wblock(ob, cb) * b[cb]   for ob < nob, cb < ncb   (blocks of 16).
-//  TR=false: LDS block holds Wt rows = OUTPUT features, cols = contraction index  (forward:  Z^T  = Wt  * X^T)
-//  TR=true : LDS block holds Wt rows = CONTRACTION index, cols = output index     (backward: dX^T = Wt^T * dZ^T)
-template <bool TR>
-__device__ __forceinline__ void mfma_stage(Act& acc, const Act& b, const float* __restrict__ wlds, int nob, int ncb) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward form (TR=false).  LDS image of a half block: [128 output rows][64 contraction cols], 256-byte rows, the sixteen
+// 16-byte groups of a row XOR-swizzled with (row & 15):  (r, c) -> r*64 + (((c>>2) ^ (r&15)) << 2) + (c&3).
+// Lane (m = lane&15, kq = lane>>4) reads Wt[16*ob + m][64*H + 16*cb + 4*kq + 0..3] with ONE conflict-free ds_read_b128
+// per (ob, cb); the four values feed four MFMAs (k-steps r = 0..3 of contraction block 4*H + cb).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wswz_n(int r, int c) { return r * HALF + ((((c >> 2) ^ (r & 15)) << 2) | (c & 3)); }
+
+template <int H>
+__device__ __forceinline__ void mfma_half_n(Act& acc, const Act& b, const float* __restrict__ wlds, int nob, int ncb) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
-  if (!TR) {
-    // lane (m,kq) needs Wt[16*ob + m][16*cb + 4*kq + r], r = 0..3  ->  ONE ds_read_b128 per (ob, cb).
-    // row & 31 = m + 16*(ob & 1);  16-byte group = 4*cb + kq.
-    const float* base = wlds + m * LDW;
-    const int pe = (m ^ kq) << 2;                 // ob even:  ((4cb + kq) ^ m)        << 2  =  pe ^ (16cb)
-    const int po = ((m + 16) ^ kq) << 2;          // ob odd :  ((4cb + kq) ^ (m + 16)) << 2  =  po ^ (16cb)
+  const float* base = wlds + m * HALF;
+  const int p = (m ^ kq) << 2;                       // ((4cb + kq) ^ m) << 2  =  p ^ (16cb)
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      if (cb < ncb) {
-        const int xe = pe ^ (16 * cb), xo = po ^ (16 * cb);
+  for (int cb = 0; cb < 4; ++cb) {
+    if (cb < ncb) {
+      const int xo = p ^ (16 * cb);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          f32x4 a[4];
+      for (int half = 0; half < 2; ++half) {
+        f32x4 a[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int ob = 4 * half + q;
-            if (ob < nob) a[q] = *reinterpret_cast<const f32x4*>(base + 16 * LDW * ob + ((ob & 1) ? xo : xe));
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int ob = 4 * half + q;
-              if (ob < nob) acc.v[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][r], b.v[cb][r], acc.v[ob], 0, 0, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);     // keep the weight fragments of later blocks out of the register file
+        for (int q = 0; q < 4; ++q) {
+          const int ob = 4 * half + q;
+          if (ob < nob) a[q] = *reinterpret_cast<const f32x4*>(base + 16 * HALF * ob + xo);
         }
-      }
-    }
-  } else {
-    // lane (m,kq) needs Wt[16*cb + 4*kq + r][16*ob + m]  (ds_read_b32).  With oc = ob ^ 4*(cb&1) the swizzled float
-    // index is  (16cb + r)*128 + ((oc & 4) << 4)   [compile time]
-    //         +  4kq*128 + (((oc & 3) ^ kq) << 4) + (((m >> 2) ^ r) << 2) + (m & 3)   [per lane, 16 variants].
-    int off[4][4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) off[v][r] = 4 * kq * LDW + ((v ^ kq) << 4) + ((((m >> 2) ^ r)) << 2) + (m & 3);
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      if (cb < ncb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-          for (int ob = 0; ob < NB; ++ob) {
-            if (ob < nob) {
-              const int oc = ob ^ (4 * (cb & 1));
-              const int imm = (16 * cb + r) * LDW + ((oc & 4) << 4);
-              acc.v[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlds[imm + off[oc & 3][r]], b.v[cb][r], acc.v[ob], 0, 0, 0);
-            }
+          for (int q = 0; q < 4; ++q) {
+            const int ob = 4 * half + q;
+            if (ob < nob)
+              acc.v[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][r], b.v[4 * H + cb][r], acc.v[ob], 0, 0, 0);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);     // keep the weight fragments of later blocks out of the register file
       }
     }
   }
 }
 
-// Cooperative copy of a weight block W[r*ldw + c] (r < rows, c < cols; zero beyond) into the swizzled LDS image, rows
-// [0,rpad) x cols [0,cpad).  Full, 16-byte-aligned 128x128 blocks go by LDS-DMA: each wave-instruction moves two rows
-// (1 KiB, lane-linear in LDS); the swizzle is applied to the per-lane SOURCE address.  Completion is covered by the
-// vmcnt(0) hipcc emits ahead of the following __syncthreads().
-__device__ __forceinline__ void stage_weight(float* __restrict__ wlds, const float* __restrict__ W, long ldw,
-                                             int rows, int cols, int rpad, int cpad) {
-  const bool dma = rows == 128 && cols == 128 && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+// ---------------------------------------------------------------------------------------------------------------------
+// Transposed form (TR=true).  LDS image of a half block: [64 contraction rows][128 output cols], 512-byte rows, 16-byte
+// groups XOR-swizzled with (row & 31):  (r, c) -> r*128 + (((c>>2) ^ (r&31)) << 2) + (c&3).
+// Lane (m, kq) reads Wt[64*H + 16*cb + 4*kq + r][16*ob + m] with conflict-free ds_read_b32.  With oc = ob ^ 4*(cb&1) the
+// swizzled index is (16cb + r)*128 + ((oc & 4) << 4) [compile time] + one of 16 per-lane offsets.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wswz_t(int r, int c) { return r * LDW + ((((c >> 2) ^ (r & 31)) << 2) | (c & 3)); }
+
+template <int H>
+__device__ __forceinline__ void mfma_half_t(Act& acc, const Act& b, const float* __restrict__ wlds, int nob, int ncb) {
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, kq = lane >> 4;
+  int off[4][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) off[v][r] = 4 * kq * LDW + ((v ^ kq) << 4) + ((((m >> 2) ^ r)) << 2) + (m & 3);
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    if (cb < ncb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+          if (ob < nob) {
+            const int oc = ob ^ (4 * (cb & 1));
+            const int imm = (16 * cb + r) * LDW + ((oc & 4) << 4);
+            acc.v[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlds[imm + off[oc & 3][r]], b.v[4 * H + cb][r], acc.v[ob], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Staging of a half block W[r*ldw + c], r < rows, c < cols (zero beyond, up to rpad x cpad).  Full, 16-byte-aligned halves
+// go by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, lane-linear in LDS, swizzle applied to the per-lane
+// SOURCE address, no VGPR traffic); completion is covered by the vmcnt(0) ahead of the following __syncthreads().
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_half_n(float* __restrict__ wlds, const float* __restrict__ W, long ldw, int rows,
+                                             int cols, int rpad, int cpad) {
+  // forward form: up to 128 rows x 64 cols
+  const bool dma = rows == 128 && cols == HALF && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
   if (dma) {
-    // 32-bit offsets from the (wave-uniform) block pointer: one VGPR per in-flight DMA address
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned ld = (unsigned)ldw;
 #pragma unroll
-    for (unsigned i = wave; i < 64; i += WG / 64) {
+    for (unsigned i = wave; i < 32; i += WG / 64) {              // instruction i fills rows 4i .. 4i+3
+      const unsigned r = 4 * i + (lane >> 4);
+      const unsigned g = (lane & 15) ^ (r & 15);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (r * ld + 4 * g)),
+                                       (__attribute__((address_space(3))) void*)(wlds + i * 256), 16, 0, 0);
+    }
+    return;
+  }
+  const int c = threadIdx.x & 63;
+  const int r0 = threadIdx.x >> 6;
+  if (c < cpad) {
+#pragma unroll 4
+    for (int r = r0; r < rpad; r += WG / 64) {
+      float v = 0.f;
+      if (r < rows && c < cols) v = W[(long)r * ldw + c];
+      wlds[wswz_n(r, c)] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_half_t(float* __restrict__ wlds, const float* __restrict__ W, long ldw, int rows,
+                                             int cols, int rpad, int cpad) {
+  // transposed form: up to 64 rows x 128 cols
+  const bool dma = rows == HALF && cols == 128 && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+  if (dma) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned ld = (unsigned)ldw;
+#pragma unroll
+    for (unsigned i = wave; i < 32; i += WG / 64) {              // instruction i fills rows 2i, 2i+1
       const unsigned r = 2 * i + (lane >> 5);
       const unsigned g = (lane & 31) ^ (r & 31);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (r * ld + 4 * g)),
@@ -129,7 +169,7 @@ __device__ __forceinline__ void stage_weight(float* __restrict__ wlds, const flo
     for (int r = r0; r < rpad; r += WG / 128) {
       float v = 0.f;
       if (r < rows && c < cols) v = W[(long)r * ldw + c];
-      wlds[wswz(r, c)] = v;
+      wlds[wswz_t(r, c)] = v;
     }
   }
 }
@@ -205,6 +245,46 @@ __device__ __forceinline__ float row_sum(const Act& a) {
   t += __shfl_xor(t, 16);
   t += __shfl_xor(t, 32);
   return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One 128-wide contraction block = two staged halves.  `between()` is called once, after the first half's DMA has been
+// issued and before the wait, so the caller's own global loads fly together with it.
+//   gemm_n: acc[ob] += W[out rows < rows][k < kw] * b          (W = &Wt[0][k0], forward form)
+//   gemm_t: acc[ob] += W[j < jw][cols < cols]^T * b            (W = &Wt[0][c0], transposed form; contraction over rows j)
+// ---------------------------------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void gemm_n(Act& acc, const Act& b, float* __restrict__ wlds, const float* __restrict__ W,
+                                       long ldw, int rows, int kw, F&& between) {
+  const int nob = (rows + 15) >> 4, ncb = (kw + 15) >> 4;
+  wg_barrier_lds();
+  stage_half_n(wlds, W, ldw, rows, min(kw, HALF), 16 * nob, 16 * min(ncb, 4));
+  between();
+  __syncthreads();
+  mfma_half_n<0>(acc, b, wlds, nob, min(ncb, 4));
+  if (ncb > 4) {
+    wg_barrier_lds();
+    stage_half_n(wlds, W + HALF, ldw, rows, kw - HALF, 16 * nob, 16 * (ncb - 4));
+    __syncthreads();
+    mfma_half_n<1>(acc, b, wlds, nob, ncb - 4);
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void gemm_t(Act& acc, const Act& b, float* __restrict__ wlds, const float* __restrict__ W,
+                                       long ldw, int jw, int cols, F&& between) {
+  const int nob = (cols + 15) >> 4, ncb = (jw + 15) >> 4;
+  wg_barrier_lds();
+  stage_half_t(wlds, W, ldw, min(jw, HALF), cols, 16 * min(ncb, 4), 16 * nob);
+  between();
+  __syncthreads();
+  mfma_half_t<0>(acc, b, wlds, nob, min(ncb, 4));
+  if (ncb > 4) {
+    wg_barrier_lds();
+    stage_half_t(wlds, W + (long)HALF * ldw, ldw, jw - HALF, cols, 16 * (ncb - 4), 16 * nob);
+    __syncthreads();
+    mfma_half_t<1>(acc, b, wlds, nob, ncb - 4);
+  }
 }
 
 }  // namespace hgn

@@ -13,7 +13,7 @@ __device__ int g_flags = 0;     // ablations: 1 skip MFMA, 2 skip stores, 4 skip
 #define STAMP(i)                                                                                                   \
   do {                                                                                                             \
     if (g_stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                                  \
-      g_stamps[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();           \
+      g_stamps[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();           \
   } while (0)
 #define ABL(bit) (g_flags & (bit))
 #else
@@ -29,11 +29,11 @@ __device__ __forceinline__ void relu_inplace(Act& a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // forward:  out = [res +] [LN]( W3 relu(W2 relu(z1) + b2) + b3 )
-// Order inside every stage: barrier (LDS free) -> weight DMA in flight -> this wave's global loads in flight ->
-// one __syncthreads() (vmcnt(0) covers DMA, loads and the previous stage's stores together) -> MFMAs.
+// Every 128-wide contraction block is two staged halves (gemm_n); the wave's own global loads are issued between the
+// first half's DMA and its wait, so they fly together; stores of saved activations stay in flight across the raw barriers.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG, 4) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
-  __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
@@ -50,48 +50,31 @@ __global__ __launch_bounds__(WG, 4) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
     const bool vec = ((s.ld & 3) == 0) && ((s.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
     for (int k0 = 0; k0 < s.K; k0 += 128) {
       const int kw = min(128, s.K - k0);
-      const int ncb = (kw + 15) >> 4;
-      if (!ABL(32)) wg_barrier_lds();
-      if (!ABL(16)) stage_weight(wlds, s.W + k0, a.ldw1, 128, kw, 128, 16 * ncb);
-      STAMP(1);
       const float* xr = s.x + srow * s.ld + k0;
-      if (ABL(8)) t_zero(b);
-      else if (vec) { if (kw == 128) t_load(b, xr, kq); else t_load_w(b, xr, kq, kw); } else t_load_masked(b, xr, kq, kw);
-      if (first) {
-        t_load(acc, a.b1, kq);
-        if (!ABL(4)) for (int i = 0; i < a.n_add; ++i) t_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, kq);
-        first = false;
-      }
-      if (!ABL(32)) __syncthreads();
-      STAMP(2);
-      if (!ABL(1)) mfma_stage<false>(acc, b, wlds, NB, ncb);
-      STAMP(3);
+      gemm_n(acc, b, wlds, s.W + k0, a.ldw1, 128, kw, [&] {
+        if (vec) { if (kw == 128) t_load(b, xr, kq); else t_load_w(b, xr, kq, kw); } else t_load_masked(b, xr, kq, kw);
+        if (first) {
+          t_load(acc, a.b1, kq);
+          for (int i = 0; i < a.n_add; ++i) t_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, kq);
+          first = false;
+        }
+      });
     }
   }
   if (first) t_load(acc, a.b1, kq);
+  STAMP(1);
   relu_inplace(acc);
-  if (a.z1 && valid && !ABL(2)) t_store(acc, a.z1 + row * LAT, kq);
+  if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
   // ---- layer 2 ------------------------------------------------------------------------------------------
-  if (!ABL(32)) wg_barrier_lds();
-  STAMP(4);
-  if (!ABL(16)) stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
-  t_load(b, a.b2, kq);
-  if (!ABL(32)) __syncthreads();
-  STAMP(5);
-  if (!ABL(1)) mfma_stage<false>(b, acc, wlds, NB, NB);      // b now holds layer-2 pre-activations
-  STAMP(6);
+  gemm_n(b, acc, wlds, a.W2, LAT, 128, 128, [&] { t_load(b, a.b2, kq); });      // b := b2 + W2 * acc
+  STAMP(2);
   relu_inplace(b);
-  if (a.z2 && valid && !ABL(2)) t_store(b, a.z2 + row * LAT, kq);
+  if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
   // ---- layer 3 ------------------------------------------------------------------------------------------
-  const int nob = (a.out_w + 15) >> 4;
-  if (!ABL(32)) wg_barrier_lds();
-  STAMP(7);
-  if (!ABL(16)) stage_weight(wlds, a.W3, LAT, a.out_w, 128, 16 * nob, 128);
-  if (a.out_w == LAT) t_load(acc, a.b3, kq); else t_load_masked(acc, a.b3, kq, a.out_w);
-  if (!ABL(32)) __syncthreads();
-  STAMP(8);
-  if (!ABL(1)) mfma_stage<false>(acc, b, wlds, nob, NB);
-  STAMP(9);
+  gemm_n(acc, b, wlds, a.W3, LAT, a.out_w, 128, [&] {
+    if (a.out_w == LAT) t_load(acc, a.b3, kq); else t_load_masked(acc, a.b3, kq, a.out_w);
+  });
+  STAMP(3);
   // ---- LayerNorm (eps 1e-5, biased variance: torch.nn.LayerNorm) + residual -------------------------------
   if (a.ln_g) {
     const float mean = row_sum(acc) * (1.f / LAT);
@@ -102,7 +85,7 @@ __global__ __launch_bounds__(WG, 4) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
     const float var = row_sum(b) * (1.f / LAT);
     const float rstd = 1.f / sqrtf(var + 1e-5f);
     HGN_FOR_B(fb) acc.v[fb] *= rstd;
-    if (a.xhat && valid && !ABL(2)) t_store(acc, a.xhat + row * LAT, kq);
+    if (a.xhat && valid) t_store(acc, a.xhat + row * LAT, kq);
     if (a.rstd && valid && kq == 0) a.rstd[row] = rstd;
     HGN_FOR_B(fb) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
@@ -112,8 +95,8 @@ __global__ __launch_bounds__(WG, 4) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
   }
   if (valid) {
     if (a.out_w == LAT && (a.ld_out & 3) == 0) {
-      if (a.res && !ABL(8)) t_add(acc, a.res + row * a.ld_res, kq);
-      if (!ABL(2) || (n == 0 && kq == 0)) t_store(acc, a.out + row * a.ld_out, kq);
+      if (a.res) t_add(acc, a.res + row * a.ld_res, kq);
+      t_store(acc, a.out + row * a.ld_out, kq);
     } else {
       if (a.res) {
         t_load_masked(b, a.res + row * a.ld_res, kq, a.out_w);
@@ -122,7 +105,7 @@ __global__ __launch_bounds__(WG, 4) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
       t_store_masked(acc, a.out + row * a.ld_out, kq, a.out_w);
     }
   }
-  STAMP(10);
+  STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -137,7 +120,7 @@ __device__ __forceinline__ void relu_mask(Act& g, const float* __restrict__ zrow
 }
 
 __global__ __launch_bounds__(WG, 4) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
-  __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
@@ -145,34 +128,28 @@ __global__ __launch_bounds__(WG, 4) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
   const long rc = valid ? row : a.M - 1;
 
   Act g, t;
-  const int ncb3 = (a.out_w + 15) >> 4;
-  stage_weight(wlds, a.W3, LAT, a.out_w, 128, 16 * ncb3, 128);     // DMA flies under the LayerNorm backward
-  const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
-  if (vec_out) t_load(g, a.d_out + rc * a.ld_dout, kq); else t_load_masked(g, a.d_out + rc * a.ld_dout, kq, a.out_w);
-  if (a.ln_g) {
-    // y = xhat*gamma + beta ;  dz3 = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat))
-    t_load(t, a.xhat + rc * LAT, kq);
-    HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
-    const float m1 = row_sum(g) * (1.f / LAT);
-    Act p;
-    HGN_FOR_B(fb) p.v[fb] = g.v[fb] * t.v[fb];
-    const float m2 = row_sum(p) * (1.f / LAT);
-    const float r = a.rstd[rc];
-    HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
-  }
-  if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
-  // ---- dz2 = relu'(z2) * (W3^T dz3) ----------------------------------------------------------------------
-  __syncthreads();
-  t_zero(t);
-  mfma_stage<true>(t, g, wlds, NB, ncb3);
+  // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
+  gemm_t(t, g, wlds, a.W3, LAT, a.out_w, 128, [&] {
+    const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
+    if (vec_out) t_load(g, a.d_out + rc * a.ld_dout, kq); else t_load_masked(g, a.d_out + rc * a.ld_dout, kq, a.out_w);
+    if (a.ln_g) {
+      // y = xhat*gamma + beta ;  dz3 = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat))
+      t_load(t, a.xhat + rc * LAT, kq);
+      HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+      const float m1 = row_sum(g) * (1.f / LAT);
+      Act p;
+      HGN_FOR_B(fb) p.v[fb] = g.v[fb] * t.v[fb];
+      const float m2 = row_sum(p) * (1.f / LAT);
+      const float r = a.rstd[rc];
+      HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
+    }
+    if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
+    t_zero(t);
+  });
   relu_mask(t, a.z2 + rc * LAT, kq);
   if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
-  wg_barrier_lds();
-  stage_weight(wlds, a.W2, LAT, 128, 128, 128, 128);
-  __syncthreads();
-  t_zero(g);
-  mfma_stage<true>(g, t, wlds, NB, NB);
+  gemm_t(g, t, wlds, a.W2, LAT, 128, 128, [&] { t_zero(g); });
   relu_mask(g, a.z1 + rc * LAT, kq);
   if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
   // ---- dx_src = dz1 * W1[:, cols]  (+ d_out for the residual source) ---------------------------------------
@@ -180,12 +157,7 @@ __global__ __launch_bounds__(WG, 4) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
     const hgn_dx_t d = a.dx[di];
     for (int k0 = 0; k0 < d.K; k0 += 128) {
       const int kw = min(128, d.K - k0);
-      const int nob = (kw + 15) >> 4;
-      wg_barrier_lds();
-      stage_weight(wlds, d.W + k0, a.ldw1, 128, kw, 128, 16 * nob);
-      __syncthreads();
-      t_zero(t);
-      mfma_stage<true>(t, g, wlds, nob, NB);
+      gemm_t(t, g, wlds, d.W + k0, a.ldw1, 128, kw, [&] { t_zero(t); });
       if (valid) {
         float* dst = d.dx + row * d.ld + k0;
         if (kw == 128 && (d.ld & 3) == 0) {
@@ -207,27 +179,25 @@ struct LinArgs {
 };
 
 __global__ __launch_bounds__(WG, 4) void linear_fwd_kernel(const LinArgs a) {
-  __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
   const bool valid = row < a.M;
   const long rc = valid ? row : a.M - 1;
   Act acc, b;
-  t_load(b, a.x + rc * a.ldx, kq);
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    wg_barrier_lds();
-    stage_weight(wlds, a.W[blk], a.ldw, 128, 128, 128, 128);
-    __syncthreads();
-    t_zero(acc);
-    mfma_stage<false>(acc, b, wlds, NB, NB);
+    gemm_n(acc, b, wlds, a.W[blk], a.ldw, 128, 128, [&] {
+      if (blk == 0) t_load(b, a.x + rc * a.ldx, kq);
+      t_zero(acc);
+    });
     if (valid) t_store(acc, a.out + row * a.ld_out + 128 * blk, kq);
   }
 }
 
 __global__ __launch_bounds__(WG, 4) void linear_bwd_kernel(const LinArgs a) {
   // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]
-  __shared__ __attribute__((aligned(16))) float wlds[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
@@ -235,13 +205,8 @@ __global__ __launch_bounds__(WG, 4) void linear_bwd_kernel(const LinArgs a) {
   const long rc = valid ? row : a.M - 1;
   Act acc, b;
   t_zero(acc);
-  for (int blk = 0; blk < a.n_blocks; ++blk) {
-    wg_barrier_lds();
-    stage_weight(wlds, a.W[blk], a.ldw, 128, 128, 128, 128);
-    t_load(b, a.x + rc * a.ldx + 128 * blk, kq);
-    __syncthreads();
-    mfma_stage<true>(acc, b, wlds, NB, NB);
-  }
+  for (int blk = 0; blk < a.n_blocks; ++blk)
+    gemm_t(acc, b, wlds, a.W[blk], a.ldw, 128, 128, [&] { t_load(b, a.x + rc * a.ldx + 128 * blk, kq); });
   if (valid) t_store(acc, a.out + row * a.ld_out, kq);
 }
 
