@@ -123,7 +123,9 @@ __device__ __forceinline__ void stage_half_n(float* __restrict__ wlds, const flo
   // forward form: up to 128 rows x 64 cols
   const bool dma = rows == 128 && cols == HALF && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
   if (dma) {
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));      // opaque: the 8 DMA addresses are recomputed per call instead of being kept live
+    const unsigned wave = threadIdx.x >> 6;
     const unsigned ld = (unsigned)ldw;
 #pragma unroll
     for (unsigned i = wave; i < 32; i += WG / 64) {              // instruction i fills rows 4i .. 4i+3
@@ -151,7 +153,9 @@ __device__ __forceinline__ void stage_half_t(float* __restrict__ wlds, const flo
   // transposed form: up to 64 rows x 128 cols
   const bool dma = rows == HALF && cols == 128 && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
   if (dma) {
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const unsigned wave = threadIdx.x >> 6;
     const unsigned ld = (unsigned)ldw;
 #pragma unroll
     for (unsigned i = wave; i < 32; i += WG / 64) {              // instruction i fills rows 2i, 2i+1

@@ -21,16 +21,27 @@ h = torch.randn(N, 128, device=dev, requires_grad=True)
 e = torch.randn(E, 128, device=dev, requires_grad=True)
 y = ops.edge_block(h, e, topo, w)          # warm
 torch.cuda.synchronize()
-st = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device=dev)
+st = torch.zeros(4096 * 4 * 16, dtype=torch.int64, device=dev)
 assert L.hgn_debug_set_stamps(st.data_ptr()) == 0
 y = ops.edge_block(h, e, topo, w)
 torch.cuda.synchronize()
 L.hgn_debug_set_stamps(None)
-s = st.view(4096, 8, 16).cpu().double()
-names = ['start->pre-bfrag(b1+gathers+DMA+sync)', 'bfrag loads wait', 'stage1 MFMA', 'relu+store z1+sync', 'DMA W2+sync', 'stage2 MFMA',
-         'relu+store z2+sync', 'DMA W3+sync', 'stage3 MFMA', 'LN+stores']
-d = s[:, :, 1:11] - s[:, :, 0:10]
-tot = s[:, :, 10] - s[:, :, 0]
-print('wave lifetime cycles: mean %.0f  (s_memtime ticks)' % tot.mean())
+s = st.view(4096, 4, 16).cpu().double()
+dt = s[:, :, 4] - s[:, :, 0]
+drt = s[:, :, 9] - s[:, :, 8]
+ok = drt > 0
+print('wave lifetime: %.0f shader ticks, %.1f us (realtime 100 MHz)' % (dt[ok].mean(), drt[ok].mean() / 100.0))
+print('in-kernel clock = d(memtime)/d(memrealtime) x 100 MHz = %.0f MHz (median %.0f)' % ((dt[ok] / drt[ok]).mean() * 100, (dt[ok] / drt[ok]).median() * 100))
+names = ['stage 1 (loads + gemm)', 'stage 2', 'stage 3', 'LN + stores']
 for i, n in enumerate(names):
-    print('%-45s mean %8.0f  (%.1f%%)' % (n, d[:, :, i].mean(), 100 * d[:, :, i].mean() / tot.mean()))
+    d = (s[:, :, i + 1] - s[:, :, i])[ok]
+    print('%-30s %8.0f ticks (%.1f%%)' % (n, d.mean(), 100 * d.mean() / dt[ok].mean()))
+# ---- are workgroups phase-locked chip-wide?  distribution of workgroup start times (wave 0 of each block)
+t0 = s[:, 0, 0]
+t0 = t0[t0 > 0]
+t0 = (t0 - t0.min()) / 2184.0       # us
+import numpy as np
+h, edges = np.histogram(t0.numpy(), bins=40)
+print('start-time histogram of the first 4096 workgroups (us since first start):')
+for c, e in zip(h, edges[:-1]):
+    print('  %7.1f us  %s' % (e, '#' * int(c // 8)))
