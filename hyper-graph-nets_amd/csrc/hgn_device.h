@@ -238,6 +238,16 @@ __device__ __forceinline__ void t_store_masked(const Act& a, float* __restrict__
 __device__ __forceinline__ void t_zero(Act& a) {
   HGN_FOR_B(fb) a.v[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
+// Sum of x over the 16 lanes of a DPP row (= the 16 rows n of one k-quarter): four rotate-and-add steps on the VALU
+// (v_add_f32 with row_ror DPP control), no LDS crossbar traffic; every lane of the row ends with the full sum.
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));   // row_ror:4
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false));   // row_ror:2
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return x;
+}
+
 // Sum over the 128 features of a row: 32 in-lane values, then the three partner lanes (same n, other kq).
 __device__ __forceinline__ float row_sum(const Act& a) {
   float s0 = 0.f, s1 = 0.f;

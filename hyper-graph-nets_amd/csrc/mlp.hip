@@ -119,8 +119,43 @@ __device__ __forceinline__ void relu_mask(Act& g, const float* __restrict__ zrow
   }
 }
 
-__global__ __launch_bounds__(WG, 4) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
-  __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
+// d_out_eff of the lane's row: d_out (optional) + the aggregation backward scattered back through the CSR row of the edge.
+template <bool ACC>
+__device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {
+  // ACC: add d_out_eff to g (residual path; 128-wide, aligned);  otherwise g = d_out_eff
+  if (ACC) {
+    if (a.d_out) t_add(g, a.d_out + rc * a.ld_dout, kq);
+  } else if (a.d_out) {
+    const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
+    if (vec_out) t_load(g, a.d_out + rc * a.ld_dout, kq); else t_load_masked(g, a.d_out + rc * a.ld_dout, kq, a.out_w);
+  } else {
+    t_zero(g);
+  }
+  if (a.agg_dout) {
+    const long r = a.agg_seg[rc];
+    const int cnt = a.agg_rowptr[r + 1] - a.agg_rowptr[r];
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    for (int slot = 0; slot < a.n_agg_ops; ++slot) {
+      const float* ar = a.agg_dout + r * a.ld_agg + slot * LAT;
+      const int op = a.agg_ops[slot];
+      HGN_FOR_B(fb) {
+        const int col = 16 * fb + 4 * kq;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(ar + col);
+        if (op == HGN_OP_SUM) g.v[fb] += d;
+        else if (op == HGN_OP_MEAN) g.v[fb] += d * inv;
+        else {
+          const int* ap = (op == HGN_OP_MAX ? a.agg_argmax : a.agg_argmin) + r * LAT + col;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) g.v[fb][u] += ap[u] == (int)rc ? d[u] : 0.f;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
+  __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS + (WG / 64) * 256];
+  float* lnl = wlds + WLDS_FLOATS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
@@ -130,16 +165,34 @@ __global__ __launch_bounds__(WG, 4) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
   Act g, t;
   // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
   gemm_t(t, g, wlds, a.W3, LAT, a.out_w, 128, [&] {
-    const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
-    if (vec_out) t_load(g, a.d_out + rc * a.ld_dout, kq); else t_load_masked(g, a.d_out + rc * a.ld_dout, kq, a.out_w);
+    load_dout<false>(g, a, rc, kq);
     if (a.ln_g) {
       // y = xhat*gamma + beta ;  dz3 = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat))
       t_load(t, a.xhat + rc * LAT, kq);
+      if (a.ln_ws) {
+        // LayerNorm-affine gradient partials of this wave's 16 rows: reduce over the row lanes (n), keep per feature
+        HGN_FOR_B(fb) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float pb = valid ? g.v[fb][u] : 0.f;
+            float pg = row16_sum(pb * t.v[fb][u]);
+            pb = row16_sum(pb);
+            if (n == 0) { lnl[wave * 256 + 16 * fb + 4 * kq + u] = pg; lnl[wave * 256 + 128 + 16 * fb + 4 * kq + u] = pb; }
+          }
+          __builtin_amdgcn_sched_barrier(0);      // one feature block at a time: keeps the live set small
+        }
+      }
       HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
       const float m1 = row_sum(g) * (1.f / LAT);
-      Act p;
-      HGN_FOR_B(fb) p.v[fb] = g.v[fb] * t.v[fb];
-      const float m2 = row_sum(p) * (1.f / LAT);
+      float q0 = 0.f, q1 = 0.f;
+      HGN_FOR_B(fb) {
+        q0 += g.v[fb][0] * t.v[fb][0] + g.v[fb][1] * t.v[fb][1];
+        q1 += g.v[fb][2] * t.v[fb][2] + g.v[fb][3] * t.v[fb][3];
+      }
+      float qs = q0 + q1;
+      qs += __shfl_xor(qs, 16);
+      qs += __shfl_xor(qs, 32);
+      const float m2 = qs * (1.f / LAT);
       const float r = a.rstd[rc];
       HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
     }
@@ -152,7 +205,7 @@ __global__ __launch_bounds__(WG, 4) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
   gemm_t(g, t, wlds, a.W2, LAT, 128, 128, [&] { t_zero(g); });
   relu_mask(g, a.z1 + rc * LAT, kq);
   if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
-  // ---- dx_src = dz1 * W1[:, cols]  (+ d_out for the residual source) ---------------------------------------
+  // ---- dx_src = dz1 * W1[:, cols]  (+ d_out_eff for the residual source) -----------------------------------
   for (int di = 0; di < a.n_dx; ++di) {
     const hgn_dx_t d = a.dx[di];
     for (int k0 = 0; k0 < d.K; k0 += 128) {
@@ -161,13 +214,46 @@ __global__ __launch_bounds__(WG, 4) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
       if (valid) {
         float* dst = d.dx + row * d.ld + k0;
         if (kw == 128 && (d.ld & 3) == 0) {
-          if (d.residual) t_add(t, a.d_out + row * a.ld_dout, kq);
+          if (d.residual) load_dout<true>(t, a, rc, kq);   // re-read (L2-resident) rather than kept live through three GEMMs
           t_store(t, dst, kq);
         } else {
           t_store_masked(t, dst, kq, kw);      // residual sources are always 128 wide (latent)
         }
       }
     }
+  }
+  if (a.ln_ws) {
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WG / 64; ++w) sum += lnl[w * 256 + threadIdx.x];
+    a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
+  }
+}
+
+// Fixed-order column sum of the per-workgroup LayerNorm slabs [n_wg][256] -> dgamma[128], dbeta[128].
+// 32 blocks x 1024 threads: block b owns features [8b, 8b+8); thread (rg, f) sums rows rg, rg+128, ... with eight loads in
+// flight, then the 128 row-group partials are combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ ws, long n_wg, float* __restrict__ dg,
+                                                         float* __restrict__ db, int acc) {
+  __shared__ float part[128][8];
+  const int f = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int col = blockIdx.x * 8 + f;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  long w = rg;
+  for (; w + 7 * 128 < n_wg; w += 8 * 128) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += ws[(w + u * 128) * 256 + col];
+  }
+  for (int u = 0; w < n_wg; w += 128, ++u) s[u & 7] += ws[w * 256 + col];
+  part[rg][f] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float t = 0.f;
+    for (int r = 0; r < 128; ++r) t += part[r][threadIdx.x];
+    const int c = blockIdx.x * 8 + threadIdx.x;
+    float* dst = c < 128 ? dg + c : db + (c - 128);
+    *dst = acc ? *dst + t : t;
   }
 }
 
@@ -248,13 +334,31 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   return hgn_check_launch("hgn_mlp_fwd");
 }
 
+extern "C" int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes) {
+  if (!bytes || M < 0) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd_ln_workspace_bytes: bad argument");
+  const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+  *bytes = (size_t)tiles * 256 * sizeof(float) + 256;
+  return HGN_OK;
+}
+
 extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   if (!a) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: null args");
   if (a->M == 0) return HGN_OK;
   if (a->M < 0 || a->n_dx < 0 || a->n_dx > HGN_MAX_SRC) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad counts");
   if (a->out_w < 1 || a->out_w > 128 || (a->ln_g && (a->out_w != 128 || !a->xhat || !a->rstd)))
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad out_w / LayerNorm");
-  if (!a->d_out || !a->z1 || !a->z2 || !a->W2 || !a->W3) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: null pointer");
+  if ((!a->d_out && !a->agg_dout) || !a->z1 || !a->z2 || !a->W2 || !a->W3) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: null pointer");
+  if (a->agg_dout) {
+    if (a->out_w != 128 || a->n_agg_ops < 1 || a->n_agg_ops > 4 || !a->agg_seg || !a->agg_rowptr || (a->ld_agg & 3) ||
+        !aligned16(a->agg_dout))
+      return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad aggregation-backward descriptor");
+    for (int i = 0; i < a->n_agg_ops; ++i) {
+      if (a->agg_ops[i] < 0 || a->agg_ops[i] > 3) return hgn_fail(HGN_E_INVALID, "Invalid operation type!");
+      if ((a->agg_ops[i] == HGN_OP_MAX && !a->agg_argmax) || (a->agg_ops[i] == HGN_OP_MIN && !a->agg_argmin))
+        return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: max/min need the saved arg index");
+    }
+  }
+  if (a->ln_ws && (!a->ln_g || !a->d_gamma || !a->d_beta)) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: LayerNorm gradient outputs missing");
   for (int i = 0; i < a->n_dx; ++i)
     if (!a->dx[i].W || !a->dx[i].dx || a->dx[i].K < 1 || (a->dx[i].residual && (a->dx[i].K != 128 || a->out_w != 128)))
       return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad dx request");
@@ -262,6 +366,10 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   const int kid = (a->n_dx == 1 && a->dx[0].residual && a->dz1) ? 2 : 3;
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
   hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  if (a->ln_ws) {
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3(32), dim3(1024), 0, (hipStream_t)stream, a->ln_ws, tiles, a->d_gamma, a->d_beta,
+                       a->ln_accumulate);
+  }
   return hgn_check_launch("hgn_mlp_bwd");
 }
 

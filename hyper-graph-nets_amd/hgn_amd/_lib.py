@@ -45,7 +45,10 @@ class MlpBwd(C.Structure):
     _fields_ = [('M', C.c_int64), ('d_out', c_f32p), ('ld_dout', C.c_int64), ('out_w', C.c_int32), ('ln_g', c_f32p),
                 ('xhat', c_f32p), ('rstd', c_f32p), ('z2', c_f32p), ('z1', c_f32p), ('W3', c_f32p), ('W2', c_f32p),
                 ('ldw1', C.c_int64), ('dz3', c_f32p), ('dz2', c_f32p), ('dz1', c_f32p), ('n_dx', C.c_int32),
-                ('dx', Dx * HGN_MAX_SRC)]
+                ('dx', Dx * HGN_MAX_SRC),
+                ('agg_dout', c_f32p), ('ld_agg', C.c_int64), ('n_agg_ops', C.c_int32), ('agg_ops', C.c_int32 * 4),
+                ('agg_seg', c_i32p), ('agg_rowptr', c_i32p), ('agg_argmax', c_i32p), ('agg_argmin', c_i32p),
+                ('d_gamma', c_f32p), ('d_beta', c_f32p), ('ln_ws', c_f32p), ('ln_accumulate', C.c_int32)]
 
 
 class WTask(C.Structure):
@@ -68,6 +71,7 @@ _SIGS = {
                                          C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'hgn_mlp_fwd': (C.c_int, [C.POINTER(MlpFwd), C.c_void_p]),
+    'hgn_mlp_bwd_ln_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     'hgn_mlp_bwd': (C.c_int, [C.POINTER(MlpBwd), C.c_void_p]),
     'hgn_wgrad_workspace_bytes': (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
     'hgn_mlp_wgrad': (C.c_int, [C.POINTER(WTask), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),

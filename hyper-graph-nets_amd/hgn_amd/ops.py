@@ -102,6 +102,12 @@ def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False):
         _lib.check(L.hgn_mlp_wgrad(arr, len(chunk), M, ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'hgn_mlp_wgrad')
 
 
+def _ln_workspace(M: int, dev) -> torch.Tensor:
+    nb = C.c_size_t(0)
+    _lib.check(_lib.lib().hgn_mlp_bwd_ln_workspace_bytes(M, C.byref(nb)), 'hgn_mlp_bwd_ln_workspace_bytes')
+    return _workspace(dev, nb.value)
+
+
 def _grad_targets(wt):
     """Flat-gradient mode (parallel.FlatParams): a parameter tagged with ``_hgn_grad`` receives its gradient by
     ACCUMULATION straight into that buffer (zeroed once per step) and autograd gets None for it -- no per-parameter
@@ -208,10 +214,15 @@ class MLPFn(torch.autograd.Function):
                 dxs[i] = dx
                 nd += 1
         b.n_dx = nd
+        bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
+        if has_ln:           # LayerNorm-affine gradients come out of the same pass
+            b.d_gamma = bufs[6].data_ptr(); b.d_beta = bufs[7].data_ptr(); b.ln_accumulate = accs[6]
+            b.ln_ws = _ln_workspace(M, dev).data_ptr()
         if M > 0:
             _lib.check(L.hgn_mlp_bwd(C.byref(b), _lib.stream_ptr()), 'hgn_mlp_bwd')
+        elif has_ln and not accs[6]:
+            bufs[6].zero_(); bufs[7].zero_()
         # ---- parameter gradients -------------------------------------------------------------------------------
-        bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
         dw1, db1, dw2, db2, dw3, db3 = bufs[:6]
         tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, out_w, dw3.data_ptr(), LAT, db3.data_ptr(), accs[4]),
                  _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2])]
@@ -225,9 +236,6 @@ class MLPFn(torch.autograd.Function):
                                     dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * (cols[i] + k0), ldw1,
                                     db1.data_ptr() if first else None, accs[0]))
                 first = False
-        if has_ln:
-            tasks.append(_wtask(1, xhat.data_ptr(), LAT, LAT, None, d_out.data_ptr(), _ld(d_out), LAT, bufs[6].data_ptr(), LAT,
-                                bufs[7].data_ptr(), accs[6]))
         _run_wgrad(tasks, M, dev)
         # ---- un-gather source gradients -----------------------------------------------------------------------
         for i in range(n_src):
@@ -320,27 +328,26 @@ class EdgeBlockFn(torch.autograd.Function):
         if d_out is None and d_agg is None:
             return (None,) * (5 + len(wt))
         dev = (d_out if d_out is not None else d_agg).device
-        if d_out is not None:
-            d_out = _rowmajor(d_out)
-        if d_agg is not None:
-            # dE = d(e') + scatter of d(agg) back to the edges, fused in the segment-reduce backward
-            d_agg = _rowmajor(d_agg)
-            arr, codes = _ops_array(agg_ops)
-            dE = torch.empty(E, LAT, device=dev)
-            _lib.check(L.hgn_segment_reduce_bwd(d_agg.data_ptr(), _ld(d_agg), LAT, None, topo.rcv.data_ptr(),
-                                                topo.r.rowptr.data_ptr(), E, arr, len(codes),
-                                                amax.data_ptr() if amax is not None else None,
-                                                amin.data_ptr() if amin is not None else None,
-                                                d_out.data_ptr() if d_out is not None else None, dE.data_ptr(), LAT, st),
-                       'hgn_segment_reduce_bwd')
-            d_out = dE
         dz3 = torch.empty(E, LAT, device=dev)
         dz2 = torch.empty(E, LAT, device=dev)
         dz1 = torch.empty(E, LAT, device=dev)
         de = torch.empty(E, LAT, device=dev)
         b = _lib.MlpBwd()
         b.M = E
-        b.d_out = d_out.data_ptr(); b.ld_dout = _ld(d_out); b.out_w = LAT
+        b.out_w = LAT
+        if d_out is not None:
+            d_out = _rowmajor(d_out)
+            b.d_out = d_out.data_ptr(); b.ld_dout = _ld(d_out)
+        if d_agg is not None:
+            # d(e') + the aggregation backward are summed inside the kernel's load of d_out (no dE tensor, no extra pass)
+            d_agg = _rowmajor(d_agg)
+            arr, codes = _ops_array(agg_ops)
+            b.agg_dout = d_agg.data_ptr(); b.ld_agg = _ld(d_agg); b.n_agg_ops = len(codes)
+            for i, cde in enumerate(codes):
+                b.agg_ops[i] = cde
+            b.agg_seg = topo.rcv.data_ptr(); b.agg_rowptr = topo.r.rowptr.data_ptr()
+            b.agg_argmax = amax.data_ptr() if amax is not None else None
+            b.agg_argmin = amin.data_ptr() if amin is not None else None
         b.ln_g = w.ln_w.data_ptr(); b.xhat = xhat.data_ptr(); b.rstd = rstd.data_ptr()
         b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr()
         b.W3 = w.w3.data_ptr(); b.W2 = w.w2.data_ptr(); b.ldw1 = 3 * LAT
@@ -348,16 +355,18 @@ class EdgeBlockFn(torch.autograd.Function):
         b.n_dx = 1
         d = b.dx[0]
         d.W = w.w1.data_ptr() + 4 * 2 * LAT; d.K = LAT; d.dx = de.data_ptr(); d.ld = LAT; d.residual = 1
-        if E > 0:
-            _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
         bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
         dw1, db1, dw2, db2, dw3, db3, dg, dbt = bufs
+        b.d_gamma = dg.data_ptr(); b.d_beta = dbt.data_ptr(); b.ln_accumulate = accs[6]
+        b.ln_ws = _ln_workspace(E, dev).data_ptr()
+        if E > 0:
+            _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
+        elif not accs[6]:
+            dg.zero_(); dbt.zero_()
         tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, LAT, dw3.data_ptr(), LAT, db3.data_ptr(), accs[4]),
                  _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2]),
                  _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
-                        db1.data_ptr(), accs[0]),
-                 _wtask(1, xhat.data_ptr(), LAT, LAT, None, d_out.data_ptr(), _ld(d_out), LAT, dg.data_ptr(), LAT,
-                        dbt.data_ptr(), accs[6])]
+                        db1.data_ptr(), accs[0])]
         _run_wgrad(tasks, E, dev, edge_level=True)
         # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]
         dP = torch.empty(N, 2 * LAT, device=dev)

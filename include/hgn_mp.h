@@ -136,8 +136,18 @@ typedef struct {
   float* dz3; float* dz2; float* dz1;
   int32_t n_dx;
   hgn_dx_t dx[HGN_MAX_SRC];
+  /* Optional, edge blocks: the aggregation backward (graphnet.py:50-70 / torch_scatter backward) folded into the load
+   * of d_out:  d_out_eff[i] = (d_out ? d_out[i] : 0) + sum_slot d(op_slot)(agg_dout[seg[i]][slot*128 ...]).  Rows are in
+   * CSR (receiver-sorted) order, so the arg index of max/min is the row index itself.  d_out may be null then. */
+  const float* agg_dout; int64_t ld_agg; int32_t n_agg_ops; int32_t agg_ops[4];
+  const int32_t* agg_seg; const int32_t* agg_rowptr; const int32_t* agg_argmax; const int32_t* agg_argmin;
+  /* Optional: LayerNorm-affine gradients  dgamma[j] = sum_i d_out_eff[i][j]*xhat[i][j],  dbeta[j] = sum_i d_out_eff[i][j]
+   * produced by the same pass (deterministic: per-wave shuffles -> per-workgroup slab -> two-level fixed-order sum).
+   * ln_ws: hgn_mlp_bwd_ln_workspace_bytes(M) bytes. */
+  float* d_gamma; float* d_beta; float* ln_ws; int32_t ln_accumulate;
 } hgn_mlp_bwd_t;
 
+int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes /*host*/);
 int hgn_mlp_bwd(const hgn_mlp_bwd_t* args /*host*/, void* stream);
 
 /* Weight / bias / LayerNorm-affine gradients: a list of tasks reduced over all rows in one launch.

@@ -35,7 +35,7 @@ def test_abi_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.Src) == 40 and C.sizeof(_lib.Add) == 24 and C.sizeof(_lib.Dx) == 40
     assert C.sizeof(_lib.WTask) == 96
     assert C.sizeof(_lib.MlpFwd) == 8 + 8 + 8 * 40 + 8 + 2 * 24 + 8 * 6 + 8 + 8 * 2 + 8 * 2 + 8 * 2 + 8 * 4
-    assert C.sizeof(_lib.MlpBwd) == 8 + 8 + 8 + 8 + 8 * 7 + 8 + 8 * 3 + 8 + 8 * 40
+    assert C.sizeof(_lib.MlpBwd) == 8 + 8 + 8 + 8 + 8 * 7 + 8 + 8 * 3 + 8 + 8 * 40 + (8 + 8 + 4 + 16 + 4) + 8 * 4 + 8 * 3 + 8
 
 
 def test_abi_argument_validation_without_gpu():
