@@ -32,7 +32,7 @@ __device__ __forceinline__ void relu_inplace(Act& a) {
 // Every 128-wide contraction block is two staged halves (gemm_n); the wave's own global loads are issued between the
 // first half's DMA and its wait, so they fly together; stores of saved activations stay in flight across the raw barriers.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG, 4) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
+__global__ __launch_bounds__(WG, 3) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
   __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
