@@ -219,6 +219,26 @@ def test_data_parallel_equals_single_process_on_concatenated_batch(tmp_path):
     assert float(res['acc_count']) == 32.0
 
 
+def test_batcher_matches_reference_golden_g6():
+    """f1: vectorised batcher; reference_compat mode reproduces MeshSimulator._get_batched's index arithmetic (golden G6,
+    generated by the reference itself), the default mode keeps every graph's remote edges inside that graph."""
+    from hgn_amd import batching, util
+    g6 = torch.load(os.path.join(ROOT, 'tests', 'golden', 'g6_get_batched.pt'))
+    for B, fx in g6.items():
+        graphs = []
+        for gi in fx['in']:
+            nf = [torch.zeros(n, 1) for n in gi['n']]
+            graphs.append(util.MultiGraph(nf, [util.EdgeSet(nm, torch.zeros(s.shape[0], 1), s, r) for nm, s, r in gi['sets']]))
+        compat = batching.batch_graphs(graphs, reference_compat=True)
+        assert [x.shape[0] for x in compat.node_features] == fx['n_out']
+        for e, (nm, s, r) in zip(compat.edge_sets, fx['out']):
+            assert e.name == nm and torch.equal(e.senders, s) and torch.equal(e.receivers, r), (B, nm)
+        fixed = batching.batch_graphs(graphs)
+        ora = O.batch_graphs([O.MultiGraph(g.node_features, [O.EdgeSet(*e) for e in g.edge_sets]) for g in graphs])
+        for a, b in zip(fixed.edge_sets, ora.edge_sets):
+            assert torch.equal(a.senders, b.senders) and torch.equal(a.receivers, b.receivers)
+
+
 def test_shard_indices_partition():
     from hgn_amd import parallel
     for n, w in ((8, 8), (21, 8), (3, 2), (64, 4)):
