@@ -42,8 +42,12 @@ def parse():
     ap.add_argument('--arch', default='none')
     ap.add_argument('--nx', type=int, default=40)
     ap.add_argument('--ny', type=int, default=40)
+    ap.add_argument('--clusters', type=int, default=0, help='hyper nodes per graph (remote message passing edge sets)')
+    ap.add_argument('--world-edges', type=int, default=0, help='extra world edges per graph (plate-style second edge set)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-kernel HIP events in the timed region')
+    ap.add_argument('--graph', action='store_true', help='replay the whole training step from one HIP graph (N=1; per-kernel events are '
+                    'then taken in a short eager pass after the timed region)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
 
@@ -126,7 +130,8 @@ def main():
     # ---- this rank's shard of the global batch: graphs {g : g mod world == rank}, each with its own seed ----------
     B = args.batch
     gids = parallel.shard_indices(B * world, rank, world)
-    graphs = [synthetic.grid_graph(seed=1000 + g, nx=args.nx, ny=args.ny) for g in gids[:min(len(gids), 4)]]
+    graphs = [synthetic.grid_graph(seed=1000 + g, nx=args.nx, ny=args.ny, clusters=args.clusters, world=args.world_edges)
+              for g in gids[:min(len(gids), 4)]]
     while len(graphs) < len(gids):                       # reuse topologies, fresh features (host generation is slow)
         src = graphs[len(graphs) % 4]
         gen = torch.Generator().manual_seed(2000 + gids[len(graphs)])
@@ -156,7 +161,8 @@ def main():
         model(graph)                                     # materialise lazy layers, build + cache the CSR topology
     torch.cuda.synchronize()
     log('first forward done')
-    trainer = parallel.DataParallelTrainer(model, lr=1e-4)
+    use_graph = args.graph and world == 1
+    trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph)
     n_params = trainer.fp.numel
 
     def barrier():
@@ -164,21 +170,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = lambda: trainer.step(graph, target, mask)
     for i in range(args.warmup):
-        trainer.step(graph, target, mask)
+        step()
         if i == 0:
             torch.cuda.synchronize(); log('first training step done')
+    if use_graph:
+        from hgn_amd import graphs
+        gstep = graphs.GraphedTrainStep(trainer, graph, target, mask, warmup=1)
+        step = lambda: gstep()
+        step()
     barrier()
     log('warmup done')
     prof = not args.no_prof
-    if prof:
+    if prof and not use_graph:
         ops.prof_reset(); ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(graph, target, mask)
+        loss = step()
     barrier()
     dt = time.perf_counter() - t0
     log(f'timed region done: {dt:.3f} s for {args.steps} steps')
+    if prof and use_graph:            # events cannot be recorded inside a replayed graph: short eager pass on the same buffers
+        ops.prof_reset(); ops.prof_enable(True)
+        for _ in range(2):
+            trainer.step(graph, target, mask)
+        torch.cuda.synchronize()
     if prof:
         ops.prof_enable(False)
     tmax = torch.tensor([dt], device=dev)
@@ -197,13 +214,14 @@ def main():
                                       f'{args.nx}x{args.ny} triangulated grid per graph ({per} nodes, {E_graph} directed '
                                       f'edges); full training step fwd+loss+bwd+allreduce+Adam',
                           'graphs_per_gpu': B, 'global_batch': B * world, 'edges_per_step': E_rank * world,
-                          'params': n_params, 'parallelism': f'dp{world}', 'loss': float(loss)}}
+                          'params': n_params, 'parallelism': f'dp{world}', 'loss': float(loss), 'hip_graph': bool(use_graph)}}
         if prof:
             k = ops.prof_collect()
             log('profile collected')
             dom = max(k.items(), key=lambda kv: kv[1]['ms'])
-            kernels = {n: {'ms_per_launch': v['ms'] / v['count'], 'launches_per_step': v['count'] / args.steps,
-                           'share_of_step': v['ms'] / args.steps / ms_per_step} for n, v in k.items()}
+            psteps = 2 if use_graph else args.steps
+            kernels = {n: {'ms_per_launch': v['ms'] / v['count'], 'launches_per_step': v['count'] / psteps,
+                           'share_of_step': v['ms'] / psteps / ms_per_step} for n, v in k.items()}
             res['kernels'] = kernels
             name, v = dom
             t_launch = v['ms'] / v['count'] * 1e-3
@@ -228,7 +246,8 @@ def main():
                                                'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
                                                'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3}
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(args, synthetic.grid_graph(seed=1000, nx=args.nx, ny=args.ny))
+            res['cpu_baseline'] = cpu_baseline(args, synthetic.grid_graph(seed=1000, nx=args.nx, ny=args.ny, clusters=args.clusters,
+                                                                          world=args.world_edges))
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

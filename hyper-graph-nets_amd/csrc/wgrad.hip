@@ -262,6 +262,26 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // Chunk counts: the MFMA tasks (type 0) get one full round of workgroups (2 per CU x 256 CUs) split evenly over the
 // tasks; the LayerNorm-affine tasks (type 1: no MFMA, pure streaming) are launched separately with many small chunks.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                const int* __restrict__ step, float gscale) {
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const double t = (double)(*step);
+    bc[0] = (float)(1.0 - pow((double)b1, t));
+    bc[1] = (float)sqrt(1.0 - pow((double)b2, t));
+  }
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  p[i] -= (lr / bc[0]) * (mi / (sqrtf(vi) / bc[1] + eps));
+}
+__global__ void step_incr_kernel(int* step) { *step += 1; }
+
 static int chunks_mfma(long M, int n_tasks) {
   long c = 512 / (n_tasks > 0 ? n_tasks : 1);
   const long by_rows = (M + 63) / 64;
@@ -352,4 +372,16 @@ extern "C" int hgn_adam_step(float* p, const float* g, float* m, float* v, int64
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr,
                      beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
   return hgn_check_launch("hgn_adam_step");
+}
+
+extern "C" int hgn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                 float eps, int32_t* step_dev, float grad_scale, void* stream) {
+  if (!step_dev) return hgn_fail(HGN_E_INVALID, "hgn_adam_step_dev: null step counter");
+  hipLaunchKernelGGL(step_incr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  if (n == 0) return hgn_check_launch("hgn_adam_step_dev");
+  if (!p || !g || !m || !v || n < 0) return hgn_fail(HGN_E_INVALID, "hgn_adam_step_dev: bad argument");
+  ProfScope ps(9, (double)n, (hipStream_t)stream);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr,
+                     beta1, beta2, eps, step_dev, grad_scale);
+  return hgn_check_launch("hgn_adam_step_dev");
 }

@@ -81,6 +81,8 @@ _SIGS = {
                                  C.c_void_p, C.c_int64, C.c_void_p]),
     'hgn_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    'hgn_adam_step_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
     'hgn_prof_enable': (C.c_int, [C.c_int]),
     'hgn_prof_tag': (C.c_int, [C.c_int]),
     'hgn_prof_reset': (C.c_int, []),

@@ -1,0 +1,85 @@
+"""HIP-graph capture of the launch-bound regimes.
+
+A 15-layer forward is ~130 kernel launches, a training step ~560; on one small graph (the reference's rollout,
+``FlagModel.rollout/_step_fn`` src/model/flag.py:193-246: batch size 1, strictly sequential) the GPU finishes each kernel
+in a few microseconds and the step is bound by launch latency.  Mesh topology is constant along a trajectory (cells are
+static), so the whole forward -- or the whole training step -- is captured ONCE into a HIP graph over static buffers and
+replayed with new features copied in: one hipGraphLaunch per step instead of hundreds of launches.
+
+Capture goes through torch.cuda.CUDAGraph (on ROCm this is hipGraph): the kernels of libhgn_mp.so are launched on torch's
+current stream, which during capture is the capturing stream, so they become graph nodes like any other launch.  The
+topology cache (CSR build, which synchronises) must be warm before capture -- the warm-up calls below do that.
+"""
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from .util import EdgeSet, MultiGraph
+
+
+def _static_copy(graph: MultiGraph) -> MultiGraph:
+    nodes = [x.detach().clone() for x in graph.node_features]
+    sets = [EdgeSet(e.name, e.features.detach().clone(), e.senders, e.receivers) for e in graph.edge_sets]
+    return MultiGraph(nodes, sets)
+
+
+def _copy_in(static: MultiGraph, node_features: Sequence[torch.Tensor], edge_features: Dict[str, torch.Tensor]):
+    for dst, src in zip(static.node_features, node_features):
+        dst.copy_(src, non_blocking=True)
+    for e in static.edge_sets:
+        if e.name in edge_features:
+            e.features.copy_(edge_features[e.name], non_blocking=True)
+
+
+class GraphedForward:
+    """model(graph) for a fixed topology, replayed from a HIP graph (inference / rollout)."""
+
+    def __init__(self, model: torch.nn.Module, example: MultiGraph, warmup: int = 2):
+        self.model = model
+        self.static = _static_copy(example)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                model(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = model(self.static)
+
+    def __call__(self, node_features: Sequence[torch.Tensor], edge_features: Dict[str, torch.Tensor]) -> torch.Tensor:
+        _copy_in(self.static, node_features, edge_features)
+        self.graph.replay()
+        return self.out
+
+
+class GraphedTrainStep:
+    """parallel.DataParallelTrainer.step (forward + loss + backward + fused Adam) for a fixed topology, single process.
+    The trainer must have been built with ``device_step=True`` (the Adam step counter lives on the device)."""
+
+    def __init__(self, trainer, example: MultiGraph, target: torch.Tensor, mask: torch.Tensor, warmup: int = 3):
+        if trainer.world != 1:
+            raise RuntimeError('graph capture of the training step is single-process; the collective stays eager')
+        if trainer.t_dev is None:
+            raise RuntimeError('build the trainer with device_step=True')
+        self.trainer = trainer
+        self.static = _static_copy(example)
+        self.target = target.detach().clone()
+        self.mask = mask.detach().clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                trainer.step(self.static, self.target, self.mask)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = trainer.step(self.static, self.target, self.mask)
+
+    def __call__(self, node_features=None, edge_features: Optional[Dict[str, torch.Tensor]] = None, target=None) -> torch.Tensor:
+        if node_features is not None:
+            _copy_in(self.static, node_features, edge_features or {})
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        return self.loss

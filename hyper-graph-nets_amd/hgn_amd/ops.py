@@ -480,6 +480,16 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
                                         eps, step, grad_scale, _lib.stream_ptr()), 'hgn_adam_step')
 
 
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):
+    """Adam with the step counter on the device (int32 tensor, incremented by the call): capturable into a HIP graph."""
+    for t in (p, g, m, v, step_dev):
+        _lib.require_gpu(t)
+    if step_dev.dtype != torch.int32 or step_dev.numel() != 1:
+        raise _lib.HgnError('step_dev must be a one-element int32 tensor')
+    _lib.check(_lib.lib().hgn_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2,
+                                            eps, step_dev.data_ptr(), grad_scale, _lib.stream_ptr()), 'hgn_adam_step_dev')
+
+
 def prof_enable(on: bool):
     _lib.check(_lib.lib().hgn_prof_enable(1 if on else 0))
 

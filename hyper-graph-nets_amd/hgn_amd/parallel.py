@@ -73,7 +73,8 @@ class DataParallelTrainer:
     """fwd -> global-mean masked MSE -> bwd -> one all-reduce -> fused Adam, on this rank's shard of the batch."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 group: Optional[dist.ProcessGroup] = None, adam_fn: Optional[Callable] = None):
+                 group: Optional[dist.ProcessGroup] = None, adam_fn: Optional[Callable] = None,
+                 device_step: bool = False):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = group
@@ -84,6 +85,8 @@ class DataParallelTrainer:
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.t = 0
+        # device-resident step counter: needed when step() is captured into a HIP graph (graphs.GraphedTrainStep)
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=self.fp.flat.device) if device_step else None
         if adam_fn is None:
             from . import ops
             adam_fn = ops.adam_step
@@ -96,13 +99,17 @@ class DataParallelTrainer:
         n_global = n_local.clone()
         if self.world > 1:
             dist.all_reduce(n_global, group=self.group)
-        diff = (out - target)[mask]
+        diff = (out - target) * mask.unsqueeze(1).to(out.dtype)       # masked without boolean indexing: no host sync, capturable
         loss = diff.square().sum() / (n_global * out.shape[1]).squeeze(0)     # this rank's share of the global mean
         loss.backward()
         if self.world > 1:
             dist.all_reduce(self.fp.grad, group=self.group)                    # ONE collective for all gradients
         self.t += 1
-        self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        if self.t_dev is not None:
+            from . import ops
+            ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t_dev)
+        else:
+            self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
         return loss.detach()
 
 

@@ -183,6 +183,10 @@ int hgn_linear_bwd(const float* g, int64_t ldg, int64_t M, const float* const* W
  * ---------------------------------------------------------------------------------------------------- */
 int hgn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int32_t step, float grad_scale, void* stream);
+/* Same update with the step counter in DEVICE memory: *step_dev is incremented, then used for the bias corrections, so the
+ * call can be captured once into a HIP graph and replayed (a host-side step would be frozen at capture time). */
+int hgn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, int32_t* step_dev, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line).

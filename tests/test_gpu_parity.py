@@ -418,3 +418,43 @@ def test_trainer_flat_gradients_and_adam_match_torch():
     # on the scale of the updates they received (3 steps x lr): 0.5 % of that.
     for (k, p), (_, q) in zip(ref.named_parameters(), flat.named_parameters()):
         assert float((q - p).abs().max()) <= 0.005 * 3 * 1e-3, k
+
+
+def test_hip_graph_forward_and_train_step_replay():
+    """f4: the forward (rollout) and the whole training step captured into a HIP graph replay bit-identically to the eager
+    path on new inputs (fixed topology)."""
+    import hgn_amd
+    from hgn_amd import graphs, parallel
+    g0 = synth.grid_graph(seed=1, nx=12, ny=10)
+    g1 = synth.grid_graph(seed=2, nx=12, ny=10)
+    shapes = O.param_shapes('none', 'sum', 3, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=1)
+
+    def dev(g):
+        return hgn_amd.MultiGraph([x.cuda() for x in g.node_features],
+                                  [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in g.edge_sets])
+    model = H.hip_model('none', 'sum', 3, ['mesh_edges'], sd)
+    G0, G1 = dev(g0), dev(g1)
+    gf = graphs.GraphedForward(model, G0)
+    with torch.no_grad():
+        ref0, ref1 = model(G0).clone(), model(G1).clone()
+    out0 = gf(G0.node_features, {'mesh_edges': G0.edge_sets[0].features}).clone()
+    out1 = gf(G1.node_features, {'mesh_edges': G1.edge_sets[0].features}).clone()
+    assert torch.equal(out0, ref0) and torch.equal(out1, ref1)
+    # training step
+    N = 120
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(0)).cuda()
+    mask = torch.ones(N, dtype=torch.bool).cuda()
+    eager = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 3, ['mesh_edges'], sd), lr=1e-3)
+    captured = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 3, ['mesh_edges'], sd), lr=1e-3, device_step=True)
+    for _ in range(3):                                   # GraphedTrainStep warms up with 3 eager steps + 1 captured
+        eager.step(G0, target, mask)
+    gs = graphs.GraphedTrainStep(captured, G0, target, mask, warmup=3)
+    eager.step(G0, target, mask)                          # the step executed during capture? no: capture does not execute
+    l_e = [float(eager.step(G1, target, mask)) for _ in range(2)]
+    gs()                                                  # replay #1 on G0 (matches eager's 4th step)
+    l_g = [float(gs(G1.node_features, {'mesh_edges': G1.edge_sets[0].features})) for _ in range(2)]
+    assert int(captured.t_dev) == 6
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 1e-6 * abs(a)
+    assert H.rel_err(captured.fp.flat, eager.fp.flat) <= 1e-6
