@@ -300,7 +300,7 @@ extern "C" int hgn_segment_reduce_fwd(const float* data, int64_t ld, int D, cons
   bool need_arg = false;
   for (int i = 0; i < n_ops; ++i) need_arg |= ops[i] >= HGN_OP_MAX;
   (void)need_arg;
-  ProfScope ps(5, (double)N, (hipStream_t)stream);
+  ProfScope ps(g_prof_tag == 2 ? 12 : 5, (double)N, (hipStream_t)stream);
   const bool fast = D == 128 && (ld & 3) == 0 && (ld_out & 3) == 0 && ((uintptr_t)data & 15) == 0 && ((uintptr_t)out & 15) == 0;
   if (fast) {
     hipLaunchKernelGGL(seg_fwd128_kernel, dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, data,

@@ -12,10 +12,10 @@ LIB_PATH = os.path.join(_HERE, 'libhgn_mp.so')
 HGN_MAX_SRC = 8
 HGN_MAX_ADD = 2
 HGN_MAX_WTASK = 16
-NUM_KERNEL_IDS = 12
+NUM_KERNEL_IDS = 14
 OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
 KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
-                'linear_bwd', 'adam', 'csr', 'wgrad_node']
+                'linear_bwd', 'adam', 'csr', 'wgrad_node', 'seg_fwd_agg', 'reserved']
 
 c_f32p = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 c_i32p = C.c_void_p

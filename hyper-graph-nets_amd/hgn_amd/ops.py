@@ -18,8 +18,21 @@ LAT = 128
 _ws_cache = {}
 
 
-def _workspace(device, nbytes: int) -> torch.Tensor:
-    key = (device.type, device.index)
+_WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
+
+
+def set_wgrad_stream(stream):
+    """Run every hgn_mlp_wgrad launch on `stream` (forked from / joined to the current stream by the caller).
+
+    Weight gradients are only consumed by the optimiser, so they need not sit on the critical path of the backward pass;
+    on a second stream they co-run with the next layer's backward kernels, whose memory-bound and MFMA-bound phases they
+    fill.  Only valid when the consumer joins the stream before reading gradients (the flat-buffer trainer does)."""
+    global _WGRAD_STREAM
+    _WGRAD_STREAM = stream
+
+
+def _workspace(device, nbytes: int, tag: str = 'wgrad') -> torch.Tensor:
+    key = (device.type, device.index, tag)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
@@ -90,7 +103,19 @@ def _alloc_saves(M, has_ln, dev):
     return z1, z2, xhat, rstd
 
 
-def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False):
+def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False, keep=()):
+    side = _WGRAD_STREAM
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+        for t in keep:                       # operands were allocated on the main stream: keep them alive for the side stream
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            _run_wgrad_here(tasks, M, dev, edge_level)
+        return
+    _run_wgrad_here(tasks, M, dev, edge_level)
+
+
+def _run_wgrad_here(tasks: List[_lib.WTask], M: int, dev, edge_level: bool):
     L = _lib.lib()
     L.hgn_prof_tag(0 if edge_level else 1)
     for i in range(0, len(tasks), _lib.HGN_MAX_WTASK):
@@ -105,7 +130,7 @@ def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False):
 def _ln_workspace(M: int, dev) -> torch.Tensor:
     nb = C.c_size_t(0)
     _lib.check(_lib.lib().hgn_mlp_bwd_ln_workspace_bytes(M, C.byref(nb)), 'hgn_mlp_bwd_ln_workspace_bytes')
-    return _workspace(dev, nb.value)
+    return _workspace(dev, nb.value, 'ln')
 
 
 def _grad_targets(wt):
@@ -236,7 +261,7 @@ class MLPFn(torch.autograd.Function):
                                     dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * (cols[i] + k0), ldw1,
                                     db1.data_ptr() if first else None, accs[0]))
                 first = False
-        _run_wgrad(tasks, M, dev)
+        _run_wgrad(tasks, M, dev, keep=[z1, z2, dz1, dz2, dz3, *srcs])
         # ---- un-gather source gradients -----------------------------------------------------------------------
         for i in range(n_src):
             if dxs[i] is not None and idxs[i] is not None:
@@ -303,9 +328,11 @@ class EdgeBlockFn(torch.autograd.Function):
                 amax = torch.empty(N, LAT, dtype=torch.int32, device=dev)
             if train and 3 in codes:
                 amin = torch.empty(N, LAT, dtype=torch.int32, device=dev)
+            L.hgn_prof_tag(2)
             _lib.check(L.hgn_segment_reduce_fwd(out.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr(), N, arr, k,
                                                 agg.data_ptr(), k * LAT, amax.data_ptr() if amax is not None else None,
                                                 amin.data_ptr() if amin is not None else None, st), 'hgn_segment_reduce_fwd')
+            L.hgn_prof_tag(0)
         if train:
             ctx.set_materialize_grads(False)
             ctx.topo = topo
@@ -367,7 +394,7 @@ class EdgeBlockFn(torch.autograd.Function):
                  _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2]),
                  _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
                         db1.data_ptr(), accs[0])]
-        _run_wgrad(tasks, E, dev, edge_level=True)
+        _run_wgrad(tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
         # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]
         dP = torch.empty(N, 2 * LAT, device=dev)
         ops = (C.c_int32 * 1)(0)
@@ -379,7 +406,7 @@ class EdgeBlockFn(torch.autograd.Function):
                         accs[0]),
                  _wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr() + 4 * LAT, 2 * LAT, LAT,
                         dw1.data_ptr() + 4 * LAT, 3 * LAT, None, accs[0])]
-        _run_wgrad(tasks, N, dev)
+        _run_wgrad(tasks, N, dev, keep=[h_all, dP])
         dh = None
         if ctx.needs_input_grad[3]:
             dh = torch.empty(N, LAT, device=dev)

@@ -74,7 +74,7 @@ class DataParallelTrainer:
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  group: Optional[dist.ProcessGroup] = None, adam_fn: Optional[Callable] = None,
-                 device_step: bool = False):
+                 device_step: bool = False, wgrad_stream: bool = True):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = group
@@ -91,9 +91,14 @@ class DataParallelTrainer:
             from . import ops
             adam_fn = ops.adam_step
         self.adam_fn = adam_fn
+        self.side = torch.cuda.Stream() if (wgrad_stream and self.fp.flat.is_cuda) else None
 
     def step(self, graph, target: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         self.fp.zero_grad()
+        if self.side is not None:
+            from . import ops
+            self.side.wait_stream(torch.cuda.current_stream())      # the zeroed gradient buffer is visible to the side stream
+            ops.set_wgrad_stream(self.side)
         out = self.model(graph)
         n_local = mask.sum().to(torch.float32).reshape(1)
         n_global = n_local.clone()
@@ -102,6 +107,9 @@ class DataParallelTrainer:
         diff = (out - target) * mask.unsqueeze(1).to(out.dtype)       # masked without boolean indexing: no host sync, capturable
         loss = diff.square().sum() / (n_global * out.shape[1]).squeeze(0)     # this rank's share of the global mean
         loss.backward()
+        if self.side is not None:
+            ops.set_wgrad_stream(None)
+            torch.cuda.current_stream().wait_stream(self.side)      # join: all weight gradients are in the flat buffer
         if self.world > 1:
             dist.all_reduce(self.fp.grad, group=self.group)                    # ONE collective for all gradients
         self.t += 1

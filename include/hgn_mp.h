@@ -192,10 +192,12 @@ int hgn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, f
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line).
  * kernel ids: 0 mlp_fwd(edge) 1 mlp_fwd(other) 2 mlp_bwd(edge) 3 mlp_bwd(other) 4 wgrad 5 seg_fwd 6 seg_bwd
  *             7 linear_fwd 8 linear_bwd 9 adam 10 csr 11 wgrad on node rows (hgn_prof_tag(1) before the call)
+ *             12 seg_fwd launched as the forward aggregation (hgn_prof_tag(2) before the call)
  * ---------------------------------------------------------------------------------------------------- */
-#define HGN_NUM_KERNEL_IDS 12
+#define HGN_NUM_KERNEL_IDS 14
 int hgn_prof_enable(int on);
-int hgn_prof_tag(int tag);   /* thread-local: 1 marks the following hgn_mlp_wgrad launches as node-level */
+int hgn_prof_tag(int tag);   /* thread-local: 1 = following hgn_mlp_wgrad launches are node-level, 2 = following
+                                hgn_segment_reduce_fwd launches are the forward aggregation, 0 = reset */
 int hgn_prof_reset(void);
 int hgn_prof_collect(double* total_ms /*host [HGN_NUM_KERNEL_IDS]*/, int64_t* count /*host*/,
                      double* units /*host: rows processed*/);
