@@ -229,7 +229,7 @@ using namespace hgn;
 
 static size_t cub_temp_bytes(int64_t E, int64_t N) {
   size_t t = 0;
-  hipcub::DeviceRadixSort::SortPairs<int, int>(nullptr, t, nullptr, nullptr, nullptr, nullptr, (int)E, 0, sort_bits(N));
+  (void)hipcub::DeviceRadixSort::SortPairs<int, int>(nullptr, t, nullptr, nullptr, nullptr, nullptr, (int)E, 0, sort_bits(N));
   return t;
 }
 

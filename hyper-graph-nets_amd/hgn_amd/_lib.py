@@ -1,4 +1,4 @@
-"""ctypes binding of libhgn_mp.so (C ABI: include/hgn_mp.h).
+"""ctypes binding of libhgn_mp.so (C ABI: include/hgn_mp.h, include/hgn_features.h).
 
 The library is the product path: if it is missing or a symbol is absent this module raises -- there is no
 PyTorch/CPU fallback anywhere in the package.
@@ -15,7 +15,7 @@ HGN_MAX_WTASK = 16
 NUM_KERNEL_IDS = 14
 OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
 KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
-                'linear_bwd', 'adam', 'csr', 'wgrad_node', 'seg_fwd_agg', 'reserved']
+                'linear_bwd', 'adam', 'csr', 'wgrad_node', 'seg_fwd_agg', 'features']
 
 c_f32p = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 c_i32p = C.c_void_p
@@ -83,6 +83,23 @@ _SIGS = {
                                 C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
     'hgn_adam_step_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
+    # include/hgn_features.h
+    'hgn_cells_to_edges_workspace_bytes': (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
+    'hgn_cells_to_edges': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    'hgn_rel_edge_features': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_void_p]),
+    'hgn_node_features': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    'hgn_col_stats_workspace_bytes': (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
+    'hgn_col_stats': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'hgn_normalizer_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_float, C.c_void_p]),
+    'hgn_normalize': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                C.c_int, C.c_void_p, C.c_void_p]),
+    'hgn_lincomb3': (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int64,
+                               C.c_void_p, C.c_void_p]),
     'hgn_prof_enable': (C.c_int, [C.c_int]),
     'hgn_prof_tag': (C.c_int, [C.c_int]),
     'hgn_prof_reset': (C.c_int, []),

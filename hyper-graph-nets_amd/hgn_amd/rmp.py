@@ -1,0 +1,298 @@
+"""Remote message passing: cluster the mesh, add hyper nodes and the three remote edge sets
+(reference: src/rmp/remote_message_passing.py, hierarchical_connector.py, abstract_connector.py,
+abstract_clustering_algorithm.py, k_means_clustering.py, spectral_clustering.py, gaussian_mixture.py,
+random_clustering.py, get_rmp.py).
+
+Split the way the hardware wants it:
+  * cluster LABELS are a once-per-trajectory host step and stay on scikit-learn, like the reference;
+  * everything the reference redoes per frame in Python loops over clusters (cluster means, spreads, hyper-node
+    features, up / down / inter edge features, their normalisation) is device work here: the cluster membership
+    becomes a CSR over the hyper nodes once, and each frame is a handful of launches of the segment-reduce and
+    relative-feature kernels (include/hgn_mp.h, include/hgn_features.h) -- no per-cluster host loop, no host copy
+    of positions.
+"""
+import math
+import random
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import features, ops, topology
+from .normalizer import Normalizer
+from .util import EdgeSet, MultiGraph, MultiGraphWithPos, device
+
+
+# ------------------------------------------------------------------------------------------------------------
+# clustering (host, once per trajectory)
+# ------------------------------------------------------------------------------------------------------------
+class AbstractClusteringAlgorithm:
+    """abstract_clustering_algorithm.py: ``run`` -> list of index tensors, plus ``neigboring_clusters``."""
+
+    def __init__(self, num_clusters=10, sampling=False, alpha=0.5, threshold=0):
+        self._num_clusters = num_clusters
+        self._sampling = sampling
+        self._alpha = alpha
+        self._threshold = threshold
+        self._labels = None
+        self.neigboring_clusters = None
+
+    def _cluster(self, graph: MultiGraphWithPos) -> Sequence[int]:
+        raise NotImplementedError
+
+    def run(self, graph: MultiGraphWithPos, number=0, b4=True) -> List[Tensor]:
+        """abstract_clustering_algorithm.py:59-84."""
+        if self._sampling:
+            raise NotImplementedError('intra_cluster_sampling is not part of the accelerated path '
+                                      '(configs ship it disabled: flag.yaml:42-45)')
+        labels = self._empty_cluster_handling([int(x) for x in self._cluster(graph)])
+        self._labels = [-1] * number + labels if b4 else labels + [-1] * number
+        self.neigboring_clusters = self.get_neigbors(graph, self._labels)
+        return self._labels_to_indices(labels)
+
+    def _empty_cluster_handling(self, labels: List[int]) -> List[int]:
+        """abstract_clustering_algorithm.py:91-102: an empty cluster steals a random node of a non-empty one."""
+        result = [[] for _ in range(self._num_clusters)]
+        for i, l in enumerate(labels):
+            result[l].append(i)
+        for i in range(self._num_clusters):
+            if len(result[i]) == 0:
+                donor = random.choice([x for x in range(self._num_clusters) if len(result[x]) > 0])
+                labels[random.choice(result[donor])] = i
+        return labels
+
+    @staticmethod
+    def _labels_to_indices(labels: Sequence[int]) -> List[Tensor]:
+        """abstract_clustering_algorithm.py:104-122 (ascending node ids per cluster, label -1 skipped)."""
+        lab = np.asarray(labels)
+        return [torch.from_numpy(np.nonzero(lab == k)[0]) for k in range(int(lab.max()) + 1)]
+
+    @staticmethod
+    def get_neigbors(graph: MultiGraphWithPos, labels: Sequence[int]) -> List[Tensor]:
+        """abstract_clustering_algorithm.py:124-145: unordered pairs of different labels joined by a mesh edge.
+        (The reference's list order is Python set order; here: sorted pairs.)"""
+        es = [x for x in graph.edge_sets if x.name == 'mesh_edges'][0]
+        lab = np.asarray(labels)
+        a = lab[es.senders.cpu().numpy()]
+        b = lab[es.receivers.cpu().numpy()]
+        keep = a != b
+        lo, hi = np.minimum(a[keep], b[keep]), np.maximum(a[keep], b[keep])
+        pairs = np.unique(np.stack([lo, hi], 1), axis=0) if lo.size else np.zeros((0, 2), dtype=np.int64)
+        return [torch.tensor([int(p[0]), int(p[1])]) for p in pairs]
+
+    def visualize_cluster(self, coordinates):          # logging only in the reference (wandb): no-op here
+        return None
+
+
+class KMeansClustering(AbstractClusteringAlgorithm):
+    def _cluster(self, graph):                           # k_means_clustering.py:27-33
+        import sklearn.cluster
+        from sklearn.preprocessing import StandardScaler
+        X = StandardScaler().fit_transform(graph.mesh_features.cpu().numpy()[:, :2])
+        return sklearn.cluster.KMeans(n_clusters=self._num_clusters, random_state=0).fit(X).labels_
+
+
+class GaussianMixtureClustering(AbstractClusteringAlgorithm):
+    def _cluster(self, graph):                           # gaussian_mixture.py:24-30
+        from sklearn.mixture import GaussianMixture
+        from sklearn.preprocessing import StandardScaler
+        X = StandardScaler().fit_transform(graph.target_feature.cpu().numpy())
+        gm = GaussianMixture(n_components=self._num_clusters, random_state=0, init_params='k-means++').fit(X)
+        return gm.predict(X)
+
+
+class RandomClustering(AbstractClusteringAlgorithm):
+    def _cluster(self, graph):                           # random_clustering.py:38-39
+        return [int(x) for x in np.random.rand(graph.target_feature.shape[0]) * self._num_clusters]
+
+
+class SpectralClustering(AbstractClusteringAlgorithm):
+    def _cluster(self, graph):                           # spectral_clustering.py:26-64
+        import sklearn.cluster
+        X = self._compute_affinity_matrix(graph)
+        sc = sklearn.cluster.SpectralClustering(n_clusters=self._num_clusters, random_state=0, affinity='precomputed',
+                                                assign_labels='cluster_qr')
+        return sc.fit(X).labels_
+
+    @staticmethod
+    def _compute_affinity_matrix(graph):
+        """spectral_clustering.py:37-64: affinity = 1 / sqrt(|rel world|^2 + |rel mesh|^2) on mesh edges; edges of
+        zero length get (largest finite affinity + 1)."""
+        n = len(graph.node_features)
+        e = graph.unnormalized_edges
+        f = e.features.detach().cpu().double().numpy()
+        s, r = e.senders.cpu().numpy(), e.receivers.cpu().numpy()
+        with np.errstate(divide='ignore'):
+            w = 1.0 / np.sqrt(f[:, 3] ** 2 + f[:, -1] ** 2)
+        A = np.zeros((n, n), float)
+        fin = np.isfinite(w)
+        A[s[fin], r[fin]] = w[fin]
+        A[s[~fin], r[~fin]] = (w[fin].max() if fin.any() else 0.0) + 1
+        return A
+
+
+# ------------------------------------------------------------------------------------------------------------
+# connector (device, per frame)
+# ------------------------------------------------------------------------------------------------------------
+class _ClusterTopology:
+    """Index tensors derived once from (clusters, neighbours, N): membership CSR over the K hyper nodes, the
+    up/down edge ids and the inter-cluster edge ids.  Member order = concatenation of the cluster lists, the order in
+    which the reference emits the intra-cluster edges (hierarchical_connector.py:85-100)."""
+
+    def __init__(self, clusters: Sequence[Tensor], neighbors: Sequence[Tensor], num_nodes: int, fully_connect: bool,
+                 dev):
+        K = len(clusters)
+        sizes = [int(len(c)) for c in clusters]
+        members = torch.cat([torch.as_tensor(c).long() for c in clusters]).to(dev)
+        label = torch.repeat_interleave(torch.arange(K), torch.tensor(sizes)).to(dev)
+        hyper = label + num_nodes
+        self.K, self.N, self.M = K, num_nodes, int(members.numel())
+        self.sizes = torch.tensor(sizes, dtype=torch.float32, device=dev)
+        self.members, self.label, self.hyper = members, label, hyper
+        csr = topology.CSR(label, K)
+        # the kernels read data row perm[j]: compose with the member list so they read node rows directly
+        self.node_perm = members[csr.perm.long()].to(torch.int32).contiguous()
+        self.csr = csr
+        # abstract_connector.py:86-87: senders = [s ; r], receivers = [r ; s]
+        self.up_down_s = torch.cat([hyper, members]).contiguous()
+        self.up_down_r = torch.cat([members, hyper]).contiguous()
+        if fully_connect or K < 4:                       # hierarchical_connector.py:128-129, 207-212
+            idx = torch.combinations(torch.arange(num_nodes, num_nodes + K), with_replacement=True)
+            idx = idx[idx[:, 0] != idx[:, 1]]
+        else:                                            # :132, :201-205
+            idx = (torch.stack([torch.as_tensor(n).long() for n in neighbors]) + num_nodes) if len(neighbors) else \
+                torch.zeros(0, 2, dtype=torch.int64)
+        s, r = idx[:, 0].to(dev), idx[:, 1].to(dev)
+        self.inter_s = torch.cat([s, r]).contiguous()
+        self.inter_r = torch.cat([r, s]).contiguous()
+
+
+class AbstractConnector:
+    def __init__(self, fully_connect, noise_scale, hyper_node_features):
+        self._intra_normalizer = None
+        self._inter_normalizer = None
+        self._hyper_normalizer = None
+        self._fully_connect = fully_connect
+        self._noise_scale = noise_scale
+        self._hyper_node_features = hyper_node_features
+
+    def initialize(self, intra: Normalizer, inter: Normalizer, hyper: Normalizer) -> List:
+        self._intra_normalizer, self._inter_normalizer, self._hyper_normalizer = intra, inter, hyper
+        return list()
+
+
+class HierarchicalConnector(AbstractConnector):
+    """hierarchical_connector.py:16-143 with the per-cluster Python loops replaced by segmented device passes."""
+
+    def __init__(self, fully_connect, noise_scale, hyper_node_features):
+        super().__init__(fully_connect, noise_scale, hyper_node_features)
+        self._topo_key = None
+        self._topo = None
+
+    def initialize(self, intra, inter, hyper):
+        super().initialize(intra, inter, hyper)
+        return ['intra_cluster_to_mesh', 'intra_cluster_to_cluster', 'inter_cluster']
+
+    def _cluster_topology(self, clusters, neighbors, N, dev) -> _ClusterTopology:
+        key = (id(clusters), len(clusters), N, id(neighbors))
+        if self._topo_key != key:
+            self._topo = _ClusterTopology(clusters, neighbors, N, self._fully_connect, dev)
+            self._topo_key = key
+            self._keep = (clusters, neighbors)           # the ids in the key stay valid while we hold the objects
+        return self._topo
+
+    def run(self, graph: MultiGraphWithPos, clusters: List[Tensor], neighbors: List[Tensor], is_training: bool,
+            noise: Optional[Tensor] = None) -> MultiGraph:
+        if graph.model_type not in ('flag', 'plate'):
+            raise Exception('Model type is not specified in RippleNodeConnector.')       # abstract_connector.py:97
+        nf = graph.node_features.to(device)
+        N = nf.shape[0]
+        cf = torch.cat((graph.target_feature.to(device), graph.mesh_features.to(device)), dim=1)   # :29
+        t = self._cluster_topology(clusters, neighbors, N, cf.device)
+        C = cf.shape[1]
+        # cluster means of [clustering features | node features]: one segment-mean pass over the member rows
+        both = torch.cat((cf, nf), dim=1)
+        means_all = ops.aggregate([both], [(t.node_perm, t.csr.rowptr, t.csr.seg)], ('mean',))     # :39-45
+        means, nf_means = means_all[:, :C], means_all[:, C:]
+        if noise is None and is_training and self._noise_scale is not None:                         # :48-51
+            noise = torch.normal(torch.zeros_like(means), std=self._noise_scale)
+        if noise is not None:
+            means = means + noise.to(means.device)
+        tf = torch.cat((cf, means), dim=0).contiguous()               # rows [mesh ; hyper] (abstract_connector.py:85)
+        world, mesh = tf[:, :3], tf[:, 3:]
+        # intra-cluster edges, both directions in one pass: first half hyper->mesh, second half mesh->hyper
+        f_ud, _ = features.rel_edge_features(world, mesh, t.up_down_s, t.up_down_r)
+        if self._hyper_node_features:                                  # :54-71
+            spread_world_d = f_ud[:t.M, 3]                             # |mean[:3] - point[:3]| is the down-edge length
+            if C == 6:
+                spread_mesh_d = f_ud[:t.M, 7]
+            else:                                                      # columns [-3:] straddle world and mesh (flag)
+                _, spread_mesh_d = features.rel_edge_features(tf[:, C - 3:], None, t.up_down_s[:t.M],
+                                                              t.up_down_r[:t.M], want_feat=False, want_len=True)
+            d = torch.stack((spread_mesh_d, spread_world_d), dim=1).contiguous()
+            spreads = ops.aggregate([d], [(t.csr.perm, t.csr.rowptr, t.csr.seg)], ('max',))
+            aug = torch.cat((t.sizes.unsqueeze(1), spreads), dim=1)
+            aug = self._hyper_normalizer(aug, is_training)
+            nf_means = torch.cat((nf_means, aug), dim=1)
+        e_c = self._intra_normalizer(f_ud[t.M:], is_training)          # :104 (to_cluster is normalised first)
+        e_m = self._intra_normalizer(f_ud[:t.M], is_training)          # :117
+        to_cluster = EdgeSet('intra_cluster_to_cluster', e_c, t.up_down_s[t.M:], t.up_down_r[t.M:])
+        to_mesh = EdgeSet('intra_cluster_to_mesh', e_m, t.up_down_s[:t.M], t.up_down_r[:t.M])
+        f_i, _ = features.rel_edge_features(world, mesh, t.inter_s, t.inter_r)
+        inter = EdgeSet('inter_cluster', self._inter_normalizer(f_i, is_training), t.inter_s, t.inter_r)
+        edge_sets = list(graph.edge_sets)
+        edge_sets.extend([to_cluster, to_mesh, inter])                 # :140-141
+        return MultiGraph(node_features=[nf, nf_means.contiguous()], edge_sets=edge_sets)
+
+
+class RemoteMessagePassing:
+    """remote_message_passing.py:11-150."""
+
+    def __init__(self, clustering_algorithm: AbstractClusteringAlgorithm, connector: AbstractConnector):
+        self._clustering_algorithm = clustering_algorithm
+        self._node_connector = connector
+        self._clusters = None
+        self._neighbors = None
+
+    def initialize(self, intra: Normalizer, inter: Normalizer, hyper: Normalizer) -> List:
+        return self._node_connector.initialize(intra, inter, hyper)
+
+    def create_graph(self, graph: MultiGraphWithPos, is_training: bool) -> MultiGraph:
+        graph = graph._replace(node_features=graph.node_features[0])          # :67
+        if self._clusters is None:
+            if graph.obstacle_nodes is not None:
+                raise NotImplementedError('obstacle removal (plate) is not part of the accelerated path yet')
+            self._clusters = self._clustering_algorithm.run(graph)
+            self._neighbors = self._clustering_algorithm.neigboring_clusters
+        return self._node_connector.run(graph, self._clusters, self._neighbors, is_training)
+
+    def reset_clusters(self):
+        self._clusters = None
+
+    def visualize_cluster(self, graph):
+        self._clustering_algorithm.visualize_cluster(graph)
+
+
+def get_rmp(config) -> RemoteMessagePassing:
+    """get_rmp.py:20-98."""
+    rmp = config['rmp']
+    name, connector = str(rmp['clustering']).lower(), str(rmp['connector']).lower()
+    samp = rmp.get('intra_cluster_sampling', {})
+    args = (rmp['num_clusters'], samp.get('enabled', False), samp.get('alpha', 0.5), samp.get('spotter_threshold', 0))
+    table = {'random': RandomClustering, 'spectral': SpectralClustering, 'gmm': GaussianMixtureClustering,
+             'kmeans': KMeansClustering, 'k-means': KMeansClustering}
+    if name == 'none':
+        clustering = None
+    elif name in table:
+        clustering = table[name](*args)
+    else:
+        raise NotImplementedError('Implement your clustering algorithms here!')
+    noise = None if rmp['hyper_noise'] == 'none' else rmp['hyper_noise']
+    if connector in ('hyper', 'hetero', 'multiscale'):
+        conn = HierarchicalConnector(rmp['fully_connect'], noise, rmp['hyper_node_features'])
+    elif connector in ('none', 'repeated'):
+        conn = None
+    else:
+        raise NotImplementedError('Implement your connectors here!')
+    return RemoteMessagePassing(clustering, conn)

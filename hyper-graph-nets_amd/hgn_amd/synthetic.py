@@ -125,3 +125,40 @@ def batch(graphs) -> MultiGraph:
         out.append(EdgeSet(name, torch.cat(fs), torch.cat(ss), torch.cat(rs)))
     nodes = [torch.cat([g.node_features[j] for g in graphs]) for j in range(len(graphs[0].node_features))]
     return MultiGraph(nodes, out)
+
+
+def flag_frame(seed: int = 0, nx: int = 40, ny: int = 40, dtype=torch.float32) -> dict:
+    """One flag_simple-shape data frame as the reference's dataset hands it to ``FlagModel.build_graph``
+    (src/model/flag.py:65-71): world/prev/target positions [N,3], mesh_pos [N,2], node_type [N,1], cells [F,3]."""
+    g = torch.Generator().manual_seed(seed)
+    N = nx * ny
+    xs = torch.linspace(0, 3, nx)
+    ys = torch.linspace(0, 2, ny)
+    mesh_pos = torch.stack(torch.meshgrid(xs, ys, indexing='ij'), -1).reshape(N, 2).to(dtype)
+    world_pos = torch.cat([mesh_pos, 0.1 * torch.randn(N, 1, generator=g, dtype=dtype)], -1)
+    prev = world_pos + 0.01 * torch.randn(N, 3, generator=g, dtype=dtype)
+    target = world_pos + 0.01 * torch.randn(N, 3, generator=g, dtype=dtype)
+    node_type = torch.zeros(N, 1, dtype=torch.int32)
+    node_type[:3] = 3                                    # HANDLE (src/util.py:27-35)
+    return {'world_pos': world_pos, 'prev|world_pos': prev, 'target|world_pos': target, 'mesh_pos': mesh_pos,
+            'node_type': node_type, 'cells': grid_triangles(nx, ny)}
+
+
+def cylinder_frame(seed: int = 0, nx: int = 30, ny: int = 20, dtype=torch.float32) -> dict:
+    """One cylinder_flow-shape frame (src/model/cylinder.py:65-87): velocity [N,2], mesh_pos [N,2], node types
+    NORMAL / INFLOW(4) / OUTFLOW(5) / WALL_BOUNDARY(6)."""
+    g = torch.Generator().manual_seed(seed)
+    N = nx * ny
+    xs = torch.linspace(0, 1.6, nx)
+    ys = torch.linspace(0, 0.4, ny)
+    mesh_pos = torch.stack(torch.meshgrid(xs, ys, indexing='ij'), -1).reshape(N, 2).to(dtype)
+    velocity = torch.randn(N, 2, generator=g, dtype=dtype)
+    target = velocity + 0.01 * torch.randn(N, 2, generator=g, dtype=dtype)
+    node_type = torch.zeros(nx, ny, dtype=torch.int32)
+    node_type[0, :] = 4
+    node_type[-1, :] = 5
+    node_type[:, 0] = 6
+    node_type[:, -1] = 6
+    return {'velocity': velocity, 'target|velocity': target, 'mesh_pos': mesh_pos,
+            'node_type': node_type.reshape(N, 1), 'cells': grid_triangles(nx, ny),
+            'pressure': torch.randn(N, 1, generator=g, dtype=dtype)}

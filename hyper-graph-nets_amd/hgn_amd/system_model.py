@@ -1,0 +1,302 @@
+"""System models with the reference's class API (src/model/abstract_system_model.py, flag.py, cylinder.py): frame ->
+graph features on the device, remote-graph expansion, training / validation step, one-step update and rollout around
+the MI355X message-passing model.
+
+Per frame the reference runs ~40 small torch ops plus Python loops; here ``build_graph`` is a fixed handful of HIP
+launches (include/hgn_features.h): node features, relative edge features (+ edge lengths), one segment max/min pass
+for the node dynamics, and three launches per normaliser.  The mesh topology (cells -> two-way edges, receiver CSR) is
+computed once per ``cells`` tensor and reused for the whole trajectory (the reference recomputes it every frame,
+flag.py:76-78).
+"""
+import math
+from typing import Dict, Tuple
+
+import torch
+from torch import nn, Tensor
+
+from . import features, ops, topology
+from . import rmp as _rmp
+from .modules import MeshGraphNet
+from .normalizer import Normalizer
+from .util import EdgeSet, MultiGraph, MultiGraphWithPos, NodeType, device
+
+
+def _masked_mse(target: Tensor, output: Tensor, mask: Tensor) -> Tensor:
+    """MSELoss()(target[mask], output[mask]) (flag.py:150-152) without the boolean-index host sync."""
+    m = mask.to(output.dtype).unsqueeze(1)
+    return (((output - target) ** 2) * m).sum() / (m.sum() * output.shape[1])
+
+
+class AbstractSystemModel(nn.Module):
+    """abstract_system_model.py:10-190 (the shared constructor logic of flag.py:21-63 / cylinder.py:21-63 lives here)."""
+    _model_type = None
+
+    def __init__(self, params, node_size: int, edge_size: int) -> None:
+        super().__init__()
+        self._params = params
+        self.loss_fn = torch.nn.MSELoss()
+        self._output_normalizer = Normalizer(size=3, name='output_normalizer')
+        self._node_normalizer = Normalizer(size=node_size, name='node_normalizer')
+        self._node_dynamic_normalizer = Normalizer(size=1, name='node_dynamic_normalizer')
+        self._mesh_edge_normalizer = Normalizer(size=edge_size, name='mesh_edge_normalizer')
+        self._intra_edge_normalizer = Normalizer(size=7, name='intra_edge_normalizer')
+        self._inter_edge_normalizer = Normalizer(size=7, name='inter_edge_normalizer')
+        self._hyper_node_normalizer = Normalizer(size=3, name='hyper_node_normalizer')
+        r, b = params.get('rmp'), params.get('graph_balancer')
+        self._rmp = r.get('clustering') != 'none' and r.get('connector') != 'none'
+        self._architecture = r.get('connector') if self._rmp else 'none'
+        self._multi = r.get('connector') == 'multigraph' and self._rmp
+        self._balancer = b.get('algorithm') != 'none'
+        self.message_passing_steps = params.get('message_passing_steps')
+        self.message_passing_aggregator = params.get('aggregation')
+        self._balance_frequency = b.get('frequency')
+        self._rmp_frequency = r.get('frequency')
+        self._visualized = False
+        self._edge_sets = ['mesh_edges']
+        if self._balancer:
+            raise NotImplementedError('graph balancers (Ricci / SDRF / random) are outside the accelerated path; a '
+                                      "'balance' edge set built elsewhere can be passed to MeshGraphNet directly")
+        if self._rmp:
+            self._remote_graph = _rmp.get_rmp(params)
+            self._edge_sets += self._remote_graph.initialize(
+                self._intra_edge_normalizer, self._inter_edge_normalizer, self._hyper_node_normalizer)
+        self.learned_model = MeshGraphNet(
+            output_size=params.get('size'), latent_size=128, num_layers=2,
+            message_passing_steps=self.message_passing_steps,
+            message_passing_aggregator=self.message_passing_aggregator,
+            architecture=self._architecture, edge_sets=self._edge_sets).to(device)
+        self._cells_key = None
+        self._cells_edges = None
+
+    # ---- topology, once per mesh ------------------------------------------------------------------------------
+    def _mesh_edges(self, cells: Tensor, deform: bool = False):
+        """util.triangles_to_edges on the device, cached while the same ``cells`` tensor (or equal content) comes in."""
+        hit = self._cells_key is not None and (
+            self._cells_key is cells or (self._cells_key.shape == cells.shape and self._cells_key.device == cells.device
+                                         and torch.equal(self._cells_key, cells)))
+        if not hit:
+            s, r, _ = features.cells_to_edges(cells.to(device), deform)
+            self._cells_key, self._cells_edges = cells, (s, r)
+        return self._cells_edges
+
+    def expand_graph(self, graph: MultiGraphWithPos, step: int, num_steps: int, is_training: bool) -> MultiGraph:
+        """flag.py:130-141 / cylinder.py:108-119."""
+        if self._rmp:
+            if step % math.ceil(num_steps / self._rmp_frequency) == 0:
+                self._remote_graph.reset_clusters()
+            graph = self._remote_graph.create_graph(graph, is_training)
+        return graph
+
+    def forward(self, graph):
+        return self.learned_model(graph)
+
+    def evaluate(self) -> None:
+        self.eval()
+        self.learned_model.eval()
+
+    @torch.no_grad()
+    def n_step_computation(self, trajectory: Dict[str, Tensor], n_step: int, num_timesteps=None) -> Tuple[Tensor, Tensor]:
+        """flag.py:248-260."""
+        mse_losses, last_losses = [], []
+        num_timesteps = trajectory['cells'].shape[0] if num_timesteps is None else num_timesteps
+        for step in range(num_timesteps - n_step):
+            eval_traj = {k: v[step: step + n_step + 1] for k, v in trajectory.items()}
+            _, mse_loss = self.rollout(eval_traj, n_step + 1)
+            mse_losses.append(torch.mean(mse_loss).cpu())
+            last_losses.append(mse_loss.cpu()[-1])
+        return torch.mean(torch.stack(mse_losses)), torch.mean(torch.stack(last_losses))
+
+
+class FlagModel(AbstractSystemModel):
+    """src/model/flag.py:17-260."""
+    _model_type = 'flag'
+    _TYPE_MAP = (0,) + (1,) * 9                  # flag.py:72: class = (node_type != NORMAL)
+
+    def __init__(self, params):
+        super().__init__(params, node_size=5, edge_size=7)
+
+    def build_graph(self, inputs: Dict, is_training: bool) -> MultiGraphWithPos:
+        """flag.py:65-128."""
+        world_pos = inputs['world_pos'].to(device)
+        prev_world_pos = inputs['prev|world_pos'].to(device)
+        mesh_pos = inputs['mesh_pos'].to(device)
+        node_type = inputs['node_type'].to(device)
+        num_nodes = node_type.shape[0]
+        # velocity (3) | one-hot(type != NORMAL) (2)                                              flag.py:68-74
+        node_features = features.node_features(world_pos, prev_world_pos, node_type, self._TYPE_MAP, 2)
+        senders, receivers = self._mesh_edges(inputs['cells'])
+        edge_features, length = features.rel_edge_features(world_pos, mesh_pos, senders, receivers, want_len=True)
+        mesh_edges = EdgeSet(name='mesh_edges', features=self._mesh_edge_normalizer(edge_features, is_training),
+                             receivers=receivers, senders=senders)
+        # max - min incident edge length per node: both aggregates in one pass                      flag.py:100-115
+        csr = topology.segment_csr(receivers, num_nodes, world_pos.device)
+        mm = ops.aggregate([length.unsqueeze(1)], [(csr.perm, csr.rowptr, csr.seg)], ('max', 'min'))
+        node_dynamic = self._node_dynamic_normalizer(features.lincomb3(mm[:, 0], 1.0, mm[:, 1], -1.0))
+        return MultiGraphWithPos(
+            node_features=[self._node_normalizer(node_features, is_training)], edge_sets=[mesh_edges],
+            target_feature=world_pos, mesh_features=mesh_pos, model_type=self._model_type, node_dynamic=node_dynamic,
+            unnormalized_edges=EdgeSet(name='mesh_edges', features=edge_features, receivers=receivers, senders=senders),
+            obstacle_nodes=None)
+
+    def _loss_mask(self, data_frame):
+        return torch.eq(data_frame['node_type'].to(device)[:, 0], NodeType.NORMAL.value)
+
+    def training_step(self, graph, data_frame):
+        """flag.py:146-154."""
+        network_output = self(graph)
+        target_normalized = self.get_target(data_frame)
+        return _masked_mse(target_normalized, network_output, self._loss_mask(data_frame))
+
+    @torch.no_grad()
+    def validation_step(self, graph: MultiGraph, data_frame: Dict) -> Tuple[Tensor, Tensor]:
+        """flag.py:156-167."""
+        prediction = self(graph)
+        target_normalized = self.get_target(data_frame, False)
+        mask = self._loss_mask(data_frame)
+        acc_loss = _masked_mse(target_normalized, prediction, mask).item()
+        predicted_position = self.update(data_frame, prediction)
+        pos_error = _masked_mse(data_frame['target|world_pos'].to(device), predicted_position, mask).item()
+        return acc_loss, pos_error
+
+    def update(self, inputs: Dict, per_node_network_output: Tensor) -> Tensor:
+        """flag.py:169-180: next position = 2 cur + acceleration - prev."""
+        acceleration = self._output_normalizer.inverse(per_node_network_output)
+        return features.lincomb3(inputs['world_pos'].to(device), 2.0, acceleration, 1.0, inputs['prev|world_pos'], -1.0)
+
+    def get_target(self, data_frame, is_training=True):
+        """flag.py:182-190."""
+        cur = data_frame['world_pos'].to(device)
+        prev = data_frame['prev|world_pos'].to(device)
+        tgt = data_frame['target|world_pos'].to(device)
+        return self._output_normalizer(features.lincomb3(tgt, 1.0, cur, -2.0, prev, 1.0), is_training)
+
+    @torch.no_grad()
+    def rollout(self, trajectory: Dict[str, Tensor], num_steps: int) -> Tuple[Dict[str, Tensor], Tensor]:
+        """flag.py:192-225."""
+        num_steps = trajectory['cells'].shape[0] if num_steps is None else num_steps
+        initial_state = {k: torch.squeeze(v, 0)[0].to(device) for k, v in trajectory.items()}
+        mask = torch.eq(initial_state['node_type'][:, 0], NodeType.NORMAL.value)
+        mask = torch.stack((mask, mask, mask), dim=1)
+        prev_pos = initial_state['prev|world_pos']
+        cur_pos = initial_state['world_pos']
+        pred_trajectory = []
+        for i in range(num_steps):
+            prev_pos, cur_pos, pred_trajectory = self._step_fn(initial_state, prev_pos, cur_pos, pred_trajectory, mask, i)
+        self._visualized = False
+        predictions = torch.stack(pred_trajectory)
+        traj_ops = {'faces': trajectory['cells'], 'mesh_pos': trajectory['mesh_pos'], 'gt_pos': trajectory['world_pos'],
+                    'pred_pos': predictions}
+        gt = trajectory['world_pos'][:num_steps].to(device)
+        mse_loss = torch.mean(torch.mean((gt - predictions) ** 2, dim=-1), dim=-1).detach()
+        return traj_ops, mse_loss
+
+    @torch.no_grad()
+    def _step_fn(self, initial_state, prev_pos, cur_pos, trajectory, mask, step):
+        """flag.py:227-246."""
+        inputs = {**initial_state, 'prev|world_pos': prev_pos, 'world_pos': cur_pos}
+        graph = self.build_graph(inputs, is_training=False)
+        graph = self.expand_graph(graph, step, 399, is_training=False)
+        prediction = self.update(inputs, self(graph))
+        next_pos = torch.where(mask, prediction, cur_pos)
+        trajectory.append(cur_pos)
+        return cur_pos, next_pos, trajectory
+
+
+class CylinderModel(AbstractSystemModel):
+    """src/model/cylinder.py:17-240 (its remote edges use the 'plate' feature rule, cylinder.py:34)."""
+    _model_type = 'plate'
+    _TYPE_MAP = (0, -1, -1, -1, 1, 2, 3)        # cylinder.py:71-74: INFLOW->1, OUTFLOW->2, WALL_BOUNDARY->3
+
+    def __init__(self, params):
+        super().__init__(params, node_size=6, edge_size=3)
+
+    def build_graph(self, inputs: Dict, is_training: bool) -> MultiGraphWithPos:
+        """cylinder.py:65-106."""
+        velocity = inputs['velocity'].to(device)
+        mesh_pos = inputs['mesh_pos'].to(device)
+        node_type = inputs['node_type'].to(device)
+        node_features = features.node_features(velocity, None, node_type, self._TYPE_MAP, 4)
+        senders, receivers = self._mesh_edges(inputs['cells'])
+        edge_features, _ = features.rel_edge_features(mesh_pos, None, senders, receivers)
+        mesh_edges = EdgeSet(name='mesh_edges', features=self._mesh_edge_normalizer(edge_features, is_training),
+                             receivers=receivers, senders=senders)
+        return MultiGraphWithPos(
+            node_features=[self._node_normalizer(node_features, is_training)], edge_sets=[mesh_edges],
+            mesh_features=mesh_pos, target_feature=velocity, model_type=self._model_type,
+            unnormalized_edges=EdgeSet(name='mesh_edges', features=edge_features, receivers=receivers, senders=senders),
+            node_dynamic=[], obstacle_nodes=None)
+
+    def _loss_mask(self, data_frame):
+        t = data_frame['node_type'].to(device)[:, 0]
+        return torch.logical_or(torch.eq(t, NodeType.OUTFLOW.value), torch.eq(t, NodeType.NORMAL.value))
+
+    def training_step(self, graph, data_frame):
+        """cylinder.py:123-136."""
+        network_output = self(graph)
+        target_normalized = self.get_target(data_frame)
+        return _masked_mse(target_normalized, network_output, self._loss_mask(data_frame))
+
+    @torch.no_grad()
+    def validation_step(self, graph: MultiGraph, data_frame: Dict) -> Tuple[Tensor, Tensor]:
+        """cylinder.py:138-153."""
+        prediction = self(graph)
+        target_normalized = self.get_target(data_frame, False)
+        mask = self._loss_mask(data_frame)
+        vel_loss = _masked_mse(target_normalized, prediction, mask).item()
+        velocity_update, _ = self.update(data_frame, prediction)
+        pos_error = _masked_mse(data_frame['target|velocity'].to(device), velocity_update, mask).item()
+        return vel_loss, pos_error
+
+    def update(self, inputs: Dict, per_node_network_output: Tensor):
+        """cylinder.py:155-165."""
+        out = self._output_normalizer.inverse(per_node_network_output)
+        velocity, pressure = out[:, :2], out[:, 2:]
+        return features.lincomb3(inputs['velocity'].to(device), 1.0, velocity, 1.0), pressure
+
+    def get_target(self, data_frame, is_training=True):
+        """cylinder.py:167-173."""
+        dv = features.lincomb3(data_frame['target|velocity'].to(device), 1.0, data_frame['velocity'], -1.0)
+        return self._output_normalizer(torch.cat((dv, data_frame['pressure'].to(device)), dim=1), is_training)
+
+    @torch.no_grad()
+    def rollout(self, trajectory: Dict[str, Tensor], num_steps: int):
+        """cylinder.py:175-208."""
+        initial_state = {k: torch.squeeze(v, 0)[0].to(device) for k, v in trajectory.items()}
+        num_steps = trajectory['cells'].shape[0]
+        t = initial_state['node_type'][:, 0]
+        mask = torch.logical_or(torch.eq(t, NodeType.NORMAL.value), torch.eq(t, NodeType.OUTFLOW.value))
+        mask = torch.stack((mask, mask), dim=1)
+        velocity, pressure = initial_state['velocity'], initial_state['pressure']
+        pred_trajectory, pred_pressure = [], []
+        for step in range(num_steps):
+            velocity, pressure, pred_trajectory, pred_pressure = self._step_fn(
+                initial_state, velocity, pressure, pred_trajectory, pred_pressure, step, mask)
+        prediction, pressure = torch.stack(pred_trajectory), torch.stack(pred_pressure)
+        traj_ops = {'faces': trajectory['cells'], 'mesh_pos': trajectory['mesh_pos'],
+                    'gt_velocity': trajectory['velocity'], 'gt_pressure': trajectory['pressure'],
+                    'pred_pressure': pressure, 'pred_velocity': prediction}
+        gt = trajectory['velocity'][:num_steps].to(device)
+        mse_loss = torch.mean(torch.mean((gt - prediction) ** 2, dim=-1), dim=-1).detach()
+        return traj_ops, mse_loss
+
+    @torch.no_grad()
+    def _step_fn(self, initial_state, velocity, pressure, trajectory, pressure_trajectory, step, mask):
+        """cylinder.py:210-230."""
+        inputs = {**initial_state, 'velocity': velocity, 'pressure': pressure}
+        graph = self.build_graph(inputs, is_training=False)
+        graph = self.expand_graph(graph, step, 598, is_training=False)
+        prediction, pred_pressure = self.update(inputs, self(graph))
+        next_velocity = torch.where(mask, prediction, velocity)
+        trajectory.append(next_velocity)
+        pressure_trajectory.append(pred_pressure)
+        return next_velocity, pred_pressure, trajectory, pressure_trajectory
+
+
+def get_model(config) -> AbstractSystemModel:
+    """src/model/get_model.py:13-22."""
+    name = str(config['task']['dataset']).lower()
+    if 'flag' in name:
+        return FlagModel(config.get('model'))
+    if 'cylinder' in name:
+        return CylinderModel(config.get('model'))
+    raise NotImplementedError('Implement your algorithms here!')

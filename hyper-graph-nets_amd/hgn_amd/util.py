@@ -42,16 +42,11 @@ def read_yaml(config_name: str):
 
 
 def triangles_to_edges(faces: torch.Tensor, deform: bool = False):
-    """src/util.py:50-89: unique undirected cell edges, then both directions (cells of 3 or, `deform`, 4 nodes)."""
-    n = 4 if deform else 3
-    cols = [faces[:, i:i + 2] for i in range(n - 1)] + [torch.stack((faces[:, n - 1], faces[:, 0]), dim=1)]
-    edges = torch.cat(cols, dim=0)
-    receivers = edges.min(dim=1).values
-    senders = edges.max(dim=1).values
-    unique = torch.unique(torch.stack((senders, receivers), dim=1), dim=0)
-    senders, receivers = unique[:, 0].to(torch.int64), unique[:, 1].to(torch.int64)
-    two_way = (torch.cat((senders, receivers), dim=0), torch.cat((receivers, senders), dim=0))
-    return {'two_way_connectivity': two_way, 'senders': senders, 'receivers': receivers}
+    """src/util.py:50-89: unique undirected cell edges, then both directions (cells of 3 or, `deform`, 4 nodes).
+    Device radix sort + unique (include/hgn_features.h: hgn_cells_to_edges); same row order as torch.unique(dim=0)."""
+    from . import features
+    s2, r2, n = features.cells_to_edges(faces.to(device), deform)
+    return {'two_way_connectivity': (s2, r2), 'senders': s2[:n], 'receivers': r2[:n]}
 
 
 def unsorted_segment_operation(data, segment_ids, num_segments, operation):

@@ -1,0 +1,198 @@
+"""CPU oracle for the rows in front of the message-passing path: frame -> graph features
+and the remote-graph assembly over a given clustering (row f3).
+
+TEST INFRASTRUCTURE ONLY (same rule as mgn_oracle.py: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it).  Plain PyTorch on CPU, dtype-generic (fp32 restates the
+reference's arithmetic, fp64 gives the reference value to compare fp32 implementations against).  Each function
+cites the reference lines it follows (paths relative to /root/reference/src).
+
+Pinning: tests/golden/feat_*.pt, produced by running the reference's own FlagModel / CylinderModel /
+RemoteMessagePassing / util.triangles_to_edges in the build container (generator tools/gen_golden_features.py).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .mgn_oracle import EdgeSet, MultiGraph, Normalizer, segment_reduce
+
+
+# --------------------------------------------------------------------------------------------------------
+# util.py:50-89
+# --------------------------------------------------------------------------------------------------------
+def triangles_to_edges(cells: torch.Tensor, deform: bool = False):
+    n = 4 if deform else 3
+    pairs = [(i, (i + 1) % n) for i in range(n)]                      # (0,1),(1,2),(2,0) | (0,1),(1,2),(2,3),(3,0)
+    e = torch.cat([torch.stack((cells[:, a], cells[:, b]), 1) for a, b in pairs], 0)
+    lo, hi = e.min(1).values, e.max(1).values
+    keys = sorted(set(zip(hi.tolist(), lo.tolist())))                 # torch.unique(dim=0): lexicographic rows
+    s = torch.tensor([k[0] for k in keys], dtype=torch.int64)
+    r = torch.tensor([k[1] for k in keys], dtype=torch.int64)
+    return torch.cat([s, r]), torch.cat([r, s])                       # 'two_way_connectivity' (util.py:68)
+
+
+def rel_features(world: torch.Tensor, mesh: Optional[torch.Tensor], s: torch.Tensor, r: torch.Tensor):
+    """flag.py:80-93 / abstract_connector.py:90-95 / cylinder.py:83-87."""
+    rw = world[s] - world[r]
+    cols = [rw, torch.sqrt(rw.pow(2).sum(-1, keepdim=True))]
+    if mesh is not None:
+        rm = mesh[s] - mesh[r]
+        cols += [rm, torch.sqrt(rm.pow(2).sum(-1, keepdim=True))]
+    return torch.cat(cols, -1)
+
+
+# --------------------------------------------------------------------------------------------------------
+# model/flag.py
+# --------------------------------------------------------------------------------------------------------
+class FlagFeatures:
+    """The normalisers FlagModel owns (flag.py:26-32) and its frame -> graph functions."""
+
+    def __init__(self, dtype=torch.float32):
+        self.dtype = dtype
+        self.output = Normalizer(3, dtype=dtype)
+        self.node = Normalizer(5, dtype=dtype)
+        self.node_dynamic = Normalizer(1, dtype=dtype)
+        self.mesh_edge = Normalizer(7, dtype=dtype)
+        self.intra_edge = Normalizer(7, dtype=dtype)
+        self.inter_edge = Normalizer(7, dtype=dtype)
+        self.hyper_node = Normalizer(3, dtype=dtype)
+
+    def build_graph(self, inputs: Dict[str, torch.Tensor], is_training: bool) -> dict:
+        """flag.py:65-128."""
+        dt = self.dtype
+        world, prev, mesh = inputs['world_pos'].to(dt), inputs['prev|world_pos'].to(dt), inputs['mesh_pos'].to(dt)
+        node_type = inputs['node_type']
+        velocity = world - prev
+        cls = (node_type[:, 0] != 0).long()
+        one_hot = torch.nn.functional.one_hot(cls, 2).to(dt)         # flag.py:72-73 (HANDLE nodes always present)
+        node_features = torch.cat((velocity, one_hot), -1)
+        s, r = triangles_to_edges(inputs['cells'])
+        edge_features = rel_features(world, mesh, s, r)
+        length = torch.sqrt((world[s] - world[r]).pow(2).sum(-1))
+        N = node_type.shape[0]
+        mx = segment_reduce(length, r, N, 'max')                     # flag.py:101-113 (1-D data)
+        mn = segment_reduce(length, r, N, 'min')
+        edges_n = self.mesh_edge(edge_features, is_training)         # call order as in flag.py:95-115
+        node_dynamic = self.node_dynamic(mx - mn)                    # accumulate defaults to True (flag.py:115)
+        nodes_n = self.node(node_features, is_training)
+        return {'node_features': [nodes_n], 'edge_sets': [EdgeSet('mesh_edges', edges_n, s, r)],
+                'target_feature': world, 'mesh_features': mesh, 'node_dynamic': node_dynamic,
+                'unnormalized_edges': EdgeSet('mesh_edges', edge_features, s, r)}
+
+    def get_target(self, frame, is_training=True):
+        """flag.py:182-190."""
+        dt = self.dtype
+        cur, prev, tgt = frame['world_pos'].to(dt), frame['prev|world_pos'].to(dt), frame['target|world_pos'].to(dt)
+        return self.output(tgt - 2 * cur + prev, is_training)
+
+    def update(self, inputs, net_out):
+        """flag.py:169-180."""
+        acc = self.output.inverse(net_out.to(self.dtype))
+        return 2 * inputs['world_pos'].to(self.dtype) + acc - inputs['prev|world_pos'].to(self.dtype)
+
+
+# --------------------------------------------------------------------------------------------------------
+# model/cylinder.py
+# --------------------------------------------------------------------------------------------------------
+class CylinderFeatures:
+    def __init__(self, dtype=torch.float32):
+        self.dtype = dtype
+        self.output = Normalizer(3, dtype=dtype)
+        self.node = Normalizer(6, dtype=dtype)
+        self.mesh_edge = Normalizer(3, dtype=dtype)
+
+    def build_graph(self, inputs, is_training: bool) -> dict:
+        """cylinder.py:65-106."""
+        dt = self.dtype
+        velocity, mesh = inputs['velocity'].to(dt), inputs['mesh_pos'].to(dt)
+        t = inputs['node_type'][:, 0].long().clone()
+        t[t == 4] = 1
+        t[t == 5] = 2
+        t[t == 6] = 3                                                # cylinder.py:71-74
+        node_features = torch.cat((velocity, torch.nn.functional.one_hot(t, 4).to(dt)), -1)
+        s, r = triangles_to_edges(inputs['cells'])
+        edge_features = rel_features(mesh, None, s, r)
+        edges_n = self.mesh_edge(edge_features, is_training)
+        nodes_n = self.node(node_features, is_training)
+        return {'node_features': [nodes_n], 'edge_sets': [EdgeSet('mesh_edges', edges_n, s, r)],
+                'target_feature': velocity, 'mesh_features': mesh,
+                'unnormalized_edges': EdgeSet('mesh_edges', edge_features, s, r)}
+
+    def get_target(self, frame, is_training=True):
+        """cylinder.py:167-173."""
+        dt = self.dtype
+        dv = frame['target|velocity'].to(dt) - frame['velocity'].to(dt)
+        return self.output(torch.cat((dv, frame['pressure'].to(dt)), 1), is_training)
+
+    def update(self, inputs, net_out):
+        """cylinder.py:155-165."""
+        o = self.output.inverse(net_out.to(self.dtype))
+        return inputs['velocity'].to(self.dtype) + o[:, :2], o[:, 2:]
+
+
+# --------------------------------------------------------------------------------------------------------
+# rmp/: neighbouring clusters and the hierarchical connector
+# --------------------------------------------------------------------------------------------------------
+def neighboring_clusters(senders: torch.Tensor, receivers: torch.Tensor, labels: Sequence[int]) -> List[tuple]:
+    """abstract_clustering_algorithm.py:124-145: the set of unordered label pairs joined by a mesh edge.  The
+    reference's list order comes from Python set iteration; here the pairs are returned sorted (order of the edges
+    inside an edge set does not change the model's result beyond fp summation order)."""
+    lab = torch.as_tensor(list(labels))
+    a, b = lab[senders], lab[receivers]
+    keep = a != b
+    return sorted({(min(int(x), int(y)), max(int(x), int(y))) for x, y in zip(a[keep].tolist(), b[keep].tolist())})
+
+
+def hierarchical_connect(graph: dict, clusters: Sequence[torch.Tensor], neighbors: Sequence, intra: Normalizer,
+                         inter: Normalizer, hyper: Normalizer, is_training: bool, hyper_node_features: bool = True,
+                         fully_connect: bool = False, noise: Optional[torch.Tensor] = None) -> MultiGraph:
+    """hierarchical_connector.py:27-143 on a graph from ``build_graph`` (node_features = graph['node_features'][0],
+    remote_message_passing.py:67).  ``noise`` (if given) is the sample the reference draws at :48-51."""
+    world, mesh = graph['target_feature'], graph['mesh_features']
+    cf = torch.cat((world, mesh), 1)                                             # :29
+    nf = graph['node_features'][0]
+    N, K = nf.shape[0], len(clusters)
+    means = torch.stack([cf[c].mean(0) for c in clusters])                        # :39-43
+    if noise is not None:
+        means = means + noise
+    nf_means = torch.stack([nf[c].mean(0) for c in clusters])                     # :44-45,53
+    if hyper_node_features:                                                       # :54-71
+        spread_mesh = torch.stack([torch.sqrt((means[i][-3:] - cf[c][:, -3:]).pow(2).sum(1)).max()
+                                   for i, c in enumerate(clusters)])
+        spread_world = torch.stack([torch.sqrt((means[i][:3] - cf[c][:, :3]).pow(2).sum(1)).max()
+                                    for i, c in enumerate(clusters)])
+        sizes = torch.tensor([len(c) for c in clusters]).to(cf.dtype)
+        aug = hyper(torch.stack([sizes, spread_mesh, spread_world], -1), is_training)
+        nf_means = torch.cat([nf_means, aug], -1)
+    tf = torch.cat([cf, means], 0)                                                # _get_subgraph: cat of the list
+
+    def sub(s, r):                                                                # abstract_connector.py:84-98
+        s2, r2 = torch.cat((s, r)), torch.cat((r, s))
+        d = tf[s2] - tf[r2]
+        w, m = d[:, :3], d[:, 3:]
+        return s2, r2, torch.cat((w, torch.sqrt(w.pow(2).sum(-1, keepdim=True)), m,
+                                  torch.sqrt(m.pow(2).sum(-1, keepdim=True))), -1)
+    to_mesh, to_cluster = [], []
+    for k, c in enumerate(clusters):                                              # :85-100
+        h = torch.full((len(c),), N + k, dtype=torch.int64)
+        s, r, f = sub(h, c.long())
+        n = len(c)
+        to_mesh.append((s[:n], r[:n], f[:n]))
+        to_cluster.append((s[n:], r[n:], f[n:]))
+
+    def cat(parts, name):
+        feats = intra(torch.cat([p[2] for p in parts]), is_training)
+        return EdgeSet(name, feats, torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]))
+    e_cluster = cat(to_cluster, 'intra_cluster_to_cluster')                       # :102-113 (normalised first)
+    e_mesh = cat(to_mesh, 'intra_cluster_to_mesh')                                # :115-125
+    if fully_connect or K < 4:                                                    # :128-129, :207-212
+        idx = torch.combinations(torch.arange(N, N + K), with_replacement=True)
+        idx = idx[idx[:, 0] != idx[:, 1]]
+        s, r = idx[:, 0], idx[:, 1]
+    else:                                                                         # :132, :201-205
+        nb = torch.tensor([list(p) for p in neighbors], dtype=torch.int64).reshape(-1, 2) + N
+        s, r = nb[:, 0], nb[:, 1]
+    s2, r2, f = sub(s, r)
+    e_inter = EdgeSet('inter_cluster', inter(f, is_training), s2, r2)             # :134-138
+    return MultiGraph([nf, nf_means], list(graph['edge_sets']) + [e_cluster, e_mesh, e_inter])

@@ -1,0 +1,290 @@
+"""GPU parity of the rows in front of the message-passing path: the HIP feature kernels
+behind the reference's FlagModel / CylinderModel / RemoteMessagePassing API against (i) the reference's own outputs
+(tests/golden/feat_*.pt) and (ii) the fp64 oracle on seeded inputs, plus size-independent properties at full size.
+
+Tolerance: integer / index outputs bit-exact; fp32 features 1e-5 relative to the tensor's scale (BASELINE.json)."""
+import os
+
+import pytest
+import torch
+
+from oracle import features_oracle as FO
+from oracle import mgn_oracle as O
+from tests import synth
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TOL = 1e-5
+
+
+def load(name):
+    return torch.load(os.path.join(GOLDEN, f'feat_{name}.pt'), weights_only=False)
+
+
+def cuda_frame(fr):
+    return {k: v.cuda() for k, v in fr.items()}
+
+
+def flag_params(connector='none', K=4, fully=False, hnf=True, clustering='kmeans', steps=1, agg='sum'):
+    return {'size': 3, 'aggregation': agg, 'message_passing_steps': steps,
+            'rmp': {'clustering': clustering if connector != 'none' else 'none', 'connector': connector, 'num_clusters': K,
+                    'hyper_noise': 'none', 'hyper_node_features': hnf, 'frequency': 1, 'fully_connect': fully,
+                    'intra_cluster_sampling': {'enabled': False, 'alpha': 0.1, 'spotter_threshold': 0}},
+            'graph_balancer': {'algorithm': 'none', 'frequency': 1}}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# util.triangles_to_edges
+# ----------------------------------------------------------------------------------------------------------------
+def test_cells_to_edges_matches_reference_golden():
+    from hgn_amd import util
+    fx = load('cells_to_edges')
+    for nm, deform in (('tri', False), ('quad', True)):
+        o = util.triangles_to_edges(fx[nm]['cells'].cuda(), deform)
+        s, r = o['two_way_connectivity']
+        assert s.dtype == torch.int64 and s.is_cuda
+        assert torch.equal(s.cpu(), fx[nm]['senders']) and torch.equal(r.cpu(), fx[nm]['receivers'])
+        n = s.shape[0] // 2
+        assert torch.equal(o['senders'].cpu(), fx[nm]['senders'][:n])
+
+
+def test_cells_to_edges_large_and_edge_cases():
+    from hgn_amd import _lib, features
+    g = torch.Generator().manual_seed(3)
+    cells = torch.randint(0, 50000, (200000, 3), generator=g)
+    s, r, n = features.cells_to_edges(cells.cuda())
+    so, ro = FO.triangles_to_edges(cells)
+    assert torch.equal(s.cpu(), so) and torch.equal(r.cpu(), ro) and n == so.shape[0] // 2
+    # structured grid: E = 3(nx-1)(ny-1) + (nx-1) + (ny-1) undirected edges
+    s, r, n = features.cells_to_edges(synth.grid_triangles(40, 40).cuda())
+    assert n == 3 * 39 * 39 + 39 + 39 and s.shape[0] == 9282
+    s, r, n = features.cells_to_edges(torch.zeros(0, 3, dtype=torch.int64).cuda())
+    assert n == 0 and s.shape[0] == 0
+    with pytest.raises(IndexError):
+        features.cells_to_edges(torch.tensor([[0, 1, -2]]).cuda())
+    # degenerate cell (repeated vertex) gives a self-pair, like the reference
+    s, r, n = features.cells_to_edges(torch.tensor([[4, 4, 7]]).cuda())
+    so, ro = FO.triangles_to_edges(torch.tensor([[4, 4, 7]]))
+    assert torch.equal(s.cpu(), so) and torch.equal(r.cpu(), ro)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Normalizer
+# ----------------------------------------------------------------------------------------------------------------
+def test_normalizer_matches_reference_golden_g7():
+    from hgn_amd.normalizer import Normalizer
+    fx = torch.load(os.path.join(GOLDEN, 'g7_normalizer.pt'))
+    nz = Normalizer(5, 't')
+    for x, y in zip(fx['xs'], fx['ys']):
+        torch.testing.assert_close(nz(x.cuda(), True).cpu(), y, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(nz(fx['xs'][0].cuda(), False).cpu(), fx['y_eval'], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(nz.inverse(fx['ys'][0].cuda()).cpu(), fx['inv'], rtol=1e-5, atol=1e-6)
+    nz2 = Normalizer(2, 'u', max_accumulations=2)            # accumulation stops after max_accumulations calls
+    for z, w in zip(fx['zs'], fx['ws']):
+        torch.testing.assert_close(nz2(z.cuda()).cpu(), w, rtol=1e-5, atol=1e-6)
+    assert float(nz2._num_accumulations) == 2.0
+
+
+def test_normalizer_statistics_full_size_and_device_gate():
+    from hgn_amd import features
+    from hgn_amd.normalizer import Normalizer
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(594048, 7, generator=g) * torch.tensor([1., 10., .1, 3., 1., 1., 100.]) + 5.0)
+    b = features.col_stats(x.cuda()).cpu().double()
+    xd = x.double()
+    assert rel_err(b[:7], xd.sum(0)) < 2e-7 and rel_err(b[7:], (xd ** 2).sum(0)) < 2e-7
+    b2 = features.col_stats(x.cuda()).cpu().double()
+    assert torch.equal(b, b2)                                 # deterministic
+    nz = Normalizer(7, 'big')
+    y = nz(x.cuda())
+    # the reference's fp32 formula (normalizer.py:64-71) on correctly rounded sums: E[x^2]-mean^2 cancels in fp32, so the
+    # comparison is against that formula, not against the fp64 standard deviation
+    s1, s2, n = xd.sum(0).float(), (xd ** 2).sum(0).float(), torch.tensor([float(x.shape[0])])
+    mean = s1 / n
+    std = torch.maximum(torch.sqrt(torch.abs(s2 / n - mean ** 2)), torch.tensor([1e-8]))
+    torch.testing.assert_close(y.cpu(), (x - mean) / std, rtol=2e-6, atol=2e-6)
+    assert rel_err(y, (xd - xd.mean(0)) / xd.std(0, unbiased=False)) < 1e-3
+    torch.testing.assert_close(nz.inverse(y).cpu(), x, rtol=1e-5, atol=1e-4)
+    # the device-side gate: with the host mirror bypassed the kernel itself must refuse the update
+    nz3 = Normalizer(2, 'g', max_accumulations=1)
+    z = torch.randn(10, 2).cuda()
+    nz3(z)
+    before = nz3._acc_sum.clone()
+    nz3._host_num_acc = 0
+    nz3(z)
+    assert torch.equal(nz3._acc_sum, before) and float(nz3._num_accumulations) == 1.0
+    # empty batch / 1-D data (the node-dynamic normaliser, flag.py:115)
+    nz1 = Normalizer(1, 'd')
+    v = torch.randn(33).cuda()
+    out = nz1(v)
+    assert out.shape == v.shape
+    o = O.Normalizer(1, dtype=torch.float64)
+    assert rel_err(out, o(v.cpu().double())) < TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# FlagModel / CylinderModel build_graph, targets, update
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['flag_none', 'flag_hyper_k5', 'flag_hyper_k3_full'])
+def test_flag_model_features_match_reference_golden(name):
+    from hgn_amd import system_model, util
+    fx = load(name)
+    rcfg = fx['config']['rmp']
+    model = system_model.FlagModel(flag_params(rcfg['connector'], rcfg['num_clusters'], rcfg['fully_connect'],
+                                               rcfg['hyper_node_features']))
+    ff64 = FO.FlagFeatures(dtype=torch.float64)
+    for i, fr in enumerate(fx['frames']):
+        training = i < 2
+        g = model.build_graph(cuda_frame(fr), training)
+        ref = fx['graphs'][i]
+        o64 = ff64.build_graph(fr, training)
+        e, re_ = g.edge_sets[0], ref['edge_sets'][0]
+        assert torch.equal(e.senders.cpu(), re_['senders']) and torch.equal(e.receivers.cpu(), re_['receivers'])
+        for got, want, w64 in ((g.unnormalized_edges.features, ref['unnormalized_edges']['features'],
+                                o64['unnormalized_edges'].features),
+                               (e.features, re_['features'], o64['edge_sets'][0].features),
+                               (g.node_features[0], ref['node_features'][0], o64['node_features'][0]),
+                               (g.node_dynamic, ref['node_dynamic'], o64['node_dynamic'])):
+            noise = rel_err(want, w64)                       # how far the reference's own fp32 is from fp64
+            assert rel_err(got, w64) <= max(TOL, 1.5 * noise), (rel_err(got, w64), noise)
+        t = model.get_target(cuda_frame(fr), training)
+        t64 = ff64.get_target(fr, training)
+        assert rel_err(t, t64) <= max(TOL, 1.5 * rel_err(fx['targets'][i], t64))
+        if fx['expanded']:
+            ex = fx['expanded'][i]
+            conn = model._remote_graph._node_connector
+            base = g._replace(node_features=g.node_features[0])
+            if i == 0:
+                clusters, neighbors = ex['clusters'], ex['neighbors']     # the reference's clustering = connector input
+            mg = conn.run(base, clusters, neighbors, training)
+            m64 = FO.hierarchical_connect(o64, clusters, [tuple(t_.tolist()) for t_ in neighbors], ff64.intra_edge,
+                                          ff64.inter_edge, ff64.hyper_node, training,
+                                          hyper_node_features=rcfg['hyper_node_features'],
+                                          fully_connect=rcfg['fully_connect'])
+            assert [x.name for x in mg.edge_sets] == [x['name'] for x in ex['edge_sets']]
+            for a, b, c in zip(mg.edge_sets, ex['edge_sets'], m64.edge_sets):
+                assert torch.equal(a.senders.cpu(), b['senders']) and torch.equal(a.receivers.cpu(), b['receivers']), a.name
+                assert rel_err(a.features, c.features) <= max(TOL, 1.5 * rel_err(b['features'], c.features)), a.name
+            for a, b, c in zip(mg.node_features, ex['node_features'], m64.node_features):
+                assert rel_err(a, c) <= max(TOL, 1.5 * rel_err(b, c))
+    upd = model.update(cuda_frame(fx['frames'][0]), fx['net_out'].cuda())
+    assert rel_err(upd, ff64.update(fx['frames'][0], fx['net_out'])) <= TOL
+    # running statistics equal the reference's after the same call sequence
+    for key in fx['normalizers']:
+        st, nz = fx['normalizers'][key], getattr(model, key)
+        torch.testing.assert_close(nz._acc_sum.cpu(), st['acc_sum'], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(nz._acc_sum_squared.cpu(), st['acc_sum_squared'], rtol=1e-5, atol=1e-5)
+        assert torch.equal(nz._acc_count.cpu(), st['acc_count'])
+        assert torch.equal(nz._num_accumulations.cpu(), st['num_accumulations'])
+
+
+def test_cylinder_model_features_match_reference_golden():
+    from hgn_amd import system_model
+    fx = load('cylinder')
+    p = flag_params()
+    model = system_model.CylinderModel(p)
+    cf64 = FO.CylinderFeatures(dtype=torch.float64)
+    for i, fr in enumerate(fx['frames']):
+        g = model.build_graph(cuda_frame(fr), i < 1)
+        ref = fx['graphs'][i]
+        o64 = cf64.build_graph(fr, i < 1)
+        e, re_ = g.edge_sets[0], ref['edge_sets'][0]
+        assert torch.equal(e.senders.cpu(), re_['senders']) and torch.equal(e.receivers.cpu(), re_['receivers'])
+        for got, want, w64 in ((e.features, re_['features'], o64['edge_sets'][0].features),
+                               (g.node_features[0], ref['node_features'][0], o64['node_features'][0])):
+            assert rel_err(got, w64) <= max(TOL, 1.5 * rel_err(want, w64))
+        t64 = cf64.get_target(fr, i < 1)
+        assert rel_err(model.get_target(cuda_frame(fr), i < 1), t64) <= max(TOL, 1.5 * rel_err(fx['targets'][i], t64))
+    v, pr = model.update(cuda_frame(fx['frames'][0]), fx['net_out'].cuda())
+    v64, p64 = cf64.update(fx['frames'][0], fx['net_out'])
+    assert rel_err(v, v64) <= TOL and rel_err(pr, p64) <= TOL
+
+
+def test_lincomb3_bit_exact_with_left_to_right_fp32():
+    from hgn_amd import features
+    g = torch.Generator().manual_seed(2)
+    a, b, c = (torch.randn(1000, 3, generator=g) for _ in range(3))
+    out = features.lincomb3(a.cuda(), 1.0, b.cuda(), -2.0, c.cuda(), 1.0).cpu()
+    assert torch.equal(out, a - 2 * b + c)                    # flag.py:188
+    out = features.lincomb3(b.cuda(), 2.0, a.cuda(), 1.0, c.cuda(), -1.0).cpu()
+    assert torch.equal(out, 2 * b + a - c)                    # flag.py:178
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# full-size frame: fp64 oracle on the same seeded inputs + size-independent properties
+# ----------------------------------------------------------------------------------------------------------------
+def test_flag_frame_full_size_against_fp64_oracle_and_properties():
+    from hgn_amd import system_model
+    fr = synth.flag_frame(seed=7, nx=40, ny=40)
+    model = system_model.FlagModel(flag_params('hyper', 16, False, True))
+    g = model.build_graph(cuda_frame(fr), True)
+    o64 = FO.FlagFeatures(dtype=torch.float64).build_graph(fr, True)
+    assert g.edge_sets[0].senders.shape[0] == 9282
+    assert torch.equal(g.edge_sets[0].senders.cpu(), o64['edge_sets'][0].senders)
+    assert rel_err(g.unnormalized_edges.features, o64['unnormalized_edges'].features) < TOL
+    assert rel_err(g.edge_sets[0].features, o64['edge_sets'][0].features) < 5e-5
+    assert rel_err(g.node_features[0], o64['node_features'][0]) < 5e-5
+    assert rel_err(g.node_dynamic, o64['node_dynamic']) < 5e-5
+    f = g.unnormalized_edges.features
+    E = f.shape[0] // 2
+    # antisymmetry of the two directions, norms consistent with the components
+    assert torch.equal(f[:E, :3], -f[E:, :3]) and torch.equal(f[:E, 3], f[E:, 3]) and torch.equal(f[:E, 4:6], -f[E:, 4:6])
+    torch.testing.assert_close(f[:, 3], f[:, :3].norm(dim=1), rtol=1e-6, atol=1e-7)
+    # normalised columns have zero mean / unit variance after one accumulation
+    nf = g.edge_sets[0].features.double()
+    assert float(nf.mean(0).abs().max()) < 1e-4 and float((nf.std(0, unbiased=False) - 1).abs().max()) < 1e-3
+    # cluster on the host (scikit-learn), expand on the device; compare with the fp64 oracle on the same clustering
+    mg = model.expand_graph(g, 0, 10, True)
+    rmp = model._remote_graph
+    ff = FO.FlagFeatures(dtype=torch.float64)
+    o = ff.build_graph(fr, True)
+    m64 = FO.hierarchical_connect(o, rmp._clusters, [tuple(t.tolist()) for t in rmp._neighbors], ff.intra_edge,
+                                  ff.inter_edge, ff.hyper_node, True)
+    assert [e.name for e in mg.edge_sets] == [e.name for e in m64.edge_sets]
+    for a, c in zip(mg.edge_sets, m64.edge_sets):
+        assert torch.equal(a.senders.cpu(), c.senders) and torch.equal(a.receivers.cpu(), c.receivers)
+        assert rel_err(a.features, c.features) < 5e-5, a.name
+    assert mg.node_features[1].shape == (16, 8)
+    assert rel_err(mg.node_features[1], m64.node_features[1]) < 5e-5
+    # the expanded graph runs through the message-passing model (shapes / ids consistent)
+    out = model(mg)
+    assert out.shape == (1600, 3) and bool(torch.isfinite(out).all())
+
+
+def test_flag_training_step_end_to_end_against_oracle():
+    """frame -> features -> hyper expansion -> MeshGraphNet -> masked loss, HIP path vs fp64 oracle with the same
+    weights and the same clustering."""
+    from hgn_amd import system_model
+    fr = synth.flag_frame(seed=11, nx=12, ny=10)
+    model = system_model.FlagModel(flag_params('hyper', 5, False, True, steps=2, agg='pna'))
+    g = model.build_graph(cuda_frame(fr), True)
+    mg = model.expand_graph(g, 0, 10, True)
+    loss = model.training_step(mg, cuda_frame(fr))
+    loss.backward()
+    rmp = model._remote_graph
+    ff = FO.FlagFeatures(dtype=torch.float64)
+    o = ff.build_graph(fr, True)
+    m64 = FO.hierarchical_connect(o, rmp._clusters, [tuple(t.tolist()) for t in rmp._neighbors], ff.intra_edge,
+                                  ff.inter_edge, ff.hyper_node, True)
+    sd = {k: v.detach().cpu().double() for k, v in model.learned_model.state_dict().items()}
+    out64 = O.mesh_graph_net(sd, m64, 'hyper', 'pna')
+    mask = fr['node_type'][:, 0] == 0
+    loss64 = O.masked_mse(out64, ff.get_target(fr, True), mask)
+    assert abs(float(loss) - float(loss64)) <= 2e-5 * abs(float(loss64)), (float(loss), float(loss64))
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.learned_model.parameters())
+
+
+def test_flag_rollout_runs_and_keeps_handles_fixed():
+    from hgn_amd import system_model
+    T = 4
+    frames = [synth.flag_frame(seed=20 + i, nx=8, ny=6) for i in range(T)]
+    traj = {k: torch.stack([f[k] for f in frames]).cuda() for k in frames[0]}
+    model = system_model.FlagModel(flag_params('hyper', 4, False, True))
+    model.build_graph(cuda_frame(frames[0]), True)            # give the normalisers statistics
+    model.get_target(cuda_frame(frames[0]), True)
+    ops_, mse = model.rollout(traj, T)
+    assert ops_['pred_pos'].shape == (T, 48, 3) and mse.shape == (T,)
+    assert torch.equal(ops_['pred_pos'][0], traj['world_pos'][0])
+    handles = frames[0]['node_type'][:, 0] != 0
+    assert torch.equal(ops_['pred_pos'][:, handles], traj['world_pos'][0][handles].expand(T, -1, -1))

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_abi_exports_match_header():
     from hgn_amd import _lib
-    header = open(os.path.join(ROOT, 'include', 'hgn_mp.h')).read()
+    header = ''.join(open(os.path.join(ROOT, 'include', h)).read() for h in ('hgn_mp.h', 'hgn_features.h'))
     declared = set(re.findall(r'^\s*(?:const\s+char\s*\*|int)\s+(hgn_\w+)\s*\(', header, flags=re.M))
     assert declared, 'no declarations parsed'
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
@@ -54,6 +54,16 @@ def test_abi_argument_validation_without_gpu():
     ops = (C.c_int32 * 1)(7)
     assert lib.hgn_segment_reduce_fwd(None, 128, 128, None, None, 4, ops, 1, None, 128, None, None, None) == -1
     assert b'Invalid operation type' in lib.hgn_last_error()
+    # include/hgn_features.h
+    assert lib.hgn_cells_to_edges_workspace_bytes(100, 3, C.byref(nb)) == 0 and nb.value > 3 * 300 * 8
+    assert lib.hgn_cells_to_edges_workspace_bytes(100, 5, C.byref(nb)) == -1
+    assert lib.hgn_col_stats_workspace_bytes(1000, 7, C.byref(nb)) == 0 and nb.value > 0
+    assert lib.hgn_col_stats_workspace_bytes(1000, 33, C.byref(nb)) == -1
+    assert lib.hgn_rel_edge_features(None, 3, 4, None, 0, 0, 10, None, None, 5, None, 8, None, None) == -1
+    assert b'1<=da<=3' in lib.hgn_last_error()
+    assert lib.hgn_node_features(None, None, 3, 3, None, 1, None, 0, 40, 1, -1, 5, None, 43, None) == -1
+    assert lib.hgn_normalize(None, 5, 0, None, None, None, 1e-8, 0, None, None) == -1
+    assert lib.hgn_lincomb3(None, 1.0, None, 1.0, None, 0.0, 5, None, None) == -1
     with pytest.raises(_lib.HgnError):
         _lib.check(-1, 'x')
     with pytest.raises(IndexError):
@@ -102,38 +112,54 @@ def test_no_product_import_of_oracle():
                 assert 'oracle' not in src.replace('# oracle', ''), f'{f} mentions the oracle'
 
 
-def test_normalizer_matches_golden_on_cpu():
-    """Normalizer is host-side element-wise torch code (not a kernel): checked against the reference's G7 vectors."""
+def test_feature_path_refuses_cpu_tensors():
+    """Normaliser / cell-edge / feature kernels are HIP only: a CPU tensor must raise, not fall back to torch math."""
+    from hgn_amd import _lib, features, util
     from hgn_amd.normalizer import Normalizer
-    fx = torch.load(os.path.join(ROOT, 'tests', 'golden', 'g7_normalizer.pt'))
     nz = Normalizer(5, 't')
-    dev = nz._acc_sum.device
-    for x, y in zip(fx['xs'], fx['ys']):
-        torch.testing.assert_close(nz(x.to(dev), True).cpu(), y, rtol=1e-6, atol=1e-6)
-    torch.testing.assert_close(nz(fx['xs'][0].to(dev), False).cpu(), fx['y_eval'], rtol=1e-6, atol=1e-6)
-    torch.testing.assert_close(nz.inverse(fx['ys'][0].to(dev)).cpu(), fx['inv'], rtol=1e-6, atol=1e-6)
     assert 'acc' not in ''.join(nz.state_dict().keys())            # statistics are not buffers (reference semantics)
-    nz2 = Normalizer(2, 'u', max_accumulations=2)
-    for z, w in zip(fx['zs'], fx['ws']):
-        torch.testing.assert_close(nz2(z.to(dev)).cpu(), w, rtol=1e-6, atol=1e-6)
+    if torch.cuda.is_available():
+        pytest.skip('CPU-only check')
+    with pytest.raises(_lib.HgnError):
+        nz(torch.randn(4, 5))
+    with pytest.raises(_lib.HgnError):
+        util.triangles_to_edges(torch.tensor([[0, 1, 2]]))
+    with pytest.raises(_lib.HgnError):
+        features.rel_edge_features(torch.randn(3, 3), None, torch.tensor([0]), torch.tensor([1]))
 
 
-def test_triangles_to_edges_and_batcher():
-    from hgn_amd import util, synthetic
+def test_synthetic_edges_and_batcher():
+    from hgn_amd import synthetic
     faces = synthetic.grid_triangles(4, 3)
-    e = util.triangles_to_edges(faces)
-    s, r = e['two_way_connectivity']
+    s, r = synthetic.two_way_edges(faces)
     assert s.dtype == torch.int64 and s.shape == r.shape
     pairs = set(zip(s.tolist(), r.tolist()))
     assert all((b, a) in pairs for a, b in pairs) and len(pairs) == s.shape[0]
-    s2, r2 = synthetic.two_way_edges(faces)
-    assert torch.equal(s, s2) and torch.equal(r, r2)
     # batching: correct hyper mapping equals the oracle's non-compat mapping
     gs = [synthetic.grid_graph(seed=i, nx=3, ny=3, clusters=2) for i in range(3)]
     a = synthetic.batch(gs)
     b = O.batch_graphs([O.MultiGraph(g.node_features, [O.EdgeSet(*e) for e in g.edge_sets]) for g in gs])
     for ea, eb in zip(a.edge_sets, b.edge_sets):
         assert torch.equal(ea.senders, eb.senders) and torch.equal(ea.receivers, eb.receivers)
+
+
+def test_clustering_host_logic_matches_reference_labels():
+    """Cluster labels stay on scikit-learn (host, once per trajectory): same labels and neighbour pairs as the
+    reference produced for the golden frames (tests/golden/feat_flag_hyper_k5.pt)."""
+    from hgn_amd import rmp, util
+    fx = torch.load(os.path.join(ROOT, 'tests', 'golden', 'feat_flag_hyper_k5.pt'), weights_only=False)
+    fr, ex, ref = fx['frames'][0], fx['expanded'][0], fx['graphs'][0]
+    es = ref['edge_sets'][0]
+    g = util.MultiGraphWithPos(node_features=ref['node_features'][0],
+                               edge_sets=[util.EdgeSet('mesh_edges', es['features'], es['senders'], es['receivers'])],
+                               target_feature=fr['world_pos'], mesh_features=fr['mesh_pos'], model_type='flag',
+                               node_dynamic=None, unnormalized_edges=None, obstacle_nodes=None)
+    alg = rmp.KMeansClustering(5, False, 0.1, 0)
+    clusters = alg.run(g)
+    assert alg._labels == ex['labels']
+    assert all(torch.equal(a, b) for a, b in zip(clusters, ex['clusters']))
+    want = sorted({(min(a, b), max(a, b)) for a, b in (tuple(t.tolist()) for t in ex['neighbors'])})
+    assert [tuple(t.tolist()) for t in alg.neigboring_clusters] == want
 
 
 # -------------------------------------------------------------------------------------------------------------
@@ -176,10 +202,10 @@ def _dp_worker(rank, world, port, out):
               for _ in range(3)]
     nz = Normalizer(3, 'n')
     parallel.attach_normalizer_sync([nz])
-    y = nz(targets[mine[0]] * (rank + 1.0))
+    x = targets[mine[0]] * (rank + 1.0)         # the statistics kernels need the GPU: exercise the all-reduce hook itself
+    cnt, s1, s2 = nz._reduce_fn(torch.tensor([float(x.shape[0])]), x.sum(0), (x ** 2).sum(0))
     if rank == 0:
-        torch.save({'flat': tr.fp.flat.clone(), 'losses': losses, 'acc_sum': nz._acc_sum, 'acc_count': nz._acc_count,
-                    'y': y}, out)
+        torch.save({'flat': tr.fp.flat.clone(), 'losses': losses, 'acc_sum': s1, 'acc_sq': s2, 'acc_count': cnt}, out)
     flat0 = tr.fp.flat.clone()
     dist.broadcast(flat0, src=0)
     assert torch.equal(flat0, tr.fp.flat), 'replicas diverged'
@@ -216,6 +242,7 @@ def test_data_parallel_equals_single_process_on_concatenated_batch(tmp_path):
     # normaliser: both ranks accumulated the union of the two inputs
     both = torch.cat([targets[0] * 1.0, targets[1] * 2.0])
     torch.testing.assert_close(res['acc_sum'], both.sum(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res['acc_sq'], (both ** 2).sum(0), rtol=1e-5, atol=1e-5)
     assert float(res['acc_count']) == 32.0
 
 
