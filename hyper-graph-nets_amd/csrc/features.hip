@@ -131,12 +131,22 @@ __global__ void col_stats_kernel(const float* __restrict__ x, long n_elem, int F
   }
 }
 
+// One block: 256 threads = G groups x 2F columns; a group strides over the block partials, groups are folded in
+// fixed order (deterministic).
 __global__ void col_stats_final_kernel(const double* __restrict__ part, int nblk, int F, float* __restrict__ batch) {
-  const int t = threadIdx.x;
-  if (t >= 2 * F) return;
+  __shared__ double sh[ST];
+  const int t = threadIdx.x, W = 2 * F, G = ST / W;
+  const int c = t % W, g = t / W;
   double A = 0.0;
-  for (int b = 0; b < nblk; ++b) A += part[(long)b * 2 * F + t];
-  batch[t] = (float)A;
+  if (g < G)
+    for (int b = g; b < nblk; b += G) A += part[(long)b * W + c];
+  sh[t] = A;
+  __syncthreads();
+  if (t < W) {
+    double S = 0.0;
+    for (int k = 0; k < G; ++k) S += sh[k * W + t];
+    batch[t] = (float)S;
+  }
 }
 
 __global__ void normalizer_update_kernel(float* acc_sum, float* acc_sumsq, float* acc_count, float* num_acc,
@@ -294,7 +304,7 @@ extern "C" int hgn_col_stats(const float* x, int64_t rows, int F, float* batch, 
   int active = 0;
   const int nblk = stats_blocks(rows, F, &active);
   hipLaunchKernelGGL(col_stats_kernel, dim3(nblk), dim3(ST), 0, stream, x, (long)(rows * F), F, active, (double*)workspace);
-  hipLaunchKernelGGL(col_stats_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, nblk, F, batch);
+  hipLaunchKernelGGL(col_stats_final_kernel, dim3(1), dim3(ST), 0, stream, (const double*)workspace, nblk, F, batch);
   return hgn_check_launch("hgn_col_stats");
 }
 
