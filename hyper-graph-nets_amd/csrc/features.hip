@@ -187,6 +187,52 @@ __global__ void lincomb3_kernel(const float* __restrict__ a, float ca, const flo
   out[i] = v;
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// world edges by radius: one wavefront per sender row, receivers in chunks of 64 (ballot keeps ascending order)
+// ----------------------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ void radius_edges_kernel(const float* __restrict__ pos, long ld, int d, const int64_t* __restrict__ node_type,
+                                    long ldt, long N, float radius, int sender_type, int receiver_type,
+                                    const int* __restrict__ nbr_rowptr, const int* __restrict__ nbr,
+                                    int* __restrict__ counts, const int* __restrict__ offsets,
+                                    int64_t* __restrict__ senders, int64_t* __restrict__ receivers) {
+  const int lane = threadIdx.x & 63;
+  const long s = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (s >= N) return;
+  const bool active = sender_type < 0 || node_type[s * ldt] == sender_type;      // uniform per wave
+  if (!active) { if (!FILL && lane == 0) counts[s] = 0; return; }
+  float ps[3];
+  for (int i = 0; i < 3; ++i) ps[i] = i < d ? pos[s * ld + i] : 0.f;
+  const int nb0 = nbr_rowptr ? nbr_rowptr[s] : 0, nb1 = nbr_rowptr ? nbr_rowptr[s + 1] : 0;
+  long base = FILL ? offsets[s] : 0;
+  int total = 0;
+  for (long r0 = 0; r0 < N; r0 += 64) {
+    const long r = r0 + lane;
+    bool hit = false;
+    if (r < N && r != s && (receiver_type < 0 || node_type[r * ldt] == receiver_type)) {
+      float q = 0.f;
+      for (int i = 0; i < 3; ++i) {
+        const float df = i < d ? ps[i] - pos[r * ld + i] : 0.f;
+        q = q + df * df;
+      }
+      hit = sqrtf(q) < radius;
+      if (hit)
+        for (int k = nb0; k < nb1; ++k)
+          if (nbr[k] == (int)r) { hit = false; break; }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (FILL && hit) {
+      const int before = __popcll(m & ((1ULL << lane) - 1ULL));
+      senders[base + before] = s;
+      receivers[base + before] = r;
+    }
+    const int c = __popcll(m);
+    base += c;
+    total += c;
+  }
+  if (!FILL && lane == 0) counts[s] = total;
+}
+
 static int stats_blocks(int64_t rows, int F, int* active) {
   *active = (ST / F) * F;
   const int64_t n = rows * F;
@@ -341,4 +387,66 @@ extern "C" int hgn_lincomb3(const float* a, float ca, const float* b, float cb, 
   hipLaunchKernelGGL(lincomb3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, ca, b, cb, c, cc, (long)n,
                      out);
   return hgn_check_launch("hgn_lincomb3");
+}
+
+extern "C" int hgn_radius_edges_workspace_bytes(int64_t N, size_t* bytes) {
+  if (!bytes || N < 0 || N > 0x7ffffffe) return hgn_fail(HGN_E_INVALID, "hgn_radius_edges_workspace_bytes: bad size");
+  size_t t = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum<int*, int*>(nullptr, t, nullptr, nullptr, (int)(N + 1));
+  *bytes = up256((size_t)(N + 1) * 4) + up256(t) + 256;
+  return HGN_OK;
+}
+
+static int radius_args_ok(const float* pos, int64_t ld, int d, const int64_t* node_type, int64_t ldt, int64_t N,
+                          float radius, const int32_t* nbr_rowptr, const int32_t* nbr) {
+  if (N < 0 || d < 1 || d > 3 || ld < d || ldt < 1 || !(radius >= 0.f)) return 0;
+  if (N > 0 && (!pos || !node_type)) return 0;
+  if ((nbr_rowptr == nullptr) != (nbr == nullptr)) return 0;
+  return 1;
+}
+
+extern "C" int hgn_radius_edges_count(const float* pos, int64_t ld, int d, const int64_t* node_type, int64_t ldt, int64_t N,
+                                      float radius, int sender_type, int receiver_type, const int32_t* nbr_rowptr,
+                                      const int32_t* nbr, int32_t* offsets, int64_t* total, void* workspace,
+                                      size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  size_t need = 0;
+  if (hgn_radius_edges_workspace_bytes(N, &need) != HGN_OK) return HGN_E_INVALID;
+  if (!radius_args_ok(pos, ld, d, node_type, ldt, N, radius, nbr_rowptr, nbr) || !offsets || !total || !workspace ||
+      ws_bytes < need)
+    return hgn_fail(HGN_E_INVALID, "hgn_radius_edges_count: bad argument or workspace too small");
+  *total = 0;
+  ProfScope ps(13, (double)N, stream);
+  int* counts = (int*)workspace;
+  void* temp = (char*)workspace + up256((size_t)(N + 1) * 4);
+  size_t tb = need - up256((size_t)(N + 1) * 4);
+  if (hipMemsetAsync(counts, 0, (size_t)(N + 1) * 4, stream) != hipSuccess) return hgn_check_launch("hgn_radius_edges_count memset");
+  if (N > 0)
+    hipLaunchKernelGGL(radius_edges_kernel<false>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, pos, (long)ld, d,
+                       node_type, (long)ldt, (long)N, radius, sender_type, receiver_type, nbr_rowptr, nbr, counts,
+                       (const int*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
+  if (hipcub::DeviceScan::ExclusiveSum(temp, tb, counts, offsets, (int)(N + 1), stream) != hipSuccess)
+    return hgn_check_launch("hgn_radius_edges_count scan");
+  int host_total = 0;
+  if (hipMemcpyAsync(&host_total, offsets + N, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return hgn_check_launch("hgn_radius_edges_count readback");
+  *total = host_total;
+  return hgn_check_launch("hgn_radius_edges_count");
+}
+
+extern "C" int hgn_radius_edges_fill(const float* pos, int64_t ld, int d, const int64_t* node_type, int64_t ldt, int64_t N,
+                                     float radius, int sender_type, int receiver_type, const int32_t* nbr_rowptr,
+                                     const int32_t* nbr, const int32_t* offsets, int64_t* senders, int64_t* receivers,
+                                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!radius_args_ok(pos, ld, d, node_type, ldt, N, radius, nbr_rowptr, nbr) || !offsets)
+    return hgn_fail(HGN_E_INVALID, "hgn_radius_edges_fill: bad argument");
+  if (N == 0) return HGN_OK;
+  if (!senders || !receivers) return hgn_fail(HGN_E_INVALID, "hgn_radius_edges_fill: null output");
+  ProfScope ps(13, (double)N, stream);
+  hipLaunchKernelGGL(radius_edges_kernel<true>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, pos, (long)ld, d,
+                     node_type, (long)ldt, (long)N, radius, sender_type, receiver_type, nbr_rowptr, nbr, (int*)nullptr,
+                     offsets, senders, receivers);
+  return hgn_check_launch("hgn_radius_edges_fill");
 }

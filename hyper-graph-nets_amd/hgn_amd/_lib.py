@@ -98,6 +98,13 @@ _SIGS = {
                                         C.c_int, C.c_float, C.c_void_p]),
     'hgn_normalize': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_int, C.c_void_p, C.c_void_p]),
+    'hgn_radius_edges_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
+    'hgn_radius_edges_count': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
+                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    'hgn_radius_edges_fill': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
+                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     'hgn_lincomb3': (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int64,
                                C.c_void_p, C.c_void_p]),
     'hgn_prof_enable': (C.c_int, [C.c_int]),

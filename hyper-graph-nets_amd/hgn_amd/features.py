@@ -182,3 +182,34 @@ def lincomb3(a: torch.Tensor, ca: float, b: torch.Tensor, cb: float, c=None, cc:
                                        c.data_ptr() if c is not None else None, float(cc), a.numel(), out.data_ptr(),
                                        _lib.stream_ptr()), 'hgn_lincomb3')
     return out
+
+
+def radius_edges(pos: torch.Tensor, node_type: torch.Tensor, radius: float, sender_type: int, receiver_type: int,
+                 nbr_rowptr=None, nbr=None):
+    """plate.py:84-110: directed pairs closer than ``radius`` with the given endpoint types that are not mesh
+    neighbours (CSR ``nbr_rowptr`` / ``nbr``); ascending (sender, receiver) order.  -> (senders, receivers) int64."""
+    _lib.require_gpu(pos)
+    dev = pos.device
+    pos = _f32_rows(pos)
+    nt = node_type.to(device=dev, dtype=torch.int64)
+    if nt.dim() == 2:
+        nt = nt[:, 0]
+    N = pos.shape[0]
+    ldt = nt.stride(0) if N > 1 else 1
+    L = _lib.lib()
+    nb = C.c_size_t(0)
+    _lib.check(L.hgn_radius_edges_workspace_bytes(N, C.byref(nb)), 'hgn_radius_edges_workspace_bytes')
+    ws = _workspace(dev, nb.value, 'radius')
+    offsets = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    total = C.c_int64(0)
+    args = (pos.data_ptr(), _ld(pos), pos.shape[1], nt.data_ptr(), ldt, N, float(radius), int(sender_type),
+            int(receiver_type), nbr_rowptr.data_ptr() if nbr_rowptr is not None else None,
+            nbr.data_ptr() if nbr is not None else None)
+    _lib.check(L.hgn_radius_edges_count(*args, offsets.data_ptr(), C.byref(total), ws.data_ptr(), ws.numel(),
+                                        _lib.stream_ptr()), 'hgn_radius_edges_count')
+    s = torch.empty(total.value, dtype=torch.int64, device=dev)
+    r = torch.empty(total.value, dtype=torch.int64, device=dev)
+    if total.value:
+        _lib.check(L.hgn_radius_edges_fill(*args, offsets.data_ptr(), s.data_ptr(), r.data_ptr(), _lib.stream_ptr()),
+                   'hgn_radius_edges_fill')
+    return s, r

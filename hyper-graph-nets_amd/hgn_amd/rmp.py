@@ -262,10 +262,35 @@ class RemoteMessagePassing:
         graph = graph._replace(node_features=graph.node_features[0])          # :67
         if self._clusters is None:
             if graph.obstacle_nodes is not None:
-                raise NotImplementedError('obstacle removal (plate) is not part of the accelerated path yet')
-            self._clusters = self._clustering_algorithm.run(graph)
+                self.remove_obstacles(graph)
+            else:
+                self._clusters = self._clustering_algorithm.run(graph)
             self._neighbors = self._clustering_algorithm.neigboring_clusters
         return self._node_connector.run(graph, self._clusters, self._neighbors, is_training)
+
+    def remove_obstacles(self, graph: MultiGraphWithPos) -> None:
+        """remote_message_passing.py:82-137: cluster only the non-obstacle nodes (the obstacle block is contiguous, at
+        the start or at the end of the node list); cluster members keep their ids in the full graph.  Host-side index
+        work, once per trajectory."""
+        idx = graph.obstacle_nodes.nonzero().squeeze(1).cpu()
+        fst, lst = int(idx[0]), int(idx[-1])
+        e = graph.unnormalized_edges
+        s, r, f = e.senders.cpu(), e.receivers.cpu(), e.features.cpu()
+        if fst == 0:                                                   # keep [lst + 1, end)
+            keep = slice(lst + 1, None)
+            m = (s > lst) & (r > lst)
+            new_edges = EdgeSet('mesh_edges', f[m], s[m] - lst - 1, r[m] - lst - 1)
+            offset, b4 = lst + 1, True
+        else:                                                          # keep [0, fst)
+            keep = slice(0, fst)
+            m = (s < fst) & (r < fst)
+            new_edges = EdgeSet('mesh_edges', f[m], s[m], r[m])
+            offset, b4 = lst - fst + 1, False
+        new_graph = graph._replace(node_features=graph.node_features[keep], target_feature=graph.target_feature[keep],
+                                   mesh_features=graph.mesh_features[keep], unnormalized_edges=new_edges)
+        self._clusters = self._clustering_algorithm.run(new_graph, offset, b4)
+        if fst == 0:
+            self._clusters = [c + (lst + 1) for c in self._clusters]
 
     def reset_clusters(self):
         self._clusters = None

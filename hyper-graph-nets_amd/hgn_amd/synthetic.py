@@ -162,3 +162,50 @@ def cylinder_frame(seed: int = 0, nx: int = 30, ny: int = 20, dtype=torch.float3
     return {'velocity': velocity, 'target|velocity': target, 'mesh_pos': mesh_pos,
             'node_type': node_type.reshape(N, 1), 'cells': grid_triangles(nx, ny),
             'pressure': torch.randn(N, 1, generator=g, dtype=dtype)}
+
+
+def _grid_tets(nx: int, ny: int, nz: int, offset: int = 0) -> torch.Tensor:
+    """4-vertex cells of an nx x ny x nz node grid: five tetrahedra per cube."""
+    def nid(i, j, k):
+        return offset + (i * ny + j) * nz + k
+    cells = []
+    for i in range(nx - 1):
+        for j in range(ny - 1):
+            for k in range(nz - 1):
+                v = [nid(i + a, j + b, k + c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]   # v[4a+2b+c]
+                cells += [[v[0], v[1], v[2], v[4]], [v[3], v[1], v[2], v[7]], [v[5], v[1], v[4], v[7]],
+                          [v[6], v[2], v[4], v[7]], [v[1], v[2], v[4], v[7]]]
+    return torch.tensor(cells, dtype=torch.int64)
+
+
+def plate_frame(seed: int = 0, nx: int = 7, ny: int = 6, nz: int = 3, obstacle=(4, 4, 2), obstacle_first: bool = True,
+                spacing: float = 0.02, dtype=torch.float32) -> dict:
+    """One deforming_plate-shape frame (src/model/plate.py:69-83): a plate of NORMAL (0) / HANDLE (3) nodes and a
+    contiguous block of OBSTACLE (1) nodes hovering 0.8 grid spacings above it (so obstacle -> plate pairs fall inside the
+    0.03 world-edge radius), 4-vertex cells, world / target positions [N,3], mesh_pos [N,3]."""
+    g = torch.Generator().manual_seed(seed)
+
+    def grid(n, origin):
+        ax = [torch.arange(m, dtype=dtype) * spacing for m in n]
+        p = torch.stack(torch.meshgrid(*ax, indexing='ij'), -1).reshape(-1, 3)
+        return p + torch.tensor(origin, dtype=dtype)
+    plate = grid((nx, ny, nz), (0.0, 0.0, 0.0))
+    ox, oy, oz = obstacle
+    obst = grid(obstacle, (0.4 * spacing, 0.3 * spacing, (nz - 1) * spacing + 0.8 * spacing))
+    n_p, n_o = plate.shape[0], obst.shape[0]
+    t_plate = torch.zeros(n_p, dtype=torch.int32)
+    t_plate[:ny * nz] = 3                                       # the i = 0 face is clamped (HANDLE)
+    t_obst = torch.ones(n_o, dtype=torch.int32)
+    if obstacle_first:
+        mesh_pos = torch.cat([obst, plate])
+        node_type = torch.cat([t_obst, t_plate])
+        cells = torch.cat([_grid_tets(ox, oy, oz, 0), _grid_tets(nx, ny, nz, n_o)])
+    else:
+        mesh_pos = torch.cat([plate, obst])
+        node_type = torch.cat([t_plate, t_obst])
+        cells = torch.cat([_grid_tets(nx, ny, nz, 0), _grid_tets(ox, oy, oz, n_p)])
+    world = mesh_pos + 0.002 * torch.randn(mesh_pos.shape, generator=g, dtype=dtype)
+    target = world + 0.001 * torch.randn(mesh_pos.shape, generator=g, dtype=dtype)
+    target[node_type == 1] = world[node_type == 1] + torch.tensor([0.0, 0.0, -0.002], dtype=dtype)
+    return {'world_pos': world, 'target|world_pos': target, 'mesh_pos': mesh_pos, 'node_type': node_type.reshape(-1, 1),
+            'cells': cells, 'stress': torch.zeros(mesh_pos.shape[0], 1, dtype=dtype)}

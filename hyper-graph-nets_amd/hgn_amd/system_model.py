@@ -1,4 +1,4 @@
-"""System models with the reference's class API (src/model/abstract_system_model.py, flag.py, cylinder.py): frame ->
+"""System models with the reference's class API (src/model/abstract_system_model.py, flag.py, cylinder.py, plate.py): frame ->
 graph features on the device, remote-graph expansion, training / validation step, one-step update and rollout around
 the MI355X message-passing model.
 
@@ -31,7 +31,8 @@ class AbstractSystemModel(nn.Module):
     """abstract_system_model.py:10-190 (the shared constructor logic of flag.py:21-63 / cylinder.py:21-63 lives here)."""
     _model_type = None
 
-    def __init__(self, params, node_size: int, edge_size: int) -> None:
+    def __init__(self, params, node_size: int, edge_size: int, remote_edge_size: int = 7,
+                 edge_sets=('mesh_edges',)) -> None:
         super().__init__()
         self._params = params
         self.loss_fn = torch.nn.MSELoss()
@@ -39,12 +40,12 @@ class AbstractSystemModel(nn.Module):
         self._node_normalizer = Normalizer(size=node_size, name='node_normalizer')
         self._node_dynamic_normalizer = Normalizer(size=1, name='node_dynamic_normalizer')
         self._mesh_edge_normalizer = Normalizer(size=edge_size, name='mesh_edge_normalizer')
-        self._intra_edge_normalizer = Normalizer(size=7, name='intra_edge_normalizer')
-        self._inter_edge_normalizer = Normalizer(size=7, name='inter_edge_normalizer')
+        self._intra_edge_normalizer = Normalizer(size=remote_edge_size, name='intra_edge_normalizer')
+        self._inter_edge_normalizer = Normalizer(size=remote_edge_size, name='inter_edge_normalizer')
         self._hyper_node_normalizer = Normalizer(size=3, name='hyper_node_normalizer')
         r, b = params.get('rmp'), params.get('graph_balancer')
         self._rmp = r.get('clustering') != 'none' and r.get('connector') != 'none'
-        self._architecture = r.get('connector') if self._rmp else 'none'
+        self._architecture = self._select_architecture(r.get('connector'))
         self._multi = r.get('connector') == 'multigraph' and self._rmp
         self._balancer = b.get('algorithm') != 'none'
         self.message_passing_steps = params.get('message_passing_steps')
@@ -52,7 +53,7 @@ class AbstractSystemModel(nn.Module):
         self._balance_frequency = b.get('frequency')
         self._rmp_frequency = r.get('frequency')
         self._visualized = False
-        self._edge_sets = ['mesh_edges']
+        self._edge_sets = list(edge_sets)
         if self._balancer:
             raise NotImplementedError('graph balancers (Ricci / SDRF / random) are outside the accelerated path; a '
                                       "'balance' edge set built elsewhere can be passed to MeshGraphNet directly")
@@ -68,6 +69,9 @@ class AbstractSystemModel(nn.Module):
         self._cells_key = None
         self._cells_edges = None
 
+    def _select_architecture(self, connector):
+        return connector if self._rmp else 'none'                     # flag.py:36, cylinder.py:36
+
     # ---- topology, once per mesh ------------------------------------------------------------------------------
     def _mesh_edges(self, cells: Tensor, deform: bool = False):
         """util.triangles_to_edges on the device, cached while the same ``cells`` tensor (or equal content) comes in."""
@@ -76,7 +80,7 @@ class AbstractSystemModel(nn.Module):
                                          and torch.equal(self._cells_key, cells)))
         if not hit:
             s, r, _ = features.cells_to_edges(cells.to(device), deform)
-            self._cells_key, self._cells_edges = cells, (s, r)
+            self._cells_key, self._cells_edges = cells, (s.contiguous(), r.contiguous())
         return self._cells_edges
 
     def expand_graph(self, graph: MultiGraphWithPos, step: int, num_steps: int, is_training: bool) -> MultiGraph:
@@ -292,11 +296,130 @@ class CylinderModel(AbstractSystemModel):
         return next_velocity, pred_pressure, trajectory, pressure_trajectory
 
 
+class PlateModel(AbstractSystemModel):
+    """src/model/plate.py:17-340 (deforming plate: world edges from obstacle to plate nodes, 4-vertex cells)."""
+    _model_type = 'plate'
+    _TYPE_MAP = (0, 1, 2, 2)                     # plate.py:78: HANDLE (3) -> class 2
+    _RADIUS = 0.03                               # plate.py:85
+
+    def __init__(self, params):
+        super().__init__(params, node_size=6, edge_size=8, remote_edge_size=8, edge_sets=('mesh_edges', 'world_edges'))
+        self._world_edge_normalizer = Normalizer(size=4, name='world_edge_normalizer')
+
+    def _select_architecture(self, connector):
+        return connector if (self._rmp or connector == 'repeated') else 'none'        # plate.py:37-39
+
+    def build_graph(self, inputs: Dict, is_training: bool) -> MultiGraphWithPos:
+        """plate.py:69-200."""
+        world_pos = inputs['world_pos'].to(device)
+        mesh_pos = inputs['mesh_pos'].to(device)
+        target_world_pos = inputs['target|world_pos'].to(device)
+        node_type = inputs['node_type'].to(device)
+        num_nodes = node_type.shape[0]
+        senders, receivers = self._mesh_edges(inputs['cells'], deform=True)
+        # world edges: obstacle -> normal pairs closer than the radius that are not mesh edges          plate.py:84-110
+        csr = topology.segment_csr(receivers, num_nodes, world_pos.device)        # neighbours of n = senders of its edges
+        if getattr(self, '_nbr_key', None) is not senders:
+            self._nbr = senders[csr.perm.long()].to(torch.int32).contiguous()
+            self._nbr_key = senders
+        world_senders, world_receivers = features.radius_edges(world_pos, node_type, self._RADIUS, NodeType.OBSTACLE.value,
+                                                                NodeType.NORMAL.value, csr.rowptr, self._nbr)
+        world_edge_features, _ = features.rel_edge_features(world_pos, None, world_senders, world_receivers)
+        world_edges = EdgeSet(name='world_edges', features=self._world_edge_normalizer(world_edge_features, is_training),
+                              receivers=world_receivers, senders=world_senders)
+        mesh_edge_features, _ = features.rel_edge_features(world_pos, mesh_pos, senders, receivers)
+        mesh_edges = EdgeSet(name='mesh_edges', features=self._mesh_edge_normalizer(mesh_edge_features, is_training),
+                             receivers=receivers, senders=senders)
+        # one-hot(3) | velocity of the kinematic (obstacle) nodes, zero elsewhere                      plate.py:186-195
+        node_features = features.node_features(target_world_pos, world_pos, node_type, self._TYPE_MAP, 3, vel_first=False,
+                                               vel_mask_type=NodeType.OBSTACLE.value)
+        obstacle_nodes = torch.eq(node_type[:, 0], NodeType.OBSTACLE.value)
+        return MultiGraphWithPos(
+            node_features=[self._node_normalizer(node_features, is_training)], edge_sets=[mesh_edges, world_edges],
+            mesh_features=mesh_pos, target_feature=world_pos, model_type=self._model_type,
+            unnormalized_edges=EdgeSet(name='mesh_edges', features=mesh_edge_features, receivers=receivers,
+                                       senders=senders),
+            node_dynamic=None, obstacle_nodes=obstacle_nodes)
+
+    def _loss_mask(self, data_frame):
+        return torch.eq(data_frame['node_type'].to(device)[:, 0], NodeType.NORMAL.value)
+
+    def training_step(self, graph, data_frame):
+        """plate.py:218-228."""
+        network_output = self(graph)
+        target_normalized = self.get_target(data_frame)
+        return _masked_mse(target_normalized, network_output, self._loss_mask(data_frame))
+
+    @torch.no_grad()
+    def validation_step(self, graph: MultiGraph, data_frame: Dict) -> Tuple[Tensor, Tensor]:
+        """plate.py:230-244."""
+        prediction = self(graph)
+        target_normalized = self.get_target(data_frame, False)
+        mask = self._loss_mask(data_frame)
+        vel_loss = _masked_mse(target_normalized, prediction, mask).item()
+        predicted_position, _, _ = self.update(data_frame, prediction)
+        pos_error = _masked_mse(data_frame['target|world_pos'].to(device), predicted_position, mask).item()
+        return vel_loss, pos_error
+
+    def update(self, inputs: Dict, per_node_network_output: Tensor):
+        """plate.py:246-257: next position = current + predicted velocity."""
+        velocity = self._output_normalizer.inverse(per_node_network_output)
+        cur_position = inputs['world_pos'].to(device)
+        return features.lincomb3(cur_position, 1.0, velocity, 1.0), cur_position, velocity
+
+    def get_target(self, data_frame, is_training=True):
+        """plate.py:259-264."""
+        v = features.lincomb3(data_frame['target|world_pos'].to(device), 1.0, data_frame['world_pos'], -1.0)
+        return self._output_normalizer(v, is_training)
+
+    @torch.no_grad()
+    def rollout(self, trajectory: Dict[str, Tensor], num_steps: int):
+        """plate.py:266-316."""
+        num_steps = trajectory['cells'].shape[0] if num_steps is None else num_steps
+        initial_state = {k: torch.squeeze(v, 0)[0].to(device) for k, v in trajectory.items()}
+        node_type = initial_state['node_type']
+        mask = torch.eq(node_type[:, 0], NodeType.NORMAL.value)
+        mask = torch.stack((mask, mask, mask), dim=1)
+        cur_pos = initial_state['world_pos']
+        target_pos = trajectory['target|world_pos'].to(device)
+        pred_trajectory, cur_positions, cur_velocities = [], [], []
+        for step in range(num_steps):
+            cur_pos, pred_trajectory, cur_positions, cur_velocities = self._step_fn(
+                initial_state, cur_pos, pred_trajectory, cur_positions, cur_velocities, target_pos[step], step, mask,
+                num_steps)
+        prediction, cur_positions, cur_velocities = (torch.stack(pred_trajectory), torch.stack(cur_positions),
+                                                     torch.stack(cur_velocities))
+        faces = trajectory['cells']                      # tetrahedra -> triangles for the viewer (plate.py:289-297)
+        faces_result = torch.stack([torch.cat((f[:, 0:3], torch.cat((f[:, 2:4], f[:, 0:1]), -1)), 0) for f in faces], 0)
+        traj_ops = {'faces': faces_result, 'mesh_pos': trajectory['mesh_pos'],
+                    'mask': torch.eq(node_type[:, 0], NodeType.OBSTACLE.value), 'gt_pos': trajectory['world_pos'],
+                    'pred_pos': prediction, 'cur_positions': cur_positions, 'cur_velocities': cur_velocities}
+        gt = trajectory['world_pos'][:num_steps].to(device)
+        mse_loss = torch.mean(torch.mean((gt - prediction) ** 2, dim=-1), dim=-1).detach()
+        return traj_ops, mse_loss
+
+    @torch.no_grad()
+    def _step_fn(self, initial_state, cur_pos, trajectory, cur_positions, cur_velocities, target_world_pos, step, mask,
+                 num_steps):
+        """plate.py:318-340."""
+        inputs = {**initial_state, 'world_pos': cur_pos, 'target|world_pos': target_world_pos}
+        graph = self.build_graph(inputs, is_training=False)
+        graph = self.expand_graph(graph, step, num_steps, is_training=False)
+        prediction, cur_position, cur_velocity = self.update(inputs, self(graph))
+        next_pos = torch.where(mask, prediction, target_world_pos)
+        trajectory.append(next_pos)
+        cur_positions.append(cur_position)
+        cur_velocities.append(cur_velocity)
+        return next_pos, trajectory, cur_positions, cur_velocities
+
+
 def get_model(config) -> AbstractSystemModel:
     """src/model/get_model.py:13-22."""
     name = str(config['task']['dataset']).lower()
     if 'flag' in name:
         return FlagModel(config.get('model'))
+    if 'plate' in name:
+        return PlateModel(config.get('model'))
     if 'cylinder' in name:
         return CylinderModel(config.get('model'))
     raise NotImplementedError('Implement your algorithms here!')

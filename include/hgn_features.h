@@ -10,6 +10,7 @@
  *   rmp/abstract_connector.py:84-98  relative position features of an edge set -> hgn_rel_edge_features
  *   model/flag.py:68-74, cylinder.py:67-76, plate.py:75-79,186-195
  *                                    velocity + one-hot node features          -> hgn_node_features
+ *   model/plate.py:84-110            world edges (cdist + masks + nonzero)      -> hgn_radius_edges_count/_fill
  *   model/flag.py:178,188, cylinder.py:163,171  target / integrator arithmetic   -> hgn_lincomb3
  *   migration/normalizer.py:40-71    Normalizer.forward / inverse / _accumulate -> hgn_col_stats,
  *                                                                              hgn_normalizer_update, hgn_normalize
@@ -73,6 +74,26 @@ int hgn_normalizer_update(float* acc_sum, float* acc_sumsq, float* acc_count, fl
                           const float* count /*device [1]*/, int F, float max_acc, void* stream);
 int hgn_normalize(const float* x, int64_t rows, int F, const float* acc_sum, const float* acc_sumsq,
                   const float* acc_count, float eps, int inverse, float* out, void* stream);
+
+/* ---- world edges by radius (plate.py:84-110) ---------------------------------------------------------------
+ * Directed pairs (s, r), s != r, with |pos[s] - pos[r]| < radius, node_type[s] == sender_type, node_type[r] ==
+ * receiver_type (a negative type = any), and (s, r) not adjacent in the mesh given as a CSR (nbr_rowptr [N+1],
+ * nbr [nnz]: neighbours of node n = nbr[nbr_rowptr[n] .. nbr_rowptr[n+1]); nullable = no exclusion).  Output order =
+ * torch.nonzero of the reference's N x N mask: ascending s, then ascending r.  Distances are evaluated as
+ * sqrt(sum (pos[s]-pos[r])^2) in fp32 (the reference's cdist switches to the |a|^2+|b|^2-2ab form for N > 25, which
+ * differs only for pairs within fp32 noise of the radius).
+ * Two calls (the result size is data dependent): _count fills offsets[N+1] (device int32, exclusive prefix of the per-
+ * sender counts, offsets[N] = total) and returns the total on the HOST (synchronises the stream); _fill writes
+ * senders / receivers [total] int64.  One wavefront per sender row; no N x N matrix is formed. */
+int hgn_radius_edges_workspace_bytes(int64_t N, size_t* bytes);
+int hgn_radius_edges_count(const float* pos, int64_t ld, int d, const int64_t* node_type, int64_t ldt, int64_t N,
+                           float radius, int sender_type, int receiver_type, const int32_t* nbr_rowptr,
+                           const int32_t* nbr, int32_t* offsets /*[N+1]*/, int64_t* total /*host*/, void* workspace,
+                           size_t ws_bytes, void* stream);
+int hgn_radius_edges_fill(const float* pos, int64_t ld, int d, const int64_t* node_type, int64_t ldt, int64_t N,
+                          float radius, int sender_type, int receiver_type, const int32_t* nbr_rowptr,
+                          const int32_t* nbr, const int32_t* offsets, int64_t* senders, int64_t* receivers,
+                          void* stream);
 
 /* ---- targets and the one-step integrator ---------------------------------------------------------------------
  * out[i] = (ca*a[i] + cb*b[i]) + cc*c[i]   (c nullable), each product and sum rounded separately (no fma), so that

@@ -132,6 +132,63 @@ class CylinderFeatures:
 
 
 # --------------------------------------------------------------------------------------------------------
+# model/plate.py
+# --------------------------------------------------------------------------------------------------------
+class PlateFeatures:
+    RADIUS = 0.03                                                     # plate.py:85
+
+    def __init__(self, dtype=torch.float32):
+        self.dtype = dtype
+        self.output = Normalizer(3, dtype=dtype)
+        self.node = Normalizer(6, dtype=dtype)
+        self.mesh_edge = Normalizer(8, dtype=dtype)
+        self.world_edge = Normalizer(4, dtype=dtype)
+        self.intra_edge = Normalizer(8, dtype=dtype)
+        self.inter_edge = Normalizer(8, dtype=dtype)
+        self.hyper_node = Normalizer(3, dtype=dtype)
+
+    def build_graph(self, inputs, is_training: bool) -> dict:
+        """plate.py:69-200.  Distances by the direct difference formula (the reference's cdist uses the matrix-product
+        form above 25 points; both agree unless a pair sits within fp32 noise of the radius)."""
+        dt = self.dtype
+        world, mesh, target = inputs['world_pos'].to(dt), inputs['mesh_pos'].to(dt), inputs['target|world_pos'].to(dt)
+        raw = inputs['node_type'][:, 0].long()
+        t = raw.clone()
+        t[t == 3] = 2                                                 # plate.py:78
+        one_hot = torch.nn.functional.one_hot(t, 3).to(dt)
+        s, r = triangles_to_edges(inputs['cells'], deform=True)
+        dist = torch.sqrt((world[:, None, :] - world[None, :, :]).pow(2).sum(-1))
+        conn = dist < self.RADIUS                                     # plate.py:86-88
+        conn.fill_diagonal_(False)
+        conn[s, r] = False                                            # :91
+        conn[raw != 1, :] = False                                     # :96-97 only OBSTACLE senders
+        conn[:, raw != 0] = False                                     # :105-106 only NORMAL receivers
+        ws, wr = torch.nonzero(conn, as_tuple=True)
+        world_feat = rel_features(world, None, ws, wr)                # :137-140
+        mesh_feat = rel_features(world, mesh, s, r)                   # :165-173
+        world_n = self.world_edge(world_feat, is_training)
+        mesh_n = self.mesh_edge(mesh_feat, is_training)
+        vel = torch.zeros(world.shape[0], 3, dtype=dt)
+        obst = raw == 1
+        vel[obst] = target[obst] - world[obst]                        # :190-194
+        node_features = torch.cat((one_hot, vel), -1)
+        nodes_n = self.node(node_features, is_training)
+        return {'node_features': [nodes_n],
+                'edge_sets': [EdgeSet('mesh_edges', mesh_n, s, r), EdgeSet('world_edges', world_n, ws, wr)],
+                'target_feature': world, 'mesh_features': mesh, 'obstacle_nodes': obst,
+                'unnormalized_edges': EdgeSet('mesh_edges', mesh_feat, s, r)}
+
+    def get_target(self, frame, is_training=True):
+        """plate.py:259-264."""
+        return self.output(frame['target|world_pos'].to(self.dtype) - frame['world_pos'].to(self.dtype), is_training)
+
+    def update(self, inputs, net_out):
+        """plate.py:246-257."""
+        v = self.output.inverse(net_out.to(self.dtype))
+        return inputs['world_pos'].to(self.dtype) + v
+
+
+# --------------------------------------------------------------------------------------------------------
 # rmp/: neighbouring clusters and the hierarchical connector
 # --------------------------------------------------------------------------------------------------------
 def neighboring_clusters(senders: torch.Tensor, receivers: torch.Tensor, labels: Sequence[int]) -> List[tuple]:

@@ -288,3 +288,95 @@ def test_flag_rollout_runs_and_keeps_handles_fixed():
     assert torch.equal(ops_['pred_pos'][0], traj['world_pos'][0])
     handles = frames[0]['node_type'][:, 0] != 0
     assert torch.equal(ops_['pred_pos'][:, handles], traj['world_pos'][0][handles].expand(T, -1, -1))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# PlateModel: world edges by radius, 4-vertex cells, obstacle removal before clustering, hetero expansion
+# ----------------------------------------------------------------------------------------------------------------
+def plate_params(connector, K):
+    p = flag_params(connector, K, False, True)
+    return p
+
+
+@pytest.mark.parametrize('name', ['plate_hetero_k4_first', 'plate_none_last', 'plate_hetero_k4_last'])
+def test_plate_model_features_match_reference_golden(name):
+    from hgn_amd import system_model
+    fx = load(name)
+    rcfg = fx['config']['rmp']
+    model = system_model.PlateModel(plate_params(rcfg['connector'], rcfg['num_clusters']))
+    pf64 = FO.PlateFeatures(dtype=torch.float64)
+    for i, fr in enumerate(fx['frames']):
+        training = i < 1
+        g = model.build_graph(cuda_frame(fr), training)
+        ref = fx['graphs'][i]
+        o64 = pf64.build_graph(fr, training)
+        assert [e.name for e in g.edge_sets] == ['mesh_edges', 'world_edges']
+        for e, re_, e64 in zip(g.edge_sets, ref['edge_sets'], o64['edge_sets']):
+            assert torch.equal(e.senders.cpu(), re_['senders']) and torch.equal(e.receivers.cpu(), re_['receivers']), e.name
+            assert rel_err(e.features, e64.features) <= max(TOL, 1.5 * rel_err(re_['features'], e64.features)), e.name
+        assert rel_err(g.node_features[0], o64['node_features'][0]) <= \
+            max(TOL, 1.5 * rel_err(ref['node_features'][0], o64['node_features'][0]))
+        assert torch.equal(g.obstacle_nodes.cpu(), ref['obstacle_nodes'])
+        t64 = pf64.get_target(fr, training)
+        assert rel_err(model.get_target(cuda_frame(fr), training), t64) <= max(TOL, 1.5 * rel_err(fx['targets'][i], t64))
+        if fx['expanded']:
+            ex = fx['expanded'][i]
+            mg = model.expand_graph(g, i, 2, training)          # step 0: obstacle removal + k-means on the host
+            rmp = model._remote_graph
+            assert all(torch.equal(a.cpu(), b) for a, b in zip(rmp._clusters, ex['clusters']))
+            want_nb = sorted({(min(a, b), max(a, b)) for a, b in (tuple(t.tolist()) for t in ex['neighbors'])})
+            assert [tuple(t.tolist()) for t in rmp._neighbors] == want_nb
+            m64 = FO.hierarchical_connect(o64, rmp._clusters, [tuple(t.tolist()) for t in rmp._neighbors],
+                                          pf64.intra_edge, pf64.inter_edge, pf64.hyper_node, training)
+            assert [x.name for x in mg.edge_sets] == [x['name'] for x in ex['edge_sets']]
+            for a, b, c in zip(mg.edge_sets, ex['edge_sets'], m64.edge_sets):
+                if a.name != 'inter_cluster':                    # inter edges: same set, the reference's order is set order
+                    assert torch.equal(a.senders.cpu(), b['senders']) and torch.equal(a.receivers.cpu(), b['receivers'])
+                else:
+                    assert sorted(zip(a.senders.tolist(), a.receivers.tolist())) == \
+                        sorted(zip(b['senders'].tolist(), b['receivers'].tolist()))
+                assert torch.equal(a.senders.cpu(), c.senders) and torch.equal(a.receivers.cpu(), c.receivers)
+                assert rel_err(a.features, c.features) <= 5e-5, a.name
+            for a, b, c in zip(mg.node_features, ex['node_features'], m64.node_features):
+                assert rel_err(a, c) <= max(TOL, 1.5 * rel_err(b, c))
+            out = model(mg)                                      # hetero block over all five edge sets
+            assert out.shape == (fr['world_pos'].shape[0], 3) and bool(torch.isfinite(out).all())
+    upd = model.update(cuda_frame(fx['frames'][0]), fx['net_out'].cuda())[0]
+    assert rel_err(upd, pf64.update(fx['frames'][0], fx['net_out'])) <= TOL
+
+
+def test_radius_edges_against_brute_force():
+    from hgn_amd import features, topology
+    g = torch.Generator().manual_seed(4)
+    N = 3000
+    pos = torch.rand(N, 3, generator=g) * 0.25
+    types = torch.randint(0, 3, (N, 1), generator=g)
+    ms = torch.randint(0, N, (9000,), generator=g)
+    mr = torch.randint(0, N, (9000,), generator=g)
+    ms, mr = torch.cat([ms, mr]), torch.cat([mr, ms])            # symmetric "mesh" to exclude
+    radius = 0.03
+    d = torch.cdist(pos.double(), pos.double())
+    conn = d < radius
+    conn.fill_diagonal_(False)
+    conn[ms, mr] = False
+    conn[types[:, 0] != 1, :] = False
+    conn[:, types[:, 0] != 0] = False
+    border = ((d - radius).abs() < 1e-7) & (types[:, 0] == 1)[:, None] & (types[:, 0] == 0)[None, :]
+    assert not bool(border.any())                                 # no pair within fp32 noise of the radius
+    ws, wr = torch.nonzero(conn, as_tuple=True)
+    csr = topology.segment_csr(mr.cuda(), N, torch.device('cuda'))
+    nbr = ms.cuda()[csr.perm.long()].to(torch.int32).contiguous()
+    s, r = features.radius_edges(pos.cuda(), types.cuda(), radius, 1, 0, csr.rowptr, nbr)
+    assert s.shape[0] > 1000 and torch.equal(s.cpu(), ws) and torch.equal(r.cpu(), wr)
+    # no exclusion list, any receiver type
+    conn2 = d < radius
+    conn2.fill_diagonal_(False)
+    conn2[types[:, 0] != 1, :] = False
+    ws2, wr2 = torch.nonzero(conn2, as_tuple=True)
+    s2, r2 = features.radius_edges(pos.cuda(), types.cuda(), radius, 1, -1)
+    assert torch.equal(s2.cpu(), ws2) and torch.equal(r2.cpu(), wr2)
+    # nothing in range -> empty edge set flows through features and normaliser
+    s3, r3 = features.radius_edges(pos.cuda(), types.cuda(), 1e-6, 1, 0)
+    assert s3.numel() == 0
+    f3, _ = features.rel_edge_features(pos.cuda(), None, s3, r3)
+    assert f3.shape == (0, 4)

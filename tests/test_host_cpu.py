@@ -271,3 +271,13 @@ def test_shard_indices_partition():
     for n, w in ((8, 8), (21, 8), (3, 2), (64, 4)):
         parts = [parallel.shard_indices(n, r, w) for r in range(w)]
         assert sorted(sum(parts, [])) == list(range(n))
+
+
+def test_abi_radius_edges_validation():
+    from hgn_amd import _lib
+    lib = _lib.lib()
+    nb = C.c_size_t(0)
+    assert lib.hgn_radius_edges_workspace_bytes(1000, C.byref(nb)) == 0 and nb.value >= 4004
+    tot = C.c_int64(0)
+    assert lib.hgn_radius_edges_count(None, 3, 5, None, 1, 10, 0.03, 1, 0, None, None, None, C.byref(tot), None, 0, None) == -1
+    assert lib.hgn_radius_edges_fill(None, 3, 3, None, 1, 10, 0.03, 1, 0, None, None, None, None, None, None) == -1

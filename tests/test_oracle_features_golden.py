@@ -87,3 +87,32 @@ def test_cylinder_build_graph():
     v, p = cf.update(fx['frames'][0], fx['net_out'])
     torch.testing.assert_close(v, fx['update'][0], **TOL)
     torch.testing.assert_close(p, fx['update'][1], **TOL)
+
+
+@pytest.mark.parametrize('name', ['plate_hetero_k4_first', 'plate_none_last', 'plate_hetero_k4_last'])
+def test_plate_build_graph_and_expand(name):
+    fx = load(name)
+    pf = FO.PlateFeatures()
+    for i, fr in enumerate(fx['frames']):
+        training = i < 1
+        g = pf.build_graph(fr, training)
+        ref = fx['graphs'][i]
+        assert [e.name for e in g['edge_sets']] == [e['name'] for e in ref['edge_sets']]
+        for e, re_ in zip(g['edge_sets'], ref['edge_sets']):
+            assert torch.equal(e.senders, re_['senders']) and torch.equal(e.receivers, re_['receivers']), e.name
+            torch.testing.assert_close(e.features, re_['features'], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(g['unnormalized_edges'].features, ref['unnormalized_edges']['features'], **TOL)
+        torch.testing.assert_close(g['node_features'][0], ref['node_features'][0], rtol=1e-4, atol=1e-4)
+        assert torch.equal(g['obstacle_nodes'], ref['obstacle_nodes'])
+        torch.testing.assert_close(pf.get_target(fr, training), fx['targets'][i], rtol=1e-4, atol=1e-4)
+        if fx['expanded']:
+            ex = fx['expanded'][i]
+            mg = FO.hierarchical_connect(g, ex['clusters'], [tuple(t.tolist()) for t in ex['neighbors']], pf.intra_edge,
+                                         pf.inter_edge, pf.hyper_node, training)
+            assert [x.name for x in mg.edge_sets] == [x['name'] for x in ex['edge_sets']]
+            for a, b in zip(mg.edge_sets, ex['edge_sets']):
+                assert torch.equal(a.senders, b['senders']) and torch.equal(a.receivers, b['receivers']), a.name
+                torch.testing.assert_close(a.features, b['features'], rtol=1e-4, atol=1e-4)
+            for a, b in zip(mg.node_features, ex['node_features']):
+                torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(pf.update(fx['frames'][0], fx['net_out']), fx['update'], **TOL)
