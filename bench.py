@@ -36,7 +36,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='graphs per GPU (weak scaling: fixed per-GPU work)')
+    ap.add_argument('--batch', type=int, default=128,
+                    help='graphs per GPU (weak scaling: fixed per-GPU work); 128 = the saturating batch of SURVEY 8d')
     ap.add_argument('--layers', type=int, default=15)
     ap.add_argument('--agg', default='sum')
     ap.add_argument('--arch', default='none')
@@ -46,8 +47,12 @@ def parse():
     ap.add_argument('--world-edges', type=int, default=0, help='extra world edges per graph (plate-style second edge set)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-kernel HIP events in the timed region')
-    ap.add_argument('--graph', action='store_true', help='replay the whole training step from one HIP graph (N=1; per-kernel events are '
-                    'then taken in a short eager pass after the timed region)')
+    ap.add_argument('--eager', action='store_true',
+                    help='N=1: launch every kernel from the host in the timed region (per-kernel HIP events recorded live). '
+                         'Default at N=1 is to replay the whole training step from one HIP graph, which keeps the measurement '
+                         'independent of host-side launch jitter; per-kernel events are then taken in a short eager pass on the '
+                         'same buffers right after the timed region (events cannot be timed inside a replayed graph).')
+    ap.add_argument('--graph', action='store_true', help='(default at N=1; kept for compatibility)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
 
@@ -161,7 +166,7 @@ def main():
         model(graph)                                     # materialise lazy layers, build + cache the CSR topology
     torch.cuda.synchronize()
     log('first forward done')
-    use_graph = args.graph and world == 1
+    use_graph = world == 1 and not args.eager
     trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph)
     n_params = trainer.fp.numel
 
@@ -177,9 +182,14 @@ def main():
             torch.cuda.synchronize(); log('first training step done')
     if use_graph:
         from hgn_amd import graphs
-        gstep = graphs.GraphedTrainStep(trainer, graph, target, mask, warmup=1)
-        step = lambda: gstep()
-        step()
+        try:
+            gstep = graphs.GraphedTrainStep(trainer, graph, target, mask, warmup=1)
+            gstep()
+            step = lambda: gstep()
+        except Exception as ex:                          # capture refused: measure the eager launches instead
+            log(f'HIP-graph capture failed ({type(ex).__name__}: {ex}); falling back to eager launches')
+            torch.cuda.synchronize()
+            use_graph = False
     barrier()
     log('warmup done')
     prof = not args.no_prof
