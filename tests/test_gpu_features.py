@@ -380,3 +380,33 @@ def test_radius_edges_against_brute_force():
     assert s3.numel() == 0
     f3, _ = features.rel_edge_features(pos.cuda(), None, s3, r3)
     assert f3.shape == (0, 4)
+
+
+def test_end_to_end_training_loop_overfits_a_small_batch():
+    """The whole chain as the reference's fit loop strings it together (MeshSimulator.fit_iteration): frames ->
+    FlagModel.build_graph -> expand_graph (hyper) -> batch of graphs -> MeshGraphNet -> masked loss -> Adam, on the device
+    kernels end to end; the loss on a fixed batch must fall."""
+    from hgn_amd import batching, parallel, system_model
+    torch.manual_seed(0)
+    frames = [synth.flag_frame(seed=50 + i, nx=10, ny=8) for i in range(4)]
+    model = system_model.FlagModel(flag_params('hyper', 4, False, True, steps=3, agg='sum'))
+    graphs, targets, masks = [], [], []
+    for i, fr in enumerate(frames):
+        cf = cuda_frame(fr)
+        if i == 0:
+            cells = cf['cells']
+        cf['cells'] = cells                                   # one mesh per trajectory: the topology cache is hit
+        g = model.build_graph(cf, True)
+        mg = model.expand_graph(g, i, 4, True)
+        graphs.append(mg)
+        targets.append(model.get_target(cf, True))
+        masks.append(cf['node_type'][:, 0] == 0)
+    big = batching.batch_graphs(graphs)
+    target, mask = torch.cat(targets), torch.cat(masks)
+    assert big.node_features[0].shape[0] == 4 * 80 and big.node_features[1].shape[0] == 4 * 4
+    with torch.no_grad():
+        model.learned_model(big)
+    trainer = parallel.DataParallelTrainer(model.learned_model, lr=1e-3)
+    losses = [float(trainer.step(big, target, mask)) for _ in range(40)]
+    assert all(l == l for l in losses)
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
