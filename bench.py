@@ -166,7 +166,7 @@ def main():
         model(graph)                                     # materialise lazy layers, build + cache the CSR topology
     torch.cuda.synchronize()
     log('first forward done')
-    use_graph = world == 1 and not args.eager
+    use_graph = not args.eager
     trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph)
     n_params = trainer.fp.numel
 
@@ -183,7 +183,8 @@ def main():
     if use_graph:
         from hgn_amd import graphs
         try:
-            gstep = graphs.GraphedTrainStep(trainer, graph, target, mask, warmup=1)
+            # N=1: the whole step (incl. Adam) is one graph; N>1: forward+backward is the graph, all-reduce and Adam eager
+            gstep = (graphs.GraphedTrainStep if world == 1 else graphs.GraphedShardStep)(trainer, graph, target, mask, warmup=1)
             gstep()
             step = lambda: gstep()
         except Exception as ex:                          # capture refused: measure the eager launches instead
@@ -202,10 +203,11 @@ def main():
     dt = time.perf_counter() - t0
     log(f'timed region done: {dt:.3f} s for {args.steps} steps')
     if prof and use_graph:            # events cannot be recorded inside a replayed graph: short eager pass on the same buffers
+        barrier()
         ops.prof_reset(); ops.prof_enable(True)
         for _ in range(2):
             trainer.step(graph, target, mask)
-        torch.cuda.synchronize()
+        barrier()
     if prof:
         ops.prof_enable(False)
     tmax = torch.tensor([dt], device=dev)

@@ -83,3 +83,62 @@ class GraphedTrainStep:
             self.target.copy_(target, non_blocking=True)
         self.graph.replay()
         return self.loss
+
+
+class GraphedShardStep:
+    """Data-parallel step with the collectives OUTSIDE the graph: forward + local masked squared-error sum + backward of
+    this rank's shard are captured once and replayed; the two all-reduces (NORMAL-node count, flat gradient), the scaling to
+    the GLOBAL mean (flag.py:150-152 semantics over the whole batch) and the fused Adam stay eager.  Works for any world
+    size (world 1: no collective), keeps the measured step independent of host-side launch jitter, and needs no support for
+    capturing RCCL calls."""
+
+    def __init__(self, trainer, example: MultiGraph, target: torch.Tensor, mask: torch.Tensor, warmup: int = 2):
+        self.trainer = trainer
+        self.static = _static_copy(example)
+        self.target = target.detach().clone()
+        self.maskf = mask.detach().to(torch.float32).unsqueeze(1).clone()
+        self.n_local = mask.sum().to(torch.float32).reshape(1)
+        self.width = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.sq_sum = self._fwd_bwd()
+
+    def _fwd_bwd(self) -> torch.Tensor:
+        from . import ops
+        tr = self.trainer
+        tr.fp.zero_grad()
+        if tr.side is not None:
+            tr.side.wait_stream(torch.cuda.current_stream())
+            ops.set_wgrad_stream(tr.side)
+        out = tr.model(self.static)
+        self.width = out.shape[1]
+        s = ((out - self.target) * self.maskf).square().sum()
+        s.backward()
+        if tr.side is not None:
+            ops.set_wgrad_stream(None)
+            torch.cuda.current_stream().wait_stream(tr.side)
+        return s.detach()
+
+    def __call__(self) -> torch.Tensor:
+        import torch.distributed as dist
+        from . import ops
+        tr = self.trainer
+        self.graph.replay()
+        n_global = self.n_local.clone()
+        if tr.world > 1:
+            dist.all_reduce(n_global, group=tr.group)
+            dist.all_reduce(tr.fp.grad, group=tr.group)                       # ONE collective for all gradients
+        inv = 1.0 / (n_global * self.width)
+        tr.fp.grad.mul_(inv)                                                  # gradient of the global mean
+        tr.t += 1
+        if tr.t_dev is not None:
+            ops.adam_step_dev(tr.fp.flat, tr.fp.grad, tr.m, tr.v, tr.lr, tr.betas[0], tr.betas[1], tr.eps, tr.t_dev)
+        else:
+            tr.adam_fn(tr.fp.flat, tr.fp.grad, tr.m, tr.v, tr.lr, tr.betas[0], tr.betas[1], tr.eps, tr.t)
+        return (self.sq_sum * inv).squeeze(0)

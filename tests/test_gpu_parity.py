@@ -458,3 +458,30 @@ def test_hip_graph_forward_and_train_step_replay():
     for a, b in zip(l_e, l_g):
         assert abs(a - b) <= 1e-6 * abs(a)
     assert H.rel_err(captured.fp.flat, eager.fp.flat) <= 1e-6
+
+
+def test_graphed_shard_step_matches_trainer_step():
+    """Data-parallel step with forward+backward replayed from a HIP graph and the (here absent) collectives + Adam eager:
+    same parameters and losses as DataParallelTrainer.step, which scales the loss before the backward instead of after."""
+    import hgn_amd
+    from hgn_amd import graphs, parallel
+    g0 = synth.grid_graph(seed=3, nx=12, ny=10)
+    shapes = O.param_shapes('none', 'sum', 3, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=2)
+    G0 = hgn_amd.MultiGraph([x.cuda() for x in g0.node_features],
+                            [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in g0.edge_sets])
+    N = 120
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(0)).cuda()
+    mask = torch.ones(N, dtype=torch.bool).cuda()
+    mask[:7] = False
+    eager = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 3, ['mesh_edges'], sd), lr=1e-3)
+    shard = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 3, ['mesh_edges'], sd), lr=1e-3, device_step=True)
+    gs = graphs.GraphedShardStep(shard, G0, target, mask, warmup=1)       # warm-up touches gradients only, not parameters
+    l_e, l_g = [float(eager.step(G0, target, mask))], [float(gs())]
+    assert abs(l_e[0] - l_g[0]) <= 2e-6 * abs(l_e[0])                  # same weights: only the place of the scaling differs
+    assert H.rel_err(shard.fp.grad, eager.fp.grad) <= 1e-5               # gradient of the global mean, scaled after vs before
+    l_e += [float(eager.step(G0, target, mask)) for _ in range(3)]
+    l_g += [float(gs()) for _ in range(3)]
+    for a, b in zip(l_e, l_g):        # later steps: Adam turns rounding-level gradient entries into +-lr moves, losses stay close
+        assert abs(a - b) <= 5e-5 * abs(a), (a, b)
+    assert int(shard.t_dev) == 4
