@@ -106,7 +106,8 @@ class GraphedShardStep:
                 self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: calls made by other threads of the process (the collective backend's watchdog) must not abort the capture
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.sq_sum = self._fwd_bwd()
 
     def _fwd_bwd(self) -> torch.Tensor:
