@@ -233,6 +233,88 @@ __global__ void radius_edges_kernel(const float* __restrict__ pos, long ld, int 
   if (!FILL && lane == 0) counts[s] = total;
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// balanced Forman curvature (SDRF): one wavefront per edge / per candidate pair
+// ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_count_max(int& cnt, float& mx) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    cnt += __shfl_xor(cnt, o);
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+}
+
+// closed form of ricci.py:185-191 / 256-262 in the reference kernel's typing: fp64 expression, fp32 stores
+__device__ __forceinline__ float forman_value(double dmax, double dmin, double a2, double a, int sharp, double lam) {
+  float c = (float)(((2 / dmax) + (2 / dmin) - 2) + (2 / dmax + 1 / dmin) * a2 * a);
+  if (lam > 0) c = (float)((double)c + (double)sharp / (dmax * lam));
+  return c;
+}
+
+__global__ void forman_curvature_kernel(const float* __restrict__ A, const float* __restrict__ A2,
+                                        const float* __restrict__ d_in, const float* __restrict__ d_out, long N,
+                                        const int* __restrict__ ei, const int* __restrict__ ej, long nnz,
+                                        float* __restrict__ C) {
+  const int lane = threadIdx.x & 63;
+  const long e = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (e >= nnz) return;
+  const long i = ei[e], j = ej[e];
+  const float aij = A[i * N + j];
+  if (aij == 0.f) { if (lane == 0) C[i * N + j] = 0.f; return; }
+  const float di = d_in[i], dj = d_out[j];
+  const float dmax = di > dj ? di : dj, dmin = di > dj ? dj : di;
+  if (dmax * dmin == 0.f) { if (lane == 0) C[i * N + j] = 0.f; return; }
+  int cnt = 0;
+  float mx = 0.f;
+  for (long k = lane; k < N; k += 64) {
+    const float aik = A[i * N + k], akj = A[k * N + j];
+    const float t1 = akj * (A2[i * N + k] - aik) * aij;
+    const float t2 = aik * (A2[k * N + j] - akj) * aij;
+    if (t1 > 0.f) { ++cnt; mx = fmaxf(mx, t1); }
+    if (t2 > 0.f) { ++cnt; mx = fmaxf(mx, t2); }
+  }
+  wave_count_max(cnt, mx);
+  if (lane == 0) C[i * N + j] = forman_value(dmax, dmin, A2[i * N + j], aij, cnt, mx);
+}
+
+__global__ void forman_post_delta_kernel(const float* __restrict__ A, const float* __restrict__ A2, float d_in_x0,
+                                         float d_out_y0, long N, int x, int y, const int* __restrict__ i_nb, int dim_i,
+                                         const int* __restrict__ j_nb, int dim_j, float* __restrict__ D) {
+  const int lane = threadIdx.x & 63;
+  const long p = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= (long)dim_i * dim_j) return;
+  const int I = (int)(p / dim_j), J = (int)(p % dim_j);
+  const long i = i_nb[I], j = j_nb[J];
+  if (i == j || A[i * N + j] != 0.f) { if (lane == 0) D[p] = -1000.f; return; }
+  double dx = d_in_x0, dy = d_out_y0;
+  if (j == x) dx += 1; else if (i == y) dy += 1;
+  if (dx * dy == 0) { if (lane == 0) D[p] = 0.f; return; }
+  const double dmax = dx > dy ? dx : dy, dmin = dx > dy ? dy : dx;
+  const float axy = A[(long)x * N + y];
+  double a2xy = A2[(long)x * N + y];
+  if (x == i && A[j * N + y] != 0.f) a2xy += A[j * N + y];
+  else if (y == j && A[(long)x * N + i] != 0.f) a2xy += A[(long)x * N + i];
+  const float ajy = A[j * N + y], axi = A[(long)x * N + i];
+  int cnt = 0;
+  float mx = 0.f;
+  for (long z = lane; z < N; z += 64) {
+    float azy = A[z * N + y], axz = A[(long)x * N + z];
+    float a2zy = A2[z * N + y], a2xz = A2[(long)x * N + z];
+    if (z == i && y == j) azy += 1.f;
+    if (x == i && z == j) axz += 1.f;
+    if (z == i && ajy != 0.f) a2zy += ajy;
+    if (x == i && A[j * N + z] != 0.f) a2xz += A[j * N + z];
+    if (y == j && A[z * N + i] != 0.f) a2zy += A[z * N + i];
+    if (z == j && axi != 0.f) a2xz += axi;
+    const float t1 = azy * (a2xz - axz) * axy;          // small integers: exact in fp32
+    const float t2 = axz * (a2zy - azy) * axy;
+    if (t1 > 0.f) { ++cnt; mx = fmaxf(mx, t1); }
+    if (t2 > 0.f) { ++cnt; mx = fmaxf(mx, t2); }
+  }
+  wave_count_max(cnt, mx);
+  if (lane == 0) D[p] = forman_value(dmax, dmin, a2xy, axy, cnt, mx);
+}
+
 static int stats_blocks(int64_t rows, int F, int* active) {
   *active = (ST / F) * F;
   const int64_t n = rows * F;
@@ -449,4 +531,31 @@ extern "C" int hgn_radius_edges_fill(const float* pos, int64_t ld, int d, const 
                      node_type, (long)ldt, (long)N, radius, sender_type, receiver_type, nbr_rowptr, nbr, (int*)nullptr,
                      offsets, senders, receivers);
   return hgn_check_launch("hgn_radius_edges_fill");
+}
+
+extern "C" int hgn_forman_curvature(const float* A, const float* A2, const float* d_in, const float* d_out, int64_t N,
+                                    const int32_t* ei, const int32_t* ej, int64_t nnz, float* C, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N < 0 || nnz < 0 || N > 46340) return hgn_fail(HGN_E_INVALID, "hgn_forman_curvature: bad size (dense N x N, N <= 46340)");
+  if (nnz == 0) return HGN_OK;
+  if (!A || !A2 || !d_in || !d_out || !ei || !ej || !C) return hgn_fail(HGN_E_INVALID, "hgn_forman_curvature: null pointer");
+  ProfScope ps(13, (double)nnz, stream);
+  hipLaunchKernelGGL(forman_curvature_kernel, dim3((unsigned)((nnz + 3) / 4)), dim3(256), 0, stream, A, A2, d_in, d_out, (long)N,
+                     ei, ej, (long)nnz, C);
+  return hgn_check_launch("hgn_forman_curvature");
+}
+
+extern "C" int hgn_forman_post_delta(const float* A, const float* A2, float d_in_x, float d_out_y, int64_t N, int32_t x,
+                                     int32_t y, const int32_t* i_nb, int32_t dim_i, const int32_t* j_nb, int32_t dim_j, float* D,
+                                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N < 1 || N > 46340 || x < 0 || y < 0 || x >= N || y >= N || dim_i < 0 || dim_j < 0)
+    return hgn_fail(HGN_E_INVALID, "hgn_forman_post_delta: bad size / index");
+  if (dim_i == 0 || dim_j == 0) return HGN_OK;
+  if (!A || !A2 || !i_nb || !j_nb || !D) return hgn_fail(HGN_E_INVALID, "hgn_forman_post_delta: null pointer");
+  ProfScope ps(13, (double)dim_i * dim_j, stream);
+  const long pairs = (long)dim_i * dim_j;
+  hipLaunchKernelGGL(forman_post_delta_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, A, A2, d_in_x, d_out_y,
+                     (long)N, x, y, i_nb, dim_i, j_nb, dim_j, D);
+  return hgn_check_launch("hgn_forman_post_delta");
 }

@@ -105,6 +105,10 @@ _SIGS = {
     'hgn_radius_edges_fill': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    'hgn_forman_curvature': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_void_p, C.c_void_p]),
+    'hgn_forman_post_delta': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'hgn_lincomb3': (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int64,
                                C.c_void_p, C.c_void_p]),
     'hgn_prof_enable': (C.c_int, [C.c_int]),

@@ -55,8 +55,9 @@ class AbstractSystemModel(nn.Module):
         self._visualized = False
         self._edge_sets = list(edge_sets)
         if self._balancer:
-            raise NotImplementedError('graph balancers (Ricci / SDRF / random) are outside the accelerated path; a '
-                                      "'balance' edge set built elsewhere can be passed to MeshGraphNet directly")
+            from . import graph_balancer as _gb
+            self._graph_balancer = _gb.get_balancer(params)
+            self._edge_sets.append('balance')
         if self._rmp:
             self._remote_graph = _rmp.get_rmp(params)
             self._edge_sets += self._remote_graph.initialize(
@@ -85,6 +86,10 @@ class AbstractSystemModel(nn.Module):
 
     def expand_graph(self, graph: MultiGraphWithPos, step: int, num_steps: int, is_training: bool) -> MultiGraph:
         """flag.py:130-141 / cylinder.py:108-119."""
+        if self._balancer:
+            if step % math.ceil(num_steps / self._balance_frequency) == 0:
+                self._graph_balancer.reset_balancer()
+            graph = self._graph_balancer.create_graph(graph, self._mesh_edge_normalizer, is_training)
         if self._rmp:
             if step % math.ceil(num_steps / self._rmp_frequency) == 0:
                 self._remote_graph.reset_clusters()

@@ -11,6 +11,7 @@
  *   model/flag.py:68-74, cylinder.py:67-76, plate.py:75-79,186-195
  *                                    velocity + one-hot node features          -> hgn_node_features
  *   model/plate.py:84-110            world edges (cdist + masks + nonzero)      -> hgn_radius_edges_count/_fill
+ *   graph_balancer/ricci.py:128-301  balanced Forman curvature kernels (SDRF)   -> hgn_forman_curvature/_post_delta
  *   model/flag.py:178,188, cylinder.py:163,171  target / integrator arithmetic   -> hgn_lincomb3
  *   migration/normalizer.py:40-71    Normalizer.forward / inverse / _accumulate -> hgn_col_stats,
  *                                                                              hgn_normalizer_update, hgn_normalize
@@ -94,6 +95,20 @@ int hgn_radius_edges_fill(const float* pos, int64_t ld, int d, const int64_t* no
                           float radius, int sender_type, int receiver_type, const int32_t* nbr_rowptr,
                           const int32_t* nbr, const int32_t* offsets, int64_t* senders, int64_t* receivers,
                           void* stream);
+
+/* ---- balanced Forman curvature (graph_balancer/ricci.py:128-301, the two numba-CUDA kernels of SDRF) -------------
+ * Dense fp32 adjacency A [N,N] (row-major, entries 0/1), A2 = A*A [N,N], d_in[i] = column sums, d_out[j] = row sums.
+ * hgn_forman_curvature: C[i,j] for the nnz listed pairs (ei[e], ej[e]) with A != 0; C must be zero-filled by the caller
+ *   (the reference's dense kernel writes 0 for non-edges).  One wavefront per edge sweeps k = 0..N-1 (count and maximum
+ *   of the positive four-cycle terms by wave reduction), then evaluates the closed form in fp64 and rounds to fp32 once per
+ *   store -- the typing of the reference's numba kernel (int literal x float32 -> float64), so equal inputs give equal bits
+ *   and the argmin/argmax ties of SDRF resolve identically.
+ * hgn_forman_post_delta: D[I,J] = curvature of edge (x,y) after inserting (i_nb[I], j_nb[J]); -1000 where i == j or the
+ *   pair is already an edge (ricci.py:206-208); d_in_x = sum A[:,x], d_out_y = sum A[y,:]. */
+int hgn_forman_curvature(const float* A, const float* A2, const float* d_in, const float* d_out, int64_t N,
+                         const int32_t* ei, const int32_t* ej, int64_t nnz, float* C, void* stream);
+int hgn_forman_post_delta(const float* A, const float* A2, float d_in_x, float d_out_y, int64_t N, int32_t x, int32_t y,
+                          const int32_t* i_nb, int32_t dim_i, const int32_t* j_nb, int32_t dim_j, float* D, void* stream);
 
 /* ---- targets and the one-step integrator ---------------------------------------------------------------------
  * out[i] = (ca*a[i] + cb*b[i]) + cc*c[i]   (c nullable), each product and sum rounded separately (no fma), so that

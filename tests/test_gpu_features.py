@@ -447,3 +447,77 @@ def test_cylinder_and_plate_rollout_and_validation_paths_run():
     scripted = pfr[0]['node_type'][:, 0] != 0
     assert torch.equal(ops_['pred_pos'][:, scripted], ptraj['target|world_pos'][:, scripted])
     assert bool(torch.isfinite(ops_['pred_pos']).all())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# graph balancers: balanced Forman curvature kernels, SDRF, random balancing, the 'balance' edge set
+# ----------------------------------------------------------------------------------------------------------------
+def test_forman_curvature_kernels_bit_exact_with_reference_golden():
+    import numpy as np
+    from oracle import balancer_oracle as BO
+    from hgn_amd import graph_balancer as gb
+    fx = torch.load(os.path.join(GOLDEN, 'balancer.pt'), weights_only=False)
+    for c, d in zip(fx['curvature'], fx['post_delta']):
+        A = c['A'].cuda()
+        assert torch.equal(gb.forman_curvature(A).cpu(), c['C']), c['name']
+        D = gb.forman_post_delta(A, d['x'], d['y'], d['x_neighbors'], d['y_neighbors'])
+        assert torch.equal(D.cpu(), d['D']), d['name']
+    # a larger random graph against the oracle (dense numpy restatement)
+    g = torch.Generator().manual_seed(5)
+    n = 150
+    s = torch.randint(0, n, (700,), generator=g)
+    r = (s + 1 + torch.randint(0, n - 1, (700,), generator=g)) % n
+    A = torch.from_numpy(BO.dense_adjacency(s, r))
+    C = gb.forman_curvature(A.cuda()).cpu()
+    assert torch.equal(C, torch.from_numpy(BO.forman_curvature(A.numpy())))
+    ix = int(C.argmin()); x, y = ix // A.shape[0], ix % A.shape[0]
+    xn = torch.nonzero(A[x]).flatten().tolist() + [x]
+    yn = torch.nonzero(A[y]).flatten().tolist() + [y]
+    D = gb.forman_post_delta(A.cuda(), x, y, xn, yn).cpu()
+    assert torch.equal(D, torch.from_numpy(BO.post_delta(A.numpy(), x, y, xn, yn)))
+
+
+def test_sdrf_reproduces_reference_trajectories():
+    import numpy as np
+    from hgn_amd import graph_balancer as gb
+    fx = torch.load(os.path.join(GOLDEN, 'balancer.pt'), weights_only=False)
+    graphs = {c['name']: c['edge_index'] for c in fx['curvature']}
+    for s in fx['sdrf']:
+        ei = graphs[s['name']]
+        np.random.seed(s['seed'])
+        added, removed = gb.sdrf(ei[0].cuda(), ei[1].cuda(), int(ei.max()) + 1, loops=s['loops'],
+                                 remove_edges=s['remove_edges'], tau=s['tau'])
+        assert added == {k: [int(v) for v in vs] for k, vs in s['added'].items()}, s['name']
+        assert removed == {k: [int(v) for v in vs] for k, vs in s['removed'].items()}, s['name']
+
+
+@pytest.mark.parametrize('alg', ['random', 'ricci'])
+def test_flag_model_with_graph_balancer_matches_reference_golden(alg):
+    import numpy as np
+    from hgn_amd import system_model
+    fx = torch.load(os.path.join(GOLDEN, 'balancer.pt'), weights_only=False)
+    case = [c for c in fx['flag'] if c['algorithm'] == alg][0]
+    params = flag_params()
+    params['graph_balancer'] = {k: (dict(v) if isinstance(v, dict) else v) for k, v in case['config']['graph_balancer'].items()}
+    model = system_model.FlagModel(params)
+    assert model._edge_sets == ['mesh_edges', 'balance']
+    np.random.seed(case['np_seed'])
+    ff64 = FO.FlagFeatures(dtype=torch.float64)
+    from oracle import balancer_oracle as BO
+    for i, fr in enumerate(case['frames']):
+        g = model.build_graph(cuda_frame(fr), True)
+        ex = model.expand_graph(g, i, 2, True)
+        ref = case['edge_sets'][i]
+        o64 = ff64.build_graph(fr, True)
+        bal = model._graph_balancer._balancer
+        mask = bal._mask.cpu() if bal._mask is not None else None
+        sets64 = BO.apply_balancer(o64, bal._added_edges, mask, ff64.mesh_edge, True)
+        assert [e.name for e in ex.edge_sets] == [e['name'] for e in ref]
+        for a, b, c in zip(ex.edge_sets, ref, sets64):
+            assert torch.equal(a.senders.cpu(), b['senders']) and torch.equal(a.receivers.cpu(), b['receivers']), a.name
+            assert rel_err(a.features, c.features) <= max(TOL, 3.0 * rel_err(b['features'], c.features)), a.name
+        if i == 0:
+            assert [int(v) for v in bal._added_edges['senders']] == [int(v) for v in case['added']['senders']]
+            assert torch.equal(bal._mask.cpu(), case['mask'])
+        out = model(ex)
+        assert out.shape == (fr['world_pos'].shape[0], 3) and bool(torch.isfinite(out).all())
