@@ -43,13 +43,60 @@ class AbstractClusteringAlgorithm:
 
     def run(self, graph: MultiGraphWithPos, number=0, b4=True) -> List[Tensor]:
         """abstract_clustering_algorithm.py:59-84."""
-        if self._sampling:
-            raise NotImplementedError('intra_cluster_sampling is not part of the accelerated path '
-                                      '(configs ship it disabled: flag.yaml:42-45)')
         labels = self._empty_cluster_handling([int(x) for x in self._cluster(graph)])
         self._labels = [-1] * number + labels if b4 else labels + [-1] * number
         self.neigboring_clusters = self.get_neigbors(graph, self._labels)
-        return self._labels_to_indices(labels)
+        if not self._sampling:
+            return self._labels_to_indices(labels)
+        spotter = self.spotter(graph, labels, self._alpha, self._threshold)
+        exemplars = self.exemplars(labels, spotter, self._alpha)
+        top_k = self.highest_dynamics(graph, labels, self._alpha)
+        return self._combine_samples(spotter, exemplars, top_k)
+
+    # ---- intra-cluster sampling (abstract_clustering_algorithm.py:148-229): which members of a cluster talk to its hyper
+    # node.  Host logic on Python lists / sets with the `random` module, like the reference (its list and set orders decide
+    # the order of the intra-cluster edges, so the same constructs are used); once per trajectory.
+    def _reduce_samples(self, groups: List[List[int]], alpha: float, shuffle: bool) -> List[List[int]]:
+        out = []
+        for members in groups:
+            if shuffle:
+                random.shuffle(members)
+            keep = min(len(members), max(int(alpha * 100), int(len(members) * alpha)))
+            out.append(members[:keep])
+        return out
+
+    def spotter(self, graph: MultiGraphWithPos, labels: Sequence[int], alpha: float, threshold: int) -> List[List[int]]:
+        """Border nodes: endpoints of mesh edges that cross clusters, kept if they occur at least `threshold` times."""
+        es = [x for x in graph.edge_sets if x.name == 'mesh_edges'][0]
+        lab = np.asarray(labels)
+        snd, rcv = es.senders.cpu().numpy(), es.receivers.cpu().numpy()
+        cross = np.nonzero(lab[snd] != lab[rcv])[0]
+        groups = [[] for _ in range(self._num_clusters)]
+        for e in cross.tolist():                                   # edge order, sender before receiver
+            groups[int(lab[snd[e]])].append(int(snd[e]))
+            groups[int(lab[rcv[e]])].append(int(rcv[e]))
+        groups = [[x for x in set(g) if g.count(x) >= threshold] for g in groups]
+        return self._reduce_samples(groups, alpha, True)
+
+    def exemplars(self, labels: Sequence[int], spotter: List[List[int]], alpha: float) -> List[List[int]]:
+        """Interior nodes: members of a cluster that were not picked as border nodes."""
+        groups = [[] for _ in range(self._num_clusters)]
+        for node, c in enumerate(labels):
+            if node not in spotter[c]:
+                groups[c].append(node)
+        return self._reduce_samples(groups, alpha, True)
+
+    def highest_dynamics(self, graph: MultiGraphWithPos, labels: Sequence[int], alpha: float) -> List[List[int]]:
+        """Members with the largest node dynamics (max - min incident edge length, flag.py:100-115)."""
+        dyn = graph.node_dynamic.detach().cpu()
+        groups = [[] for _ in range(self._num_clusters)]
+        for node, c in enumerate(labels):
+            groups[c].append(node)
+        groups = [sorted(g, key=lambda n: dyn[n], reverse=True) for g in groups]
+        return self._reduce_samples(groups, alpha, False)
+
+    def _combine_samples(self, spotter, exemplars, top_k) -> List[Tensor]:
+        return [torch.tensor(list(set(spotter[i] + exemplars[i] + top_k[i]))) for i in range(self._num_clusters)]
 
     def _empty_cluster_handling(self, labels: List[int]) -> List[int]:
         """abstract_clustering_algorithm.py:91-102: an empty cluster steals a random node of a non-empty one."""

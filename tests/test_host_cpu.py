@@ -281,3 +281,22 @@ def test_abi_radius_edges_validation():
     tot = C.c_int64(0)
     assert lib.hgn_radius_edges_count(None, 3, 5, None, 1, 10, 0.03, 1, 0, None, None, None, C.byref(tot), None, 0, None) == -1
     assert lib.hgn_radius_edges_fill(None, 3, 3, None, 1, 10, 0.03, 1, 0, None, None, None, None, None, None) == -1
+
+
+def test_intra_cluster_sampling_matches_reference_clusters():
+    """Spotter / exemplars / highest-dynamics sampling (host logic with the `random` module): same sampled cluster members,
+    in the same order, as the reference produced under random.seed(0) (tests/golden/feat_flag_hyper_k4_sampled.pt)."""
+    import random
+    from hgn_amd import rmp, util
+    fx = torch.load(os.path.join(ROOT, 'tests', 'golden', 'feat_flag_hyper_k4_sampled.pt'), weights_only=False)
+    fr, ex, ref = fx['frames'][0], fx['expanded'][0], fx['graphs'][0]
+    es = ref['edge_sets'][0]
+    g = util.MultiGraphWithPos(node_features=ref['node_features'][0],
+                               edge_sets=[util.EdgeSet('mesh_edges', es['features'], es['senders'], es['receivers'])],
+                               target_feature=fr['world_pos'], mesh_features=fr['mesh_pos'], model_type='flag',
+                               node_dynamic=ref['node_dynamic'], unnormalized_edges=None, obstacle_nodes=None)
+    random.seed(0)
+    alg = rmp.KMeansClustering(4, True, 0.1, 0)
+    clusters = alg.run(g)
+    assert [c.tolist() for c in clusters] == [c.tolist() for c in ex['clusters']]
+    assert sum(len(c) for c in clusters) < 168                     # a strict subset of the nodes is connected upwards

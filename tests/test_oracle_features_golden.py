@@ -28,7 +28,7 @@ def test_cells_to_edges_bit_exact():
         assert torch.equal(s, fx[nm]['senders']) and torch.equal(r, fx[nm]['receivers'])
 
 
-@pytest.mark.parametrize('name', ['flag_none', 'flag_hyper_k5', 'flag_hyper_k3_full'])
+@pytest.mark.parametrize('name', ['flag_none', 'flag_hyper_k5', 'flag_hyper_k3_full', 'flag_hyper_k4_sampled'])
 def test_flag_build_graph_and_expand(name):
     fx = load(name)
     cfg = fx['config']
