@@ -293,6 +293,33 @@ class HierarchicalConnector(AbstractConnector):
         return MultiGraph(node_features=[nf, nf_means.contiguous()], edge_sets=edge_sets)
 
 
+class MultigraphConnector(HierarchicalConnector):
+    """multigraph_connector.py:11-89: the hierarchical expansion folded into ONE edge set -- node rows get a 2-way and edge
+    rows a 4-way one-hot tag (mesh / inter-cluster / to-cluster / to-mesh) and all remote edges are appended to
+    'mesh_edges'; 'world_edges' passes through.  Pure data movement on top of HierarchicalConnector.run."""
+
+    def initialize(self, intra, inter, hyper):
+        AbstractConnector.initialize(self, intra, inter, hyper)
+        return []
+
+    def run(self, graph, clusters, neighbors, is_training, noise=None) -> MultiGraph:
+        g = super().run(graph, clusters, neighbors, is_training, noise)
+        nf, hnf = g.node_features
+
+        def tag(x, k, n):
+            t = torch.zeros(x.shape[0], n, dtype=x.dtype, device=x.device)
+            t[:, k] = 1
+            return torch.cat((x, t), dim=1)
+        by_name = {e.name: e for e in g.edge_sets}
+        order = ('mesh_edges', 'inter_cluster', 'intra_cluster_to_cluster', 'intra_cluster_to_mesh')
+        parts = [by_name[n] for n in order]
+        merged = EdgeSet(name='mesh_edges',
+                         features=torch.cat([tag(e.features, k, 4) for k, e in enumerate(parts)], dim=0),
+                         senders=torch.cat([e.senders.to(device) for e in parts], dim=0),
+                         receivers=torch.cat([e.receivers.to(device) for e in parts], dim=0))
+        return MultiGraph(node_features=[tag(nf, 0, 2), tag(hnf, 1, 2)], edge_sets=[merged, by_name['world_edges']])
+
+
 class RemoteMessagePassing:
     """remote_message_passing.py:11-150."""
 
@@ -363,6 +390,8 @@ def get_rmp(config) -> RemoteMessagePassing:
     noise = None if rmp['hyper_noise'] == 'none' else rmp['hyper_noise']
     if connector in ('hyper', 'hetero', 'multiscale'):
         conn = HierarchicalConnector(rmp['fully_connect'], noise, rmp['hyper_node_features'])
+    elif connector == 'multi':
+        conn = MultigraphConnector(rmp['fully_connect'], noise, rmp['hyper_node_features'])
     elif connector in ('none', 'repeated'):
         conn = None
     else:

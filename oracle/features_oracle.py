@@ -253,3 +253,20 @@ def hierarchical_connect(graph: dict, clusters: Sequence[torch.Tensor], neighbor
     s2, r2, f = sub(s, r)
     e_inter = EdgeSet('inter_cluster', inter(f, is_training), s2, r2)             # :134-138
     return MultiGraph([nf, nf_means], list(graph['edge_sets']) + [e_cluster, e_mesh, e_inter])
+
+
+def multigraph_connect(graph: dict, clusters, neighbors, intra: Normalizer, inter: Normalizer, hyper: Normalizer,
+                       is_training: bool, hyper_node_features: bool = False) -> MultiGraph:
+    """multigraph_connector.py:23-86: hierarchical expansion, then one-hot tags and everything merged into 'mesh_edges'."""
+    g = hierarchical_connect(graph, clusters, neighbors, intra, inter, hyper, is_training, hyper_node_features)
+    nf, hnf = g.node_features
+
+    def tag(x, k, n):
+        t = torch.zeros(x.shape[0], n, dtype=x.dtype)
+        t[:, k] = 1
+        return torch.cat((x, t), 1)
+    by = {e.name: e for e in g.edge_sets}
+    parts = [by[n] for n in ('mesh_edges', 'inter_cluster', 'intra_cluster_to_cluster', 'intra_cluster_to_mesh')]
+    merged = EdgeSet('mesh_edges', torch.cat([tag(e.features, k, 4) for k, e in enumerate(parts)]),
+                     torch.cat([e.senders for e in parts]), torch.cat([e.receivers for e in parts]))
+    return MultiGraph([tag(nf, 0, 2), tag(hnf, 1, 2)], [merged, by['world_edges']])

@@ -524,3 +524,34 @@ def test_flag_model_with_graph_balancer_matches_reference_golden(alg):
             assert torch.equal(bal._mask.cpu(), case['mask'])
         out = model(ex)
         assert out.shape == (fr['world_pos'].shape[0], 3) and bool(torch.isfinite(out).all())
+
+
+def test_plate_multigraph_connector_matches_reference_golden():
+    from hgn_amd import system_model
+    fx = load('plate_multi_k4_first')
+    p = plate_params('multi', 4)
+    p['rmp']['hyper_node_features'] = False                  # the 'multi' encoder shares one node MLP: widths must agree
+    model = system_model.PlateModel(p)
+    assert model._edge_sets == ['mesh_edges', 'world_edges'] and model._architecture == 'multi'
+    pf64 = FO.PlateFeatures(dtype=torch.float64)
+    for i, fr in enumerate(fx['frames']):
+        g = model.build_graph(cuda_frame(fr), i < 1)
+        mg = model.expand_graph(g, i, 2, i < 1)
+        ex = fx['expanded'][i]
+        rmp = model._remote_graph
+        assert all(torch.equal(a.cpu(), b) for a, b in zip(rmp._clusters, ex['clusters']))
+        o64 = pf64.build_graph(fr, i < 1)
+        m64 = FO.multigraph_connect(o64, rmp._clusters, [tuple(t.tolist()) for t in rmp._neighbors], pf64.intra_edge,
+                                    pf64.inter_edge, pf64.hyper_node, i < 1)
+        assert [x.name for x in mg.edge_sets] == ['mesh_edges', 'world_edges']
+        assert mg.edge_sets[0].features.shape == ex['edge_sets'][0]['features'].shape
+        for a, c in zip(mg.edge_sets, m64.edge_sets):
+            assert torch.equal(a.senders.cpu(), c.senders) and torch.equal(a.receivers.cpu(), c.receivers)
+            assert rel_err(a.features, c.features) <= 5e-5
+        # mesh / to-cluster / to-mesh rows line up with the reference one to one (inter-cluster rows: same set, set order)
+        n_same = fx['graphs'][i]['edge_sets'][0]['senders'].shape[0]
+        assert torch.equal(mg.edge_sets[0].senders[:n_same].cpu(), ex['edge_sets'][0]['senders'][:n_same])
+        for a, c in zip(mg.node_features, m64.node_features):
+            assert rel_err(a, c) <= 5e-5
+        out = model(mg)
+        assert out.shape == (fr['world_pos'].shape[0], 3) and bool(torch.isfinite(out).all())

@@ -116,3 +116,19 @@ def test_plate_build_graph_and_expand(name):
             for a, b in zip(mg.node_features, ex['node_features']):
                 torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(pf.update(fx['frames'][0], fx['net_out']), fx['update'], **TOL)
+
+
+def test_plate_multigraph_connector():
+    fx = load('plate_multi_k4_first')
+    pf = FO.PlateFeatures()
+    for i, fr in enumerate(fx['frames']):
+        g = pf.build_graph(fr, i < 1)
+        ex = fx['expanded'][i]
+        mg = FO.multigraph_connect(g, ex['clusters'], [tuple(t.tolist()) for t in ex['neighbors']], pf.intra_edge,
+                                   pf.inter_edge, pf.hyper_node, i < 1)
+        assert [x.name for x in mg.edge_sets] == [x['name'] for x in ex['edge_sets']] == ['mesh_edges', 'world_edges']
+        for a, b in zip(mg.edge_sets, ex['edge_sets']):
+            assert torch.equal(a.senders, b['senders']) and torch.equal(a.receivers, b['receivers'])
+            torch.testing.assert_close(a.features, b['features'], rtol=1e-4, atol=1e-4)
+        for a, b in zip(mg.node_features, ex['node_features']):
+            torch.testing.assert_close(a, b.float(), rtol=1e-4, atol=1e-4)
