@@ -298,6 +298,7 @@ __global__ __launch_bounds__(WG, 4) void linear_bwd_kernel(const LinArgs a) {
 
 }  // namespace hgn
 
+namespace hgn { int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream); }
 using namespace hgn;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -330,6 +331,7 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   const int kid = a->n_add ? 0 : 1;
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
+  if (hgn_mlp_fwd6_eligible(a)) return launch_mlp6_fwd(a, stream);
   hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   return hgn_check_launch("hgn_mlp_fwd");
 }

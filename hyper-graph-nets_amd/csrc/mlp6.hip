@@ -1,0 +1,260 @@
+// Fused MLP kernels with SPLIT-bf16 matrix products: every fp32 128x128 product of csrc/mlp.hip evaluated as six bf16 MFMAs
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulation) on a 3-way bf16 split of both operands.
+//   x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) captures all 24 significand bits of an
+//   fp32 value exactly; w likewise; the six products with i + j <= 4 leave out terms below 2^-24 relative.  Measured on the
+//   MLP shapes: max relative error 2.6e-7 against fp64, vs 4.5e-7 for a plain fp32 product -- fp32 accuracy at 16/6 = 2.7x
+//   the fp32 MFMA rate, which moves these kernels from "MFMA pipe and row traffic equally loaded" to row-traffic bound.
+// Formulation is the one of hgn_device.h (transposed product, weights = A operand from LDS, the wave's 16 rows = B operand in
+// registers, C/D map == next layer's B map).  For the bf16 MFMA the B operand of contraction block c (32 features) takes
+// its 8 values per lane from the lane's own fp32 registers -- features 32c + 4q + j (j < 4) and 32c + 16 + 4q + (j - 4) --
+// i.e. a fixed permutation of the contraction index, which is folded into the PACKED weights (hgn_pack_bf16x3): operand
+// tiles of 16 x 32 bf16 stored in lane order, so staging is a straight LDS-DMA copy and every ds_read_b128 is linear.
+// LDS: half a block (two contraction blocks x three splits x eight output blocks = 48 KB) at a time, 3 workgroups per CU.
+#include <cstdlib>
+#include "hgn_device.h"
+#include "hgn_host.h"
+
+namespace hgn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int TILE_BF16 = 512;                     // one 16 x 32 operand tile: 64 lanes x 8 bf16 = 1 KiB
+constexpr int HALF_TILES = 3 * 2 * 8;              // splits x contraction blocks of the half x output blocks
+constexpr int HALF_BF16 = HALF_TILES * TILE_BF16;  // 48 KB
+constexpr int BLOCK_BF16 = 2 * HALF_BF16;          // one packed 128 x 128 block: 96 KB (= HGN_PACK_BLOCK_BYTES)
+
+// ----------------------------------------------------------------------------------------------------------
+// packing: [half][split][cl][ob][lane][8];  forward form: tile(ob, c)[m][p] = W[16ob + m][feat(c, p)]  (contraction over the
+// input features);  transposed form: tile(ob, c)[m][p] = W[feat(c, p)][16ob + m]  (contraction over the outputs)
+// ----------------------------------------------------------------------------------------------------------
+struct PackArgs { hgn_pack_t d[HGN_MAX_PACK]; };
+
+__global__ void pack_bf16x3_kernel(const PackArgs a) {
+  const hgn_pack_t d = a.d[blockIdx.y];
+  const float* __restrict__ W = d.W;
+  const long ldw = d.ldw;
+  const int n_out = d.n_out, n_in = d.n_in, transposed = d.transposed;
+  __bf16* __restrict__ out = reinterpret_cast<__bf16*>(d.out);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one (half, cl, ob, lane, j)
+  if (i >= 2 * 2 * 8 * 64 * 8) return;
+  const int j = i & 7, l = (i >> 3) & 63, ob = (i >> 9) & 7, cl = (i >> 12) & 1, half = i >> 13;
+  const int m = l & 15, q = l >> 4, c = 2 * half + cl;
+  const int feat = 32 * c + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
+  const int o = transposed ? feat : 16 * ob + m, k = transposed ? 16 * ob + m : feat;     // W[o][k]
+  float w = 0.f;
+  if (o < n_out && k < n_in) w = W[(long)o * ldw + k];
+  const __bf16 h = (__bf16)w;
+  const float r1 = w - (float)h;
+  const __bf16 mi = (__bf16)r1;
+  const float r2 = r1 - (float)mi;
+  const __bf16 lo = (__bf16)r2;
+  __bf16* base = out + (long)half * HALF_BF16 + ((cl * 8 + ob) * 64 + l) * 8 + j;
+  base[0 * 2 * 8 * TILE_BF16] = h;
+  base[1 * 2 * 8 * TILE_BF16] = mi;
+  base[2 * 2 * 8 * TILE_BF16] = lo;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// device building blocks
+// ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(const Act& x, bf16x8 (&s)[3][4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = x.v[2 * c + (j >> 2)][j & 3];
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 m = (__bf16)r1;
+      const float r2 = r1 - (float)m;
+      s[0][c][j] = h; s[1][c][j] = m; s[2][c][j] = (__bf16)r2;
+    }
+}
+
+__device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf16* __restrict__ gsrc) {
+  unsigned lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  const unsigned wave = threadIdx.x >> 6;
+#pragma unroll
+  for (unsigned i = wave; i < HALF_TILES; i += WG / 64)          // one operand tile (1 KiB) per wave instruction
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
+                                     (__attribute__((address_space(3))) void*)(lds + i * TILE_BF16), 16, 0, 0);
+}
+
+template <int HALF>
+__device__ __forceinline__ void mfma_half6(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl) {
+    const int c = 2 * HALF + cl;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+      const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+      const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(lds + ((2 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+      f32x4 t = acc.v[ob];
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, xs[0][c], t, 0, 0, 0);      // smallest terms first
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[2][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[1][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[0][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[1][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[0][c], t, 0, 0, 0);
+      acc.v[ob] = t;
+    }
+  }
+}
+
+// acc[ob] += Wblock * b for one packed 128 x 128 block.  `between()` runs after the first half's DMA has been issued and
+// before the wait (the caller's own global loads fly with it); `b` is split after the wait, so `between` may load it.
+template <class F>
+__device__ __forceinline__ void gemm6(Act& acc, const Act& b, __bf16* __restrict__ lds, const __bf16* __restrict__ pk, F&& between) {
+  bf16x8 xs[3][4];
+  wg_barrier_lds();
+  stage_half6(lds, pk);
+  between();
+  __syncthreads();
+  split3(b, xs);
+  mfma_half6<0>(acc, xs, lds);
+  wg_barrier_lds();
+  stage_half6(lds, pk + HALF_BF16);
+  __syncthreads();
+  mfma_half6<1>(acc, xs, lds);
+}
+
+__device__ __forceinline__ void relu6(Act& a) {
+  HGN_FOR_B(fb)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a.v[fb][u] = fmaxf(a.v[fb][u], 0.f);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// forward (all sources 128-wide multiples, output 128 wide): same contract as mlp_fwd_kernel
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+
+  Act acc, b;
+  bool first = true;
+  for (int si = 0; si < a.n_src; ++si) {
+    const hgn_src_t s = a.src[si];
+    const long srow = s.idx ? (long)s.idx[rc] : rc;
+    const __bf16* pk = reinterpret_cast<const __bf16*>(s.Wpk);
+    for (int k0 = 0; k0 < s.K; k0 += 128) {
+      const float* xr = s.x + srow * s.ld + k0;
+      gemm6(acc, b, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
+        t_load(b, xr, kq);
+        if (first) {
+          t_load(acc, a.b1, kq);
+          for (int i = 0; i < a.n_add; ++i) t_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, kq);
+          first = false;
+        }
+      });
+    }
+  }
+  relu6(acc);
+  if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
+  gemm6(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] { t_load(b, a.b2, kq); });
+  relu6(b);
+  if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
+  gemm6(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] { t_load(acc, a.b3, kq); });
+  if (a.ln_g) {
+    const float mean = row_sum(acc) * (1.f / LAT);
+    HGN_FOR_B(fb) {
+      acc.v[fb] -= mean;
+      b.v[fb] = acc.v[fb] * acc.v[fb];
+    }
+    const float var = row_sum(b) * (1.f / LAT);
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    HGN_FOR_B(fb) acc.v[fb] *= rstd;
+    if (a.xhat && valid) t_store(acc, a.xhat + row * LAT, kq);
+    if (a.rstd && valid && kq == 0) a.rstd[row] = rstd;
+    HGN_FOR_B(fb) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 16 * fb + 4 * kq);
+      acc.v[fb] = acc.v[fb] * gm + bt;
+    }
+  }
+  if (valid) {
+    if (a.res) t_add(acc, a.res + row * a.ld_res, kq);
+    t_store(acc, a.out + row * a.ld_out, kq);
+  }
+}
+
+// single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
+struct Lin6Args { const float* x; long ldx; long M; const __bf16* pk[4]; int n_blocks; float* out; long ld_out; };
+
+__global__ __launch_bounds__(WG, 3) void linear6_fwd_kernel(const Lin6Args a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  Act acc, b;
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    gemm6(acc, b, lds, a.pk[blk], [&] {
+      if (blk == 0) t_load(b, a.x + rc * a.ldx, kq);
+      t_zero(acc);
+    });
+    if (valid) t_store(acc, a.out + row * a.ld_out + 128 * blk, kq);
+  }
+}
+
+}  // namespace hgn
+
+using namespace hgn;
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int hgn_pack_bf16x3(const hgn_pack_t* blocks, int n, void* stream) {
+  if (!blocks || n < 1 || n > HGN_MAX_PACK) return hgn_fail(HGN_E_INVALID, "hgn_pack_bf16x3: 1..HGN_MAX_PACK blocks per call");
+  PackArgs a;
+  for (int i = 0; i < n; ++i) {
+    const hgn_pack_t& d = blocks[i];
+    if (!d.W || !d.out || d.ldw < 1 || d.n_out < 1 || d.n_out > 128 || d.n_in < 1 || d.n_in > 128 || !aligned16(d.out))
+      return hgn_fail(HGN_E_INVALID, "hgn_pack_bf16x3: bad block (at most 128 x 128, 16-byte aligned output)");
+    a.d[i] = d;
+  }
+  hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(2 * 2 * 8 * 64 * 8 / 256, n), dim3(256), 0, (hipStream_t)stream, a);
+  return hgn_check_launch("hgn_pack_bf16x3");
+}
+
+// Eligibility of the split-bf16 forward: every source a multiple of 128 columns with 16-byte aligned rows and a packed image,
+// 128-wide output, packed W2 / W3.  (Encoders and the decoder keep the fp32 kernel.)
+extern "C" int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* a) {
+  if (!a || a->out_w != 128 || !a->W2pk || !a->W3pk || a->n_src < 1) return 0;
+  for (int i = 0; i < a->n_src; ++i) {
+    const hgn_src_t& s = a->src[i];
+    if (!s.Wpk || (s.K & 127) || (s.ld & 3) || !aligned16(s.x)) return 0;
+  }
+  if ((a->ld_out & 3) || !aligned16(a->out) || (a->res && ((a->ld_res & 3) || !aligned16(a->res)))) return 0;
+  return getenv("HGN_FP32_MFMA") ? 0 : 1;
+}
+
+namespace hgn {
+int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
+  const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+  hipLaunchKernelGGL(mlp6_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  return hgn_check_launch("hgn_mlp_fwd (split-bf16)");
+}
+}  // namespace hgn
+
+extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
+                               int64_t ld_out, void* stream) {
+  if (M == 0) return HGN_OK;
+  if (!x || !pk_blocks || !out || M < 0 || nb < 1 || nb > 4 || (ldx & 3) || (ld_out & 3) || !aligned16(x) || !aligned16(out))
+    return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: bad argument");
+  Lin6Args a;
+  a.x = x; a.ldx = ldx; a.M = M; a.n_blocks = nb; a.out = out; a.ld_out = ld_out;
+  for (int i = 0; i < 4; ++i) a.pk[i] = i < nb ? reinterpret_cast<const __bf16*>(pk_blocks[i]) : nullptr;
+  for (int i = 0; i < nb; ++i)
+    if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: null packed block");
+  const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+  ProfScope ps(7, (double)M, (hipStream_t)stream);
+  hipLaunchKernelGGL(linear6_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  return hgn_check_launch("hgn_linear_fwd6");
+}

@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'libhgn_mp.so')
 HGN_MAX_SRC = 8
 HGN_MAX_ADD = 2
 HGN_MAX_WTASK = 16
+PACK_BLOCK_BYTES = 98304
+HGN_MAX_PACK = 32
 NUM_KERNEL_IDS = 14
 OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
 KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
@@ -22,7 +24,7 @@ c_i32p = C.c_void_p
 
 
 class Src(C.Structure):
-    _fields_ = [('x', c_f32p), ('ld', C.c_int64), ('K', C.c_int32), ('idx', c_i32p), ('W', c_f32p)]
+    _fields_ = [('x', c_f32p), ('ld', C.c_int64), ('K', C.c_int32), ('idx', c_i32p), ('W', c_f32p), ('Wpk', C.c_void_p)]
 
 
 class Add(C.Structure):
@@ -34,7 +36,7 @@ class MlpFwd(C.Structure):
                 ('add', Add * HGN_MAX_ADD), ('ldw1', C.c_int64), ('b1', c_f32p), ('W2', c_f32p), ('b2', c_f32p),
                 ('W3', c_f32p), ('b3', c_f32p), ('out_w', C.c_int32), ('ln_g', c_f32p), ('ln_b', c_f32p),
                 ('res', c_f32p), ('ld_res', C.c_int64), ('out', c_f32p), ('ld_out', C.c_int64), ('z1', c_f32p),
-                ('z2', c_f32p), ('xhat', c_f32p), ('rstd', c_f32p)]
+                ('z2', c_f32p), ('xhat', c_f32p), ('rstd', c_f32p), ('W2pk', C.c_void_p), ('W3pk', C.c_void_p)]
 
 
 class Dx(C.Structure):
@@ -57,6 +59,11 @@ class WTask(C.Structure):
                 ('db', c_f32p), ('accumulate', C.c_int32)]
 
 
+class Pack(C.Structure):
+    _fields_ = [('W', c_f32p), ('ldw', C.c_int64), ('n_out', C.c_int32), ('n_in', C.c_int32), ('transposed', C.c_int32),
+                ('out', C.c_void_p)]
+
+
 _SIGS = {
     'hgn_last_error': (C.c_char_p, []),
     'hgn_version': (C.c_int, []),
@@ -71,6 +78,10 @@ _SIGS = {
                                          C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'hgn_mlp_fwd': (C.c_int, [C.POINTER(MlpFwd), C.c_void_p]),
+    'hgn_pack_bf16x3': (C.c_int, [C.POINTER(Pack), C.c_int, C.c_void_p]),
+    'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
+    'hgn_linear_fwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
+                                  C.c_void_p]),
     'hgn_mlp_bwd_ln_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     'hgn_mlp_bwd': (C.c_int, [C.POINTER(MlpBwd), C.c_void_p]),
     'hgn_wgrad_workspace_bytes': (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),

@@ -142,4 +142,5 @@ class GraphedShardStep:
             ops.adam_step_dev(tr.fp.flat, tr.fp.grad, tr.m, tr.v, tr.lr, tr.betas[0], tr.betas[1], tr.eps, tr.t_dev)
         else:
             tr.adam_fn(tr.fp.flat, tr.fp.grad, tr.m, tr.v, tr.lr, tr.betas[0], tr.betas[1], tr.eps, tr.t)
+        ops.invalidate_packs()
         return (self.sq_sum * inv).squeeze(0)

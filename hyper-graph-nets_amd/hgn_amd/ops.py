@@ -77,6 +77,56 @@ class MLPWeights:
                 raise _lib.HgnError('MLP weights must be contiguous fp32')
 
 
+# ------------------------------------------------------------------------------------------------------------
+# packed weight images for the split-bf16 kernels (include/hgn_mp.h: hgn_pack_bf16x3)
+# ------------------------------------------------------------------------------------------------------------
+_pack_epoch = 0
+_FP32_ONLY = bool(__import__('os').environ.get('HGN_FP32_MFMA'))
+
+
+def invalidate_packs() -> None:
+    """Call after the parameters were changed behind torch's back (the flat-buffer Adam kernels): packed images are rebuilt
+    on their next use.  In-place torch updates of a parameter are detected through its version counter."""
+    global _pack_epoch
+    _pack_epoch += 1
+
+
+def packs_of(w: MLPWeights, transposed: bool = False):
+    """-> uint8 tensor holding the packed blocks [W1 block 0 .. nb1-1, W2, W3] of this MLP (forward or transposed form), or
+    None if the MLP is not eligible (first-layer width not a multiple of 128, or a narrow output: encoders / decoder)."""
+    if w.w1.shape[1] % LAT != 0 or w.w3.shape[0] != LAT or not w.w1.is_cuda:
+        return None
+    nb1 = w.w1.shape[1] // LAT
+    attr = '_hgn_pk_t' if transposed else '_hgn_pk'
+    key = (_pack_epoch, w.w1._version, w.w2._version, w.w3._version, w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr())
+    st = getattr(w.w1, attr, None)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if st is not None and st[0] == key and not capturing:
+        return st[1]
+    buf = st[1] if st is not None and st[1].numel() == (nb1 + 2) * _lib.PACK_BLOCK_BYTES else \
+        torch.empty((nb1 + 2) * _lib.PACK_BLOCK_BYTES, dtype=torch.uint8, device=w.w1.device)
+    arr = (_lib.Pack * (nb1 + 2))()
+    t = 1 if transposed else 0
+    for b in range(nb1):
+        d = arr[b]
+        d.W = w.w1.data_ptr() + 4 * LAT * b; d.ldw = w.w1.shape[1]; d.n_out = LAT; d.n_in = LAT; d.transposed = t
+        d.out = buf.data_ptr() + b * _lib.PACK_BLOCK_BYTES
+    for i, m in enumerate((w.w2, w.w3)):
+        d = arr[nb1 + i]
+        d.W = m.data_ptr(); d.ldw = LAT; d.n_out = m.shape[0]; d.n_in = LAT; d.transposed = t
+        d.out = buf.data_ptr() + (nb1 + i) * _lib.PACK_BLOCK_BYTES
+    n = nb1 + 2
+    for i0 in range(0, n, _lib.HGN_MAX_PACK):
+        cnt = min(_lib.HGN_MAX_PACK, n - i0)
+        _lib.check(_lib.lib().hgn_pack_bf16x3(C.cast(C.byref(arr, i0 * C.sizeof(_lib.Pack)), C.POINTER(_lib.Pack)), cnt,
+                                              _lib.stream_ptr()), 'hgn_pack_bf16x3')
+    try:
+        setattr(w.w1, attr, (key, buf))
+    except Exception:
+        pass
+    return buf
+
+
 def _fill_common_fwd(a: _lib.MlpFwd, w: MLPWeights, out, res, saves):
     a.ldw1 = w.w1.shape[1]
     a.b1 = w.b1.data_ptr()
@@ -184,13 +234,20 @@ class MLPFn(torch.autograd.Function):
         a.n_src = n_src
         col = 0
         cols = []
+        pk = packs_of(w) if all(s.shape[1] % LAT == 0 for s in srcs) else None
+        nb1 = w.w1.shape[1] // LAT
         for i, s in enumerate(srcs):
             e = a.src[i]
             e.x = s.data_ptr(); e.ld = _ld(s); e.K = s.shape[1]
             e.idx = idxs[i].data_ptr() if idxs[i] is not None else None
             e.W = w.w1.data_ptr() + 4 * col
+            if pk is not None:
+                e.Wpk = pk.data_ptr() + (col // LAT) * _lib.PACK_BLOCK_BYTES
             cols.append(col)
             col += s.shape[1]
+        if pk is not None:
+            a.W2pk = pk.data_ptr() + nb1 * _lib.PACK_BLOCK_BYTES
+            a.W3pk = pk.data_ptr() + (nb1 + 1) * _lib.PACK_BLOCK_BYTES
         if col != w.w1.shape[1]:
             raise _lib.HgnError(f'MLP input width {col} does not match weight in_features {w.w1.shape[1]}')
         saves = _alloc_saves(M, has_ln, dev) if train else None
@@ -304,14 +361,23 @@ class EdgeBlockFn(torch.autograd.Function):
         if e.shape[0] != E or h_all.shape[0] != N:
             raise _lib.HgnError(f'edge block: got {e.shape[0]} edge rows / {h_all.shape[0]} node rows, topology has {E} / {N}')
         P = torch.empty(N, 2 * LAT, device=dev)
-        wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
-        _lib.check(L.hgn_linear_fwd(h_all.data_ptr(), _ld(h_all), N, wb, 2, 3 * LAT, P.data_ptr(), 2 * LAT, st), 'hgn_linear_fwd')
+        pk = packs_of(w) if (_ld(h_all) % 4 == 0 and h_all.data_ptr() % 16 == 0 and not _FP32_ONLY) else None
+        if pk is not None:
+            pb = (C.c_void_p * 2)(pk.data_ptr(), pk.data_ptr() + _lib.PACK_BLOCK_BYTES)
+            _lib.check(L.hgn_linear_fwd6(h_all.data_ptr(), _ld(h_all), N, pb, 2, P.data_ptr(), 2 * LAT, st), 'hgn_linear_fwd6')
+        else:
+            wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
+            _lib.check(L.hgn_linear_fwd(h_all.data_ptr(), _ld(h_all), N, wb, 2, 3 * LAT, P.data_ptr(), 2 * LAT, st), 'hgn_linear_fwd')
         out = torch.empty(E, LAT, device=dev)
         a = _lib.MlpFwd()
         a.M = E
         a.n_src = 1
         s = a.src[0]
         s.x = e.data_ptr(); s.ld = _ld(e); s.K = LAT; s.idx = None; s.W = w.w1.data_ptr() + 4 * 2 * LAT
+        if pk is not None:
+            s.Wpk = pk.data_ptr() + 2 * _lib.PACK_BLOCK_BYTES
+            a.W2pk = pk.data_ptr() + 3 * _lib.PACK_BLOCK_BYTES
+            a.W3pk = pk.data_ptr() + 4 * _lib.PACK_BLOCK_BYTES
         a.n_add = 2
         a.add[0].P = P.data_ptr(); a.add[0].ld = 2 * LAT; a.add[0].idx = topo.snd.data_ptr()
         a.add[1].P = P.data_ptr() + 4 * LAT; a.add[1].ld = 2 * LAT; a.add[1].idx = topo.rcv.data_ptr()

@@ -118,6 +118,9 @@ class DataParallelTrainer:
             ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t_dev)
         else:
             self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        if self.fp.flat.is_cuda:
+            from . import ops
+            ops.invalidate_packs()                  # the Adam kernel rewrote the parameters behind torch's version counters
         return loss.detach()
 
 

@@ -88,6 +88,7 @@ typedef struct {
   int32_t K;           /* columns of this source (any K >= 1)                       */
   const int32_t* idx;  /* optional row gather index [M]                             */
   const float* W;      /* &W1[0][col0]: weight columns that multiply this source    */
+  const void* Wpk;     /* optional: the same columns packed by hgn_pack_bf16x3 (forward form), K/128 consecutive blocks */
 } hgn_src_t;
 
 typedef struct {
@@ -111,9 +112,30 @@ typedef struct {
   const float* res; int64_t ld_res;       /* nullable residual [M, out_w]               */
   float* out; int64_t ld_out;
   float* z1; float* z2; float* xhat; float* rstd;   /* nullable saves [M,128] x3, [M]   */
+  const void* W2pk; const void* W3pk;     /* optional packed images of W2 / W3 (forward form); see hgn_pack_bf16x3 */
 } hgn_mlp_fwd_t;
 
 int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
+
+/* Split-bf16 matrix products (csrc/mlp6.hip).  When every weight block of a call comes with its packed image (Wpk / W2pk /
+ * W3pk ...), all widths are multiples of 128 and the output is 128 wide, the fused MLP kernels evaluate each fp32 128x128
+ * product as SIX bf16 MFMAs on a 3-way bf16 split of both operands (x = x1+x2+x3 holds all 24 significand bits; products
+ * with i+j <= 4; fp32 accumulation): at least fp32-accurate (2.6e-7 vs 4.5e-7 max relative error of a plain fp32 product
+ * on these shapes) at 2.7x the fp32 MFMA rate.  hgn_pack_bf16x3 packs blocks of at most 128 x 128 (element (o,i) at
+ * W[o*ldw+i], zero padded) into HGN_PACK_BLOCK_BYTES each.  Packs must be refreshed whenever the weights change.
+ * Setting the environment variable HGN_FP32_MFMA forces the plain fp32 kernels. */
+#define HGN_PACK_BLOCK_BYTES 98304
+#define HGN_MAX_PACK 32
+typedef struct {
+  const float* W; int64_t ldw;     /* block origin (&W[o0][i0]) and leading dimension                       */
+  int32_t n_out; int32_t n_in;     /* valid extents of the block (<= 128 each; the rest is zero padded)     */
+  int32_t transposed;              /* 0: contraction over i (forward products), 1: over o (data gradients)  */
+  void* out;                       /* HGN_PACK_BLOCK_BYTES, 16-byte aligned                                 */
+} hgn_pack_t;
+int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* stream);   /* one launch for up to HGN_MAX_PACK blocks */
+int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd will take the split-bf16 kernel */
+int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
+                    float* out, int64_t ld_out, void* stream);
 
 /* Backward data-gradient chain of the same MLP (LayerNorm bwd -> W3^T -> relu' -> W2^T -> relu' -> W1^T).
  * Writes dz3, dz2, dz1 ([M,128], consumed by hgn_mlp_wgrad and, for the pre-projected addends, by the

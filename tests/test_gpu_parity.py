@@ -265,6 +265,36 @@ CASES = [
 ]
 
 
+class _TieMargin:
+    """Records, over every max/min aggregation of an fp64 oracle run, the smallest lead of a segment's winner over its
+    runner-up (relative to the largest magnitude of that aggregation's input)."""
+
+    def __enter__(self):
+        self.worst = float('inf')
+        self._orig = O.segment_reduce
+
+        def probe(data, segment_ids, num_segments, operation, return_arg=False):
+            if operation in ('max', 'min') and data.dim() == 2 and data.shape[0] > 0:
+                d = (data if operation == 'max' else -data).detach().double()
+                ids = segment_ids.long()
+                idx = ids.unsqueeze(1).expand_as(d)
+                m1 = torch.full((num_segments, d.shape[1]), float('-inf'), dtype=d.dtype).scatter_reduce(0, idx, d, 'amax')
+                top = d == m1[ids]
+                ties = torch.zeros(num_segments, d.shape[1], dtype=d.dtype).scatter_add(0, idx, top.double())
+                m2 = torch.full_like(m1, float('-inf')).scatter_reduce(0, idx, d.masked_fill(top, float('-inf')), 'amax')
+                gap = torch.where(ties > 1, torch.zeros_like(m1), m1 - m2)
+                gap = gap[torch.isfinite(gap)]
+                if gap.numel():
+                    self.worst = min(self.worst, float(gap.min() / d.abs().max().clamp(min=1e-30)))
+            return self._orig(data, segment_ids, num_segments, operation, return_arg)
+        O.segment_reduce = probe
+        return self
+
+    def __exit__(self, *exc):
+        O.segment_reduce = self._orig
+        return False
+
+
 @pytest.mark.parametrize('arch,agg,steps,sets,gkw', CASES, ids=[f'{c[0]}-{c[1]}-L{c[2]}-S{len(c[3])}' for c in CASES])
 @pytest.mark.parametrize('index_device', ['cuda', 'cpu'])
 def test_model_vs_oracle(arch, agg, steps, sets, gkw, index_device):
@@ -285,13 +315,11 @@ def test_model_vs_oracle(arch, agg, steps, sets, gkw, index_device):
     # max/min route a gradient to ONE arg element: when the two best candidates of some segment differ by less than
     # fp32 rounding, which one wins is implementation dependent (the fp32 and fp64 oracles themselves then disagree
     # by ~1e-2).  Such ill-conditioned instances say nothing about parity: pick the first well-conditioned seed.
-    for wseed in range(11, 20):
+    for wseed in range(11, 40):
         sd = O.init_state_dict_like(shapes, seed=wseed)
-        out_o, loss_o, grads_o, ing_o = H.oracle_run(sd, graph, arch, agg, target, mask, set_order=order)
-        if agg not in ('pna', 'max', 'min'):
-            break
-        g32 = H.oracle_run(sd, graph, arch, agg, target, mask, set_order=order, dtype=torch.float32)[2]
-        if max(H.rel_err(g32[k], grads_o[k]) for k in grads_o if float(grads_o[k].abs().max()) > 0) < 1e-5:
+        with _TieMargin() as tm:
+            out_o, loss_o, grads_o, ing_o = H.oracle_run(sd, graph, arch, agg, target, mask, set_order=order)
+        if agg not in ('pna', 'max', 'min') or tm.worst > 2e-6:     # every max/min winner leads by more than fp32 rounding
             break
     model = H.hip_model(arch, agg, steps, sets, sd, set_order=order)
     out, loss, grads, ing = H.hip_run(model, graph, target, mask, index_device=index_device)
