@@ -2,6 +2,7 @@
 // See hgn_device.h for the register-chained transposed-MFMA formulation and include/hgn_mp.h for the ABI.
 #include "hgn_device.h"
 #include "hgn_host.h"
+#include "mlp_common.h"
 
 namespace hgn {
 
@@ -111,48 +112,6 @@ __global__ __launch_bounds__(WG, 3) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
 // ---------------------------------------------------------------------------------------------------------
 // backward (data gradients)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void relu_mask(Act& g, const float* __restrict__ zrow, int kq) {
-  HGN_FOR_B(fb) {
-    const f32x4 z = *reinterpret_cast<const f32x4*>(zrow + 16 * fb + 4 * kq);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) g.v[fb][u] = z[u] > 0.f ? g.v[fb][u] : 0.f;
-  }
-}
-
-// d_out_eff of the lane's row: d_out (optional) + the aggregation backward scattered back through the CSR row of the edge.
-template <bool ACC>
-__device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {
-  // ACC: add d_out_eff to g (residual path; 128-wide, aligned);  otherwise g = d_out_eff
-  if (ACC) {
-    if (a.d_out) t_add(g, a.d_out + rc * a.ld_dout, kq);
-  } else if (a.d_out) {
-    const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
-    if (vec_out) t_load(g, a.d_out + rc * a.ld_dout, kq); else t_load_masked(g, a.d_out + rc * a.ld_dout, kq, a.out_w);
-  } else {
-    t_zero(g);
-  }
-  if (a.agg_dout) {
-    const long r = a.agg_seg[rc];
-    const int cnt = a.agg_rowptr[r + 1] - a.agg_rowptr[r];
-    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
-    for (int slot = 0; slot < a.n_agg_ops; ++slot) {
-      const float* ar = a.agg_dout + r * a.ld_agg + slot * LAT;
-      const int op = a.agg_ops[slot];
-      HGN_FOR_B(fb) {
-        const int col = 16 * fb + 4 * kq;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(ar + col);
-        if (op == HGN_OP_SUM) g.v[fb] += d;
-        else if (op == HGN_OP_MEAN) g.v[fb] += d * inv;
-        else {
-          const int* ap = (op == HGN_OP_MAX ? a.agg_argmax : a.agg_argmin) + r * LAT + col;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) g.v[fb][u] += ap[u] == (int)rc ? d[u] : 0.f;
-        }
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
   __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS + (WG / 64) * 256];
   float* lnl = wlds + WLDS_FLOATS;
@@ -298,7 +257,7 @@ __global__ __launch_bounds__(WG, 4) void linear_bwd_kernel(const LinArgs a) {
 
 }  // namespace hgn
 
-namespace hgn { int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream); }
+namespace hgn { int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream); int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream); }
 using namespace hgn;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -367,7 +326,11 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   const int kid = (a->n_dx == 1 && a->dx[0].residual && a->dz1) ? 2 : 3;
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  if (hgn_mlp_bwd6_eligible(a)) {
+    if (launch_mlp6_bwd(a, stream) != HGN_OK) return HGN_E_LAUNCH;
+  } else {
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  }
   if (a->ln_ws) {
     hipLaunchKernelGGL(ln_reduce_kernel, dim3(32), dim3(1024), 0, (hipStream_t)stream, a->ln_ws, tiles, a->d_gamma, a->d_beta,
                        a->ln_accumulate);

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include "hgn_device.h"
 #include "hgn_host.h"
+#include "mlp_common.h"
 
 namespace hgn {
 
@@ -204,6 +205,97 @@ __global__ __launch_bounds__(WG, 3) void linear6_fwd_kernel(const Lin6Args a) {
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// backward (data gradients): same contract as mlp_bwd_kernel; weights come as TRANSPOSED-form packs
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) {
+  __shared__ __attribute__((aligned(16))) float ldsf[HALF_BF16 / 2 + (WG / 64) * 256];
+  __bf16* lds = reinterpret_cast<__bf16*>(ldsf);
+  float* lnl = ldsf + HALF_BF16 / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+
+  Act g, t;
+  // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
+  gemm6(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
+    load_dout<false>(g, a, rc, kq);
+    if (a.ln_g) {
+      t_load(t, a.xhat + rc * LAT, kq);
+      if (a.ln_ws) {
+        HGN_FOR_B(fb) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float pb = valid ? g.v[fb][u] : 0.f;
+            float pg = row16_sum(pb * t.v[fb][u]);
+            pb = row16_sum(pb);
+            if (n == 0) { lnl[wave * 256 + 16 * fb + 4 * kq + u] = pg; lnl[wave * 256 + 128 + 16 * fb + 4 * kq + u] = pb; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+      const float m1 = row_sum(g) * (1.f / LAT);
+      float q0 = 0.f, q1 = 0.f;
+      HGN_FOR_B(fb) {
+        q0 += g.v[fb][0] * t.v[fb][0] + g.v[fb][1] * t.v[fb][1];
+        q1 += g.v[fb][2] * t.v[fb][2] + g.v[fb][3] * t.v[fb][3];
+      }
+      float qs = q0 + q1;
+      qs += __shfl_xor(qs, 16);
+      qs += __shfl_xor(qs, 32);
+      const float m2 = qs * (1.f / LAT);
+      const float r = a.rstd[rc];
+      HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
+    }
+    if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
+    t_zero(t);
+  });
+  relu_mask(t, a.z2 + rc * LAT, kq);
+  if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
+  // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
+  gemm6(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] { t_zero(g); });
+  relu_mask(g, a.z1 + rc * LAT, kq);
+  if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
+  // ---- dx_src = dz1 * W1[:, cols]  (+ d_out_eff for the residual source) -----------------------------------
+  for (int di = 0; di < a.n_dx; ++di) {
+    const hgn_dx_t d = a.dx[di];
+    const __bf16* pk = reinterpret_cast<const __bf16*>(d.Wpk_t);
+    for (int k0 = 0; k0 < d.K; k0 += 128) {
+      gemm6(t, g, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] { t_zero(t); });
+      if (valid) {
+        float* dst = d.dx + row * d.ld + k0;
+        if (d.residual) load_dout<true>(t, a, rc, kq);
+        t_store(t, dst, kq);
+      }
+    }
+  }
+  if (a.ln_ws) {
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WG / 64; ++w) sum += lnl[w * 256 + threadIdx.x];
+    a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
+  }
+}
+
+__global__ __launch_bounds__(WG, 3) void linear6_bwd_kernel(const Lin6Args a) {
+  // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]; packs are transposed-form
+  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  Act acc, b;
+  t_zero(acc);
+  for (int blk = 0; blk < a.n_blocks; ++blk)
+    gemm6(acc, b, lds, a.pk[blk], [&] { t_load(b, a.x + rc * a.ldx + 128 * blk, kq); });
+  if (valid) t_store(acc, a.out + row * a.ld_out, kq);
+}
+
 }  // namespace hgn
 
 using namespace hgn;
@@ -257,4 +349,38 @@ extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const voi
   ProfScope ps(7, (double)M, (hipStream_t)stream);
   hipLaunchKernelGGL(linear6_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_fwd6");
+}
+
+extern "C" int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* a) {
+  if (!a || a->out_w != 128 || !a->W3pk_t || !a->W2pk_t) return 0;
+  for (int i = 0; i < a->n_dx; ++i) {
+    const hgn_dx_t& d = a->dx[i];
+    if (!d.Wpk_t || (d.K & 127) || (d.ld & 3) || !aligned16(d.dx)) return 0;
+  }
+  if (a->d_out && ((a->ld_dout & 3) || !aligned16(a->d_out))) return 0;
+  return getenv("HGN_FP32_MFMA") ? 0 : 1;
+}
+
+namespace hgn {
+int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream) {
+  const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+  hipLaunchKernelGGL(mlp6_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  return hgn_check_launch("hgn_mlp_bwd (split-bf16)");
+}
+}  // namespace hgn
+
+extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* pk_blocks, int nb, float* dx,
+                               int64_t ld_dx, void* stream) {
+  if (M == 0) return HGN_OK;
+  if (!g || !pk_blocks || !dx || M < 0 || nb < 1 || nb > 4 || (ldg & 3) || (ld_dx & 3) || !aligned16(g) || !aligned16(dx))
+    return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: bad argument");
+  Lin6Args a;
+  a.x = g; a.ldx = ldg; a.M = M; a.n_blocks = nb; a.out = dx; a.ld_out = ld_dx;
+  for (int i = 0; i < 4; ++i) a.pk[i] = i < nb ? reinterpret_cast<const __bf16*>(pk_blocks[i]) : nullptr;
+  for (int i = 0; i < nb; ++i)
+    if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: null packed block");
+  const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+  ProfScope ps(8, (double)M, (hipStream_t)stream);
+  hipLaunchKernelGGL(linear6_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  return hgn_check_launch("hgn_linear_bwd6");
 }

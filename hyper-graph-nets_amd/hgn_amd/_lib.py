@@ -40,7 +40,8 @@ class MlpFwd(C.Structure):
 
 
 class Dx(C.Structure):
-    _fields_ = [('W', c_f32p), ('K', C.c_int32), ('dx', c_f32p), ('ld', C.c_int64), ('residual', C.c_int32)]
+    _fields_ = [('W', c_f32p), ('K', C.c_int32), ('dx', c_f32p), ('ld', C.c_int64), ('residual', C.c_int32),
+                ('Wpk_t', C.c_void_p)]
 
 
 class MlpBwd(C.Structure):
@@ -50,7 +51,8 @@ class MlpBwd(C.Structure):
                 ('dx', Dx * HGN_MAX_SRC),
                 ('agg_dout', c_f32p), ('ld_agg', C.c_int64), ('n_agg_ops', C.c_int32), ('agg_ops', C.c_int32 * 4),
                 ('agg_seg', c_i32p), ('agg_rowptr', c_i32p), ('agg_argmax', c_i32p), ('agg_argmin', c_i32p),
-                ('d_gamma', c_f32p), ('d_beta', c_f32p), ('ln_ws', c_f32p), ('ln_accumulate', C.c_int32)]
+                ('d_gamma', c_f32p), ('d_beta', c_f32p), ('ln_ws', c_f32p), ('ln_accumulate', C.c_int32),
+                ('W3pk_t', C.c_void_p), ('W2pk_t', C.c_void_p)]
 
 
 class WTask(C.Structure):
@@ -81,6 +83,9 @@ _SIGS = {
     'hgn_pack_bf16x3': (C.c_int, [C.POINTER(Pack), C.c_int, C.c_void_p]),
     'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
     'hgn_linear_fwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
+                                  C.c_void_p]),
+    'hgn_mlp_bwd6_eligible': (C.c_int, [C.POINTER(MlpBwd)]),
+    'hgn_linear_bwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
     'hgn_mlp_bwd_ln_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     'hgn_mlp_bwd': (C.c_int, [C.POINTER(MlpBwd), C.c_void_p]),

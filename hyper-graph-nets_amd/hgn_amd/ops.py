@@ -259,12 +259,14 @@ class MLPFn(torch.autograd.Function):
             ctx.meta = (n_src, idxs, residual, has_ln, cols, M)
             ctx.saves = saves
             ctx.targets = _grad_targets(wt)
+            ctx.pk_t = packs_of(w, transposed=True) if pk is not None else None
             ctx.save_for_backward(*srcs, *wt)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         n_src, idxs, residual, has_ln, cols, M = ctx.meta
+        pk_t = ctx.pk_t
         saved = ctx.saved_tensors
         srcs, wt = saved[:n_src], saved[n_src:]
         w = MLPWeights(*wt)
@@ -293,9 +295,15 @@ class MLPFn(torch.autograd.Function):
                 d = b.dx[nd]
                 d.W = w.w1.data_ptr() + 4 * cols[i]; d.K = K; d.dx = dx.data_ptr(); d.ld = K
                 d.residual = 1 if i == residual else 0
+                if pk_t is not None:
+                    d.Wpk_t = pk_t.data_ptr() + (cols[i] // LAT) * _lib.PACK_BLOCK_BYTES
                 dxs[i] = dx
                 nd += 1
         b.n_dx = nd
+        if pk_t is not None:
+            nb1 = w.w1.shape[1] // LAT
+            b.W2pk_t = pk_t.data_ptr() + nb1 * _lib.PACK_BLOCK_BYTES
+            b.W3pk_t = pk_t.data_ptr() + (nb1 + 1) * _lib.PACK_BLOCK_BYTES
         bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
         if has_ln:           # LayerNorm-affine gradients come out of the same pass
             b.d_gamma = bufs[6].data_ptr(); b.d_beta = bufs[7].data_ptr(); b.ln_accumulate = accs[6]
@@ -405,6 +413,7 @@ class EdgeBlockFn(torch.autograd.Function):
             ctx.saves = saves
             ctx.agg = (agg_ops, amax, amin)
             ctx.targets = _grad_targets(wt)
+            ctx.pk_t = packs_of(w, transposed=True) if pk is not None else None
             ctx.save_for_backward(h_all, e, *wt)
         return (out, agg) if agg_ops is not None else out
 
@@ -448,6 +457,11 @@ class EdgeBlockFn(torch.autograd.Function):
         b.n_dx = 1
         d = b.dx[0]
         d.W = w.w1.data_ptr() + 4 * 2 * LAT; d.K = LAT; d.dx = de.data_ptr(); d.ld = LAT; d.residual = 1
+        pk_t = ctx.pk_t
+        if pk_t is not None:
+            d.Wpk_t = pk_t.data_ptr() + 2 * _lib.PACK_BLOCK_BYTES
+            b.W2pk_t = pk_t.data_ptr() + 3 * _lib.PACK_BLOCK_BYTES
+            b.W3pk_t = pk_t.data_ptr() + 4 * _lib.PACK_BLOCK_BYTES
         bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
         dw1, db1, dw2, db2, dw3, db3, dg, dbt = bufs
         b.d_gamma = dg.data_ptr(); b.d_beta = dbt.data_ptr(); b.ln_accumulate = accs[6]
@@ -476,8 +490,12 @@ class EdgeBlockFn(torch.autograd.Function):
         dh = None
         if ctx.needs_input_grad[3]:
             dh = torch.empty(N, LAT, device=dev)
-            wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
-            _lib.check(L.hgn_linear_bwd(dP.data_ptr(), 2 * LAT, N, wb, 2, 3 * LAT, dh.data_ptr(), LAT, st), 'hgn_linear_bwd')
+            if pk_t is not None:
+                pb = (C.c_void_p * 2)(pk_t.data_ptr(), pk_t.data_ptr() + _lib.PACK_BLOCK_BYTES)
+                _lib.check(L.hgn_linear_bwd6(dP.data_ptr(), 2 * LAT, N, pb, 2, dh.data_ptr(), LAT, st), 'hgn_linear_bwd6')
+            else:
+                wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
+                _lib.check(L.hgn_linear_bwd(dP.data_ptr(), 2 * LAT, N, wb, 2, 3 * LAT, dh.data_ptr(), LAT, st), 'hgn_linear_bwd')
         return (None, None, None, dh, de, *grads_w)
 
 

@@ -146,6 +146,7 @@ typedef struct {
   float* dx;           /* [M, ld]                                                    */
   int64_t ld;
   int32_t residual;    /* 1: dx += d_out (the `res +` skip connection)                */
+  const void* Wpk_t;   /* optional: the same columns packed by hgn_pack_bf16x3 (transposed form), K/128 consecutive blocks */
 } hgn_dx_t;
 
 typedef struct {
@@ -167,10 +168,14 @@ typedef struct {
    * produced by the same pass (deterministic: per-wave shuffles -> per-workgroup slab -> two-level fixed-order sum).
    * ln_ws: hgn_mlp_bwd_ln_workspace_bytes(M) bytes. */
   float* d_gamma; float* d_beta; float* ln_ws; int32_t ln_accumulate;
+  const void* W3pk_t; const void* W2pk_t;   /* optional packed images of W3 / W2 (transposed form): split-bf16 kernels */
 } hgn_mlp_bwd_t;
 
 int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes /*host*/);
 int hgn_mlp_bwd(const hgn_mlp_bwd_t* args /*host*/, void* stream);
+int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* args /*host*/);   /* 1 if hgn_mlp_bwd will take the split-bf16 kernel */
+int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* packed_blocks_t /*host array, transposed form*/,
+                    int n_blocks, float* dx, int64_t ld_dx, void* stream);
 
 /* Weight / bias / LayerNorm-affine gradients: a list of tasks reduced over all rows in one launch.
  *   type 0:  dW[j][k] = sum_i G[i][j] * A[idxA ? idxA[i] : i][k]   (j < 128, k < K <= 128),  db[j] = sum_i G[i][j]
