@@ -7,6 +7,7 @@
 // across the whole chunk; chunk partials go to slabs that a second kernel adds in fixed order (deterministic,
 // no float atomics -- MI355X global float atomics run at ~1.3 TB/s and are order dependent).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "hgn_host.h"
 
 namespace hgn {
@@ -216,6 +217,138 @@ __global__ __launch_bounds__(WGW, 2) void wgrad_dma_kernel(const WArgs a) {
   if (threadIdx.x < 128) slab[128 * 128 + threadIdx.x] = lds[threadIdx.x] + lds[128 + threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant of the DMA kernel: dW = G^T A with the contraction over ROWS on v_mfma_f32_16x16x32_bf16 -- both operands
+// are read from the row-major fp32 LDS tiles "transposed" (a lane takes 8 consecutive rows of one feature: eight conflict-free
+// ds_read_b32), split into three bf16 terms in registers and multiplied with six MFMAs (see csrc/mlp6.hip for the arithmetic).
+// 32 rows per contraction block = two 16-row ring slots (a "pair"); the 4-slot ring holds the pair being multiplied and the
+// pair in flight.  16-byte groups of a row are XOR-swizzled with (row >> 3) so that the four 8-row groups of a read hit
+// different bank halves.  Per pair and wave: 80 values split (VALU) against 96 MFMAs of 16 cycles -- half the cycles of the
+// fp32 MFMA formulation (256 MFMAs of 64... cycles per 32 rows), which leaves the kernel HBM-bound.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wg_dma_issue6(float* __restrict__ slotA, float* __restrict__ slotG, const WTaskDev& t,
+                                              long tile_row0, long M, int parity) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (unsigned q = 0; q < 2; ++q) {
+    const unsigned i = wave * 2 + q;                       // 8 wave-instructions of 1 KiB cover the 16x128 tile
+    const unsigned r = 2 * i + (lane >> 5);                // row inside the slot
+    long gr = tile_row0 + r;
+    gr = gr < M ? gr : M - 1;
+    const unsigned kg = 2 * parity + (r >> 3);             // 8-row group inside the 32-row pair
+    const unsigned c = 4 * ((lane & 31) ^ (kg << 2));      // LDS group position (lane & 31) holds source group ^ (kg << 2)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.A + gr * t.lda + c),
+                                     (__attribute__((address_space(3))) void*)(slotA + i * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.G + gr * t.ldg + c),
+                                     (__attribute__((address_space(3))) void*)(slotG + i * 256), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void split3v(const float (&v)[8], bf16x8 (&s)[3]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    const float r1 = v[j] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    s[0][j] = h; s[1][j] = m; s[2][j] = (__bf16)r2;
+  }
+}
+
+__global__ __launch_bounds__(WGW, 2) void wgrad6_kernel(const WArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[NS * 2 * DT * 128];      // [slot][A|G][16][128] = 64 KB, NS = 4
+  const WTaskDev t = a.t[a.task0 + blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kg = lane >> 4;
+  const long row_beg = (long)blockIdx.x * a.rows_per_chunk;
+  const long row_end = min(a.M, row_beg + a.rows_per_chunk);
+  float* slab = t.slab + (long)blockIdx.x * SLAB;
+  const int ntiles = row_beg < row_end ? (int)((row_end - row_beg + DT - 1) / DT) : 0;
+  const int npairs = (ntiles + 1) >> 1;
+  const int cs_col = threadIdx.x & 127, cs_half = threadIdx.x >> 7;
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float cs0 = 0.f;
+  auto issue_pair = [&](int p) {
+    const int s0 = 2 * (p & 1);
+    wg_dma_issue6(lds + (s0 * 2) * DT * 128, lds + (s0 * 2 + 1) * DT * 128, t, row_beg + (long)(2 * p) * DT, a.M, 0);
+    wg_dma_issue6(lds + ((s0 + 1) * 2) * DT * 128, lds + ((s0 + 1) * 2 + 1) * DT * 128, t, row_beg + (long)(2 * p + 1) * DT, a.M, 1);
+  };
+  if (npairs > 0) issue_pair(0);
+  // this lane's 8 rows of the pair: rows 8kg .. 8kg+7 -> slot kg >> 1, slot rows 8(kg & 1) + j; swizzle value kg << 2
+  const int slot_of = kg >> 1, r_base = 8 * (kg & 1), swz = kg << 2;
+  for (int p = 0; p < npairs; ++p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // pair p landed for every wave; the slots of pair p-1 are free
+    if (p + 1 < npairs) issue_pair(p + 1);
+    const int s0 = 2 * (p & 1);
+    const float* As = lds + ((s0 + slot_of) * 2) * DT * 128 + r_base * 128;
+    const float* Gs = As + DT * 128;
+    const long r0 = row_beg + (long)p * 2 * DT + 8 * kg;       // global row of j = 0
+    // G operand (this wave's 32 dW rows = two 16-feature blocks), zeroed beyond the chunk end
+    bf16x8 gs[2][3];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int f = 32 * wave + 16 * mb + m;
+      const int col = (((f >> 2) ^ swz) << 2) | (f & 3);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (r0 + j < row_end) ? Gs[j * 128 + col] : 0.f;
+      split3v(v, gs[mb]);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const int f = 16 * nb + m;
+      const int col = (((f >> 2) ^ swz) << 2) | (f & 3);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = As[j * 128 + col];
+      bf16x8 as[3];
+      split3v(v, as);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        f32x4 c = acc[mb][nb];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][2], as[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[0], c, 0, 0, 0);
+        acc[mb][nb] = c;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // column sums of G (bias gradient): thread (cs_half, cs_col) sums rows [16 cs_half, 16 cs_half + 16) of the pair
+    {
+      const float* Gp = lds + ((s0 + cs_half) * 2 + 1) * DT * 128;
+      const long rr0 = row_beg + (long)p * 2 * DT + 16 * cs_half;
+#pragma unroll
+      for (int r = 0; r < DT; ++r) {
+        const int sw = (2 * cs_half + (r >> 3)) << 2;
+        const float g = Gp[r * 128 + ((((cs_col >> 2) ^ sw) << 2) | (cs_col & 3))];
+        cs0 += (rr0 + r < row_end) ? g : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(32 * wave + 16 * mb + 4 * kg + r) * 128 + 16 * nb + m] = acc[mb][nb][r];
+  __builtin_amdgcn_s_barrier();
+  lds[threadIdx.x] = cs0;
+  __syncthreads();
+  if (threadIdx.x < 128) slab[128 * 128 + threadIdx.x] = lds[threadIdx.x] + lds[128 + threadIdx.x];
+}
+
 struct RTaskDev { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; };
 struct RArgs { RTaskDev t[HGN_MAX_WTASK]; };
 
@@ -347,8 +480,15 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   };
   ProfScope ps(g_prof_tag == 1 ? 11 : 4, (double)M * n0, (hipStream_t)stream);
   if (nd) {
-    wa.n_chunks = nch0; wa.rows_per_chunk = rows_per(nch0, DT); wa.task0 = 0;
-    hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+    static const bool fp32_only = getenv("HGN_FP32_MFMA") != nullptr;
+    wa.n_chunks = nch0; wa.task0 = 0;
+    if (fp32_only) {
+      wa.rows_per_chunk = rows_per(nch0, DT);
+      hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+    } else {                                    // split-bf16 products: 32-row contraction blocks
+      wa.rows_per_chunk = rows_per(nch0, 2 * DT);
+      hipLaunchKernelGGL(wgrad6_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+    }
   }
   if (ng) {
     wa.n_chunks = nch0; wa.rows_per_chunk = rows_per(nch0, WT_ROWS); wa.task0 = nd;
