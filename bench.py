@@ -249,8 +249,20 @@ def main():
             # formulation's 163 840 flop/edge splits between this launch and the node pre-projection
             per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1}.get(name, 3) * 2 * 128 * 128
             ach = per_row * rows / t_launch / 1e12
+            # algorithmic HBM bytes of that launch (edge forward: read e, write e', z1, z2, x-hat = 5 x 512 B per row, plus the
+            # node pre-projection rows once); reported beside the matrix figure because with split-bf16 products the
+            # kernels sit between the two roofs
+            hbm_row = {'mlp_fwd_edge': 5 * 512, 'mlp_bwd_edge': 9 * 512, 'wgrad': 2 * 512}.get(name)
+            hbm = None
+            if hbm_row is not None:
+                extra = N_nodes * 1024 if name == 'mlp_fwd_edge' else 0
+                hbm = (hbm_row * rows + extra) / t_launch / 1e9
             res['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'products': 'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate '
+                                           '(fp32-accurate; flops counted once, priced against the fp32 MFMA peak)'
+                                           if not os.environ.get('HGN_FP32_MFMA') else 'fp32 MFMA',
+                               'hbm_algorithmic_GBs': hbm, 'hbm_frac': (hbm / PEAK_HBM_GBS) if hbm else None,
                                'rows_per_launch': rows, 'ms_per_launch': t_launch * 1e3, 'flop_per_row': per_row,
                                'selection': 'heaviest kernel whose launches do not overlap side-stream work'
                                             if overlapped else 'largest accumulated time'}
