@@ -517,3 +517,62 @@ def test_graphed_shard_step_matches_trainer_step():
     for a, b in zip(l_e, l_g):        # later steps: Adam turns rounding-level gradient entries into +-lr moves, losses stay close
         assert abs(a - b) <= 5e-5 * abs(a), (a, b)
     assert int(shard.t_dev) == 4
+
+
+def test_split_bf16_products_are_fp32_accurate():
+    """The default kernels evaluate each fp32 product as six bf16 MFMAs on 3-way bf16 splits (csrc/mlp6.hip): against fp64 they
+    must be as accurate as the plain fp32-MFMA kernels (HGN_FP32_MFMA=1) on the same inputs -- forward, data gradients and
+    weight gradients of an edge block and of a two-source node MLP."""
+    import os
+    from hgn_amd import ops, topology, modules
+    import hgn_amd
+    g = synth.grid_graph(seed=3, nx=20, ny=20)
+    es = g.edge_sets[0]
+    N, E = g.node_features[0].shape[0], es.senders.shape[0]
+    topo = topology.EdgeTopology(es.senders.cuda(), es.receivers.cuda(), N, torch.device('cuda'))
+    torch.manual_seed(0)
+    m = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges']).cuda()
+    with torch.no_grad():
+        m(hgn_amd.MultiGraph([g.node_features[0].cuda()], [hgn_amd.EdgeSet(es.name, es.features.cuda(), es.senders.cuda(), es.receivers.cuda())]))
+    blk = m.processor.graphnet_blocks[0]
+    we = modules.weights_of(blk.edge_models['mesh_edges'], 384)
+    wn = modules.weights_of(blk.node_model_cross, 256)
+    h0 = torch.randn(N, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    e0 = torch.randn(E, 128, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def run():
+        h = h0.clone().requires_grad_(True); e = e0.clone().requires_grad_(True)
+        for p in list(blk.parameters()):
+            p.grad = None
+        y, agg = ops.edge_block(h, e, topo, we, ('sum',))
+        hn = ops.fused_mlp([h, agg], wn, None, 0)
+        (hn.square().sum() + y.square().sum()).backward()
+        return [y.detach(), hn.detach(), h.grad, e.grad] + [p.grad.clone() for p in blk.parameters()]
+
+    def ref64():
+        snd, rcv = topo.snd.long(), topo.rcv.long()
+        h = h0.double().requires_grad_(True); e = e0.double().requires_grad_(True)
+        ps = [p.detach().double().requires_grad_(True) for p in blk.parameters()]
+        names = [n for n, _ in blk.named_parameters()]
+        P = dict(zip(names, ps))
+
+        def mlp(x, pre):
+            z = torch.relu(x @ P[pre + '.0.layers.linear_0.weight'].T + P[pre + '.0.layers.linear_0.bias'])
+            z = torch.relu(z @ P[pre + '.0.layers.linear_1.weight'].T + P[pre + '.0.layers.linear_1.bias'])
+            z = z @ P[pre + '.0.layers.linear_2.weight'].T + P[pre + '.0.layers.linear_2.bias']
+            return torch.nn.functional.layer_norm(z, (128,), P[pre + '.1.weight'], P[pre + '.1.bias'], 1e-5)
+        y = e + mlp(torch.cat([h[snd], h[rcv], e], 1), 'edge_models.mesh_edges')
+        agg = torch.zeros(N, 128, dtype=torch.float64, device='cuda').index_add(0, rcv, y)
+        hn = h + mlp(torch.cat([h, agg], 1), 'node_model_cross')
+        (hn.square().sum() + y.square().sum()).backward()
+        return [y.detach(), hn.detach(), h.grad, e.grad] + [p.grad for p in ps]
+    r64 = ref64()
+    split = run()
+    os.environ['HGN_FP32_MFMA'] = '1'                      # read by the library at every launch
+    try:
+        plain = run()
+    finally:
+        del os.environ['HGN_FP32_MFMA']
+    for a, b, c in zip(split, plain, r64):
+        e6, e32 = H.rel_err(a, c), H.rel_err(b, c)
+        assert e6 <= max(1.5 * e32, 2e-6), (e6, e32)
