@@ -39,7 +39,10 @@ __device__ __forceinline__ void split3(const Act& x, bf16x8 (&s)[3][4]) {
 __device__ __forceinline__ void stage_half(__bf16* lds, const __bf16* gsrc) {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (unsigned i = wave; i < HALF_TILES; i += WG / 64)          // one tile (1 KiB) per wave instruction, straight copy
+#ifndef STAGE_TILES
+#define STAGE_TILES HALF_TILES
+#endif
+  for (unsigned i = wave; i < STAGE_TILES; i += WG / 64)          // one tile (1 KiB) per wave instruction, straight copy
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
                                      (__attribute__((address_space(3))) void*)(lds + i * TILE_BF16), 16, 0, 0);
 }
