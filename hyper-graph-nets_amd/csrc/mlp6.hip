@@ -144,10 +144,13 @@ __global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) 
     const hgn_src_t s = a.src[si];
     const long srow = s.idx ? (long)s.idx[rc] : rc;
     const __bf16* pk = reinterpret_cast<const __bf16*>(s.Wpk);
+    const bool vec = ((s.ld & 3) == 0) && ((s.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
     for (int k0 = 0; k0 < s.K; k0 += 128) {
+      const int kw = min(128, s.K - k0);
       const float* xr = s.x + srow * s.ld + k0;
       gemm6(acc, b, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
-        t_load(b, xr, kq);
+        // narrow / unaligned sources (encoder inputs): zero-extended to the 128-wide block whose pack is zero padded
+        if (vec) { if (kw == 128) t_load(b, xr, kq); else t_load_w(b, xr, kq, kw); } else t_load_masked(b, xr, kq, kw);
         if (first) {
           t_load(acc, a.b1, kq);
           for (int i = 0; i < a.n_add; ++i) t_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, kq);
@@ -315,13 +318,13 @@ extern "C" int hgn_pack_bf16x3(const hgn_pack_t* blocks, int n, void* stream) {
   return hgn_check_launch("hgn_pack_bf16x3");
 }
 
-// Eligibility of the split-bf16 forward: every source a multiple of 128 columns with 16-byte aligned rows and a packed image,
-// 128-wide output, packed W2 / W3.  (Encoders and the decoder keep the fp32 kernel.)
+// Eligibility of the split-bf16 forward: every source with a packed image (narrow sources: zero-padded blocks), 128-wide
+// output, packed W2 / W3.  (The decoder, 3 outputs wide, keeps the fp32 kernel.)
 extern "C" int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* a) {
   if (!a || a->out_w != 128 || !a->W2pk || !a->W3pk || a->n_src < 1) return 0;
   for (int i = 0; i < a->n_src; ++i) {
     const hgn_src_t& s = a->src[i];
-    if (!s.Wpk || (s.K & 127) || (s.ld & 3) || !aligned16(s.x)) return 0;
+    if (!s.Wpk || s.K < 1) return 0;
   }
   if ((a->ld_out & 3) || !aligned16(a->out) || (a->res && ((a->ld_res & 3) || !aligned16(a->res)))) return 0;
   return getenv("HGN_FP32_MFMA") ? 0 : 1;

@@ -92,11 +92,11 @@ def invalidate_packs() -> None:
 
 
 def packs_of(w: MLPWeights, transposed: bool = False):
-    """-> uint8 tensor holding the packed blocks [W1 block 0 .. nb1-1, W2, W3] of this MLP (forward or transposed form), or
-    None if the MLP is not eligible (first-layer width not a multiple of 128, or a narrow output: encoders / decoder)."""
-    if w.w1.shape[1] % LAT != 0 or w.w3.shape[0] != LAT or not w.w1.is_cuda:
+    """-> uint8 tensor holding the packed blocks [W1 block 0 .. nb1-1, W2, W3] of this MLP (forward or transposed form; a
+    first-layer width that is not a multiple of 128 gives a zero-padded last block), or None for a narrow output (decoder)."""
+    if w.w3.shape[0] != LAT or not w.w1.is_cuda:
         return None
-    nb1 = w.w1.shape[1] // LAT
+    nb1 = (w.w1.shape[1] + LAT - 1) // LAT
     attr = '_hgn_pk_t' if transposed else '_hgn_pk'
     key = (_pack_epoch, w.w1._version, w.w2._version, w.w3._version, w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr())
     st = getattr(w.w1, attr, None)
@@ -109,7 +109,8 @@ def packs_of(w: MLPWeights, transposed: bool = False):
     t = 1 if transposed else 0
     for b in range(nb1):
         d = arr[b]
-        d.W = w.w1.data_ptr() + 4 * LAT * b; d.ldw = w.w1.shape[1]; d.n_out = LAT; d.n_in = LAT; d.transposed = t
+        d.W = w.w1.data_ptr() + 4 * LAT * b; d.ldw = w.w1.shape[1]; d.n_out = LAT
+        d.n_in = min(LAT, w.w1.shape[1] - LAT * b); d.transposed = t
         d.out = buf.data_ptr() + b * _lib.PACK_BLOCK_BYTES
     for i, m in enumerate((w.w2, w.w3)):
         d = arr[nb1 + i]
@@ -234,8 +235,9 @@ class MLPFn(torch.autograd.Function):
         a.n_src = n_src
         col = 0
         cols = []
-        pk = packs_of(w) if all(s.shape[1] % LAT == 0 for s in srcs) else None
-        nb1 = w.w1.shape[1] // LAT
+        # every source must start on a 128-column boundary of W1 (all but the last a multiple of 128 wide)
+        pk = packs_of(w) if all(s.shape[1] % LAT == 0 for s in srcs[:-1]) else None
+        nb1 = (w.w1.shape[1] + LAT - 1) // LAT
         for i, s in enumerate(srcs):
             e = a.src[i]
             e.x = s.data_ptr(); e.ld = _ld(s); e.K = s.shape[1]
@@ -301,7 +303,7 @@ class MLPFn(torch.autograd.Function):
                 nd += 1
         b.n_dx = nd
         if pk_t is not None:
-            nb1 = w.w1.shape[1] // LAT
+            nb1 = (w.w1.shape[1] + LAT - 1) // LAT
             b.W2pk_t = pk_t.data_ptr() + nb1 * _lib.PACK_BLOCK_BYTES
             b.W3pk_t = pk_t.data_ptr() + (nb1 + 1) * _lib.PACK_BLOCK_BYTES
         bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)

@@ -265,6 +265,25 @@ CASES = [
 ]
 
 
+class _KinkMargin:
+    """Smallest |x| over every ReLU input of an fp64 oracle run (the distance of the instance from a ReLU kink)."""
+
+    def __enter__(self):
+        self.worst = float('inf')
+        self._orig = torch.relu
+
+        def probe(x):
+            if x.numel():
+                self.worst = min(self.worst, float(x.detach().abs().min()))
+            return self._orig(x)
+        torch.relu = probe
+        return self
+
+    def __exit__(self, *exc):
+        torch.relu = self._orig
+        return False
+
+
 class _TieMargin:
     """Records, over every max/min aggregation of an fp64 oracle run, the smallest lead of a segment's winner over its
     runner-up (relative to the largest magnitude of that aggregation's input)."""
@@ -342,11 +361,17 @@ def test_flag_L15_sum_vs_oracle_fp64():
     the fp64 oracle: the 1e-5 relative target through 15 residual + LayerNorm layers."""
     graph = synth.grid_graph(seed=2, nx=12, ny=12)
     shapes = O.param_shapes('none', 'sum', 15, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128)
-    sd = O.init_state_dict_like(shapes, seed=3)
     N = 144
     target = torch.randn(N, 3, generator=torch.Generator().manual_seed(4))
     mask = torch.ones(N, dtype=torch.bool); mask[:3] = False
-    out_o, loss_o, grads_o, _ = H.oracle_run(sd, graph, 'none', 'sum', target, mask)
+    # 3.6 million ReLU inputs: an instance where one of them sits within fp32 rounding of zero has a gradient that jumps with
+    # the last bit of any implementation (the fp32 and fp64 oracles disagree there too) -- take the first seed without one
+    for wseed in range(3, 40):
+        sd = O.init_state_dict_like(shapes, seed=wseed)
+        with _KinkMargin() as km:
+            out_o, loss_o, grads_o, _ = H.oracle_run(sd, graph, 'none', 'sum', target, mask)
+        if km.worst > 3e-7:
+            break
     model = H.hip_model('none', 'sum', 15, ['mesh_edges'], sd)
     out, loss, grads, _ = H.hip_run(model, graph, target, mask)
     assert H.rel_err(out, out_o) <= TOL_OUT
