@@ -147,6 +147,40 @@ class FlagModel(AbstractSystemModel):
             unnormalized_edges=EdgeSet(name='mesh_edges', features=edge_features, receivers=receivers, senders=senders),
             obstacle_nodes=None)
 
+    def build_graph_batch(self, inputs: Dict, is_training: bool) -> MultiGraphWithPos:
+        """Not in the reference (which builds one graph per frame in Python and concatenates them with
+        MeshSimulator._get_batched): B frames of ONE mesh -- `world_pos`, `prev|world_pos`, `node_type` with a leading batch
+        dimension [B, N, .], `mesh_pos` [N, 2] or [B, N, 2], `cells` [F, 3] -- become the disjoint union of B graphs in the same
+        handful of launches a single frame takes (node ids of frame b are offset by b*N, as batching.batch_graphs does).
+        Semantic difference to B separate build_graph calls: each normaliser accumulates ONCE, with the statistics of the
+        whole batch (same running sums and counts afterwards, `num_accumulations` grows by 1 instead of B)."""
+        world_pos = inputs['world_pos'].to(device)
+        B, N = world_pos.shape[0], world_pos.shape[1]
+        prev = inputs['prev|world_pos'].to(device).reshape(B * N, 3)
+        mesh_pos = inputs['mesh_pos'].to(device)
+        mesh_pos = (mesh_pos if mesh_pos.dim() == 3 else mesh_pos.unsqueeze(0).expand(B, N, -1)).reshape(B * N, -1).contiguous()
+        node_type = inputs['node_type'].to(device).reshape(B * N, -1)
+        world_pos = world_pos.reshape(B * N, 3)
+        s1, r1 = self._mesh_edges(inputs['cells'])
+        key = (B, N, s1.data_ptr())
+        if getattr(self, '_batch_edges_key', None) != key:               # batched topology: once per (mesh, batch size)
+            off = (torch.arange(B, device=s1.device) * N).repeat_interleave(s1.shape[0])
+            self._batch_edges = ((s1.repeat(B) + off).contiguous(), (r1.repeat(B) + off).contiguous())
+            self._batch_edges_key = key
+        senders, receivers = self._batch_edges
+        node_features = features.node_features(world_pos, prev, node_type, self._TYPE_MAP, 2)
+        edge_features, length = features.rel_edge_features(world_pos, mesh_pos, senders, receivers, want_len=True)
+        mesh_edges = EdgeSet(name='mesh_edges', features=self._mesh_edge_normalizer(edge_features, is_training),
+                             receivers=receivers, senders=senders)
+        csr = topology.segment_csr(receivers, B * N, world_pos.device)
+        mm = ops.aggregate([length.unsqueeze(1)], [(csr.perm, csr.rowptr, csr.seg)], ('max', 'min'))
+        node_dynamic = self._node_dynamic_normalizer(features.lincomb3(mm[:, 0], 1.0, mm[:, 1], -1.0))
+        return MultiGraphWithPos(
+            node_features=[self._node_normalizer(node_features, is_training)], edge_sets=[mesh_edges],
+            target_feature=world_pos, mesh_features=mesh_pos, model_type=self._model_type, node_dynamic=node_dynamic,
+            unnormalized_edges=EdgeSet(name='mesh_edges', features=edge_features, receivers=receivers, senders=senders),
+            obstacle_nodes=None)
+
     def _loss_mask(self, data_frame):
         return torch.eq(data_frame['node_type'].to(device)[:, 0], NodeType.NORMAL.value)
 

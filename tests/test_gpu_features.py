@@ -555,3 +555,34 @@ def test_plate_multigraph_connector_matches_reference_golden():
             assert rel_err(a, c) <= 5e-5
         out = model(mg)
         assert out.shape == (fr['world_pos'].shape[0], 3) and bool(torch.isfinite(out).all())
+
+
+def test_flag_build_graph_batch_equals_per_frame_graphs():
+    """B frames of one mesh built in one go == the per-frame graphs batched with batching.batch_graphs (identical ids;
+    identical features when the normalisers are frozen; identical running sums when they accumulate)."""
+    from hgn_amd import batching, system_model
+    B = 5
+    frames = [synth.flag_frame(seed=60 + i, nx=9, ny=7) for i in range(B)]
+    stacked = {k: (torch.stack([f[k] for f in frames]) if k not in ('cells', 'mesh_pos') else frames[0][k]).cuda()
+               for k in frames[0]}
+    a, b = system_model.FlagModel(flag_params()), system_model.FlagModel(flag_params())
+    for m in (a, b):                                           # same warm statistics in both models
+        m.build_graph(cuda_frame(synth.flag_frame(seed=1, nx=9, ny=7)), True)
+    per = [a.build_graph(cuda_frame(f), False) for f in frames]
+    ref = batching.batch_graphs(per)
+    got = b.build_graph_batch(stacked, False)
+    assert torch.equal(got.edge_sets[0].senders, ref.edge_sets[0].senders)
+    assert torch.equal(got.edge_sets[0].receivers, ref.edge_sets[0].receivers)
+    assert torch.equal(got.edge_sets[0].features, ref.edge_sets[0].features)
+    assert torch.equal(got.node_features[0], ref.node_features[0])
+    # accumulating: one accumulate over the batch == B accumulates over the frames (sums up to fp32 summation order)
+    for f in frames:
+        a.build_graph(cuda_frame(f), True)
+    b.build_graph_batch(stacked, True)
+    for name in ('_node_normalizer', '_mesh_edge_normalizer'):
+        na, nb = getattr(a, name), getattr(b, name)
+        assert torch.equal(na._acc_count, nb._acc_count)
+        torch.testing.assert_close(na._acc_sum, nb._acc_sum, rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(na._acc_sum_squared, nb._acc_sum_squared, rtol=1e-5, atol=1e-4)
+    out = b(got)
+    assert out.shape == (B * 63, 3)

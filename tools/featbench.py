@@ -70,6 +70,20 @@ def main():
         torch.cuda.synchronize()
         res[name + ' ms/frame (gpu, eager)'] = (time.perf_counter() - t0) / a.frames * 1e3
 
+    # the whole batch of frames in one go (FlagModel.build_graph_batch)
+    model = system_model.FlagModel(params('none', 16))
+    Bf = 128
+    stacked = {k: (torch.stack([frames[i % 4][k] for i in range(Bf)]).cuda() if k not in ('cells', 'mesh_pos') else dev_frames[0][k])
+               for k in frames[0]}
+    for _ in range(3):
+        model.build_graph_batch(stacked, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        model.build_graph_batch(stacked, True)
+    torch.cuda.synchronize()
+    res['build_graph_batch (128 frames) ms'] = (time.perf_counter() - t0) / 20 * 1e3
+
     # kernel-level rates at batch size
     B = 64
     s1, r1, _ = features.cells_to_edges(cells)
