@@ -66,11 +66,13 @@ __global__ __launch_bounds__(WG, 3) void mlp_fwd_kernel(const hgn_mlp_fwd_t a) {
   STAMP(1);
   relu_inplace(acc);
   if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
+  if (a.relu_bits && valid) a.relu_bits[row * 8 + kq] = relu_bits_of(acc);
   // ---- layer 2 ------------------------------------------------------------------------------------------
   gemm_n(b, acc, wlds, a.W2, LAT, 128, 128, [&] { t_load(b, a.b2, kq); });      // b := b2 + W2 * acc
   STAMP(2);
   relu_inplace(b);
   if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
+  if (a.relu_bits && valid) a.relu_bits[row * 8 + 4 + kq] = relu_bits_of(b);
   // ---- layer 3 ------------------------------------------------------------------------------------------
   gemm_n(acc, b, wlds, a.W3, LAT, a.out_w, 128, [&] {
     if (a.out_w == LAT) t_load(acc, a.b3, kq); else t_load_masked(acc, a.b3, kq, a.out_w);
@@ -122,6 +124,8 @@ __global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
   const long rc = valid ? row : a.M - 1;
 
   Act g, t;
+  unsigned mb1 = 0, mb2 = 0;
+  if (a.relu_bits) { mb1 = a.relu_bits[rc * 8 + kq]; mb2 = a.relu_bits[rc * 8 + 4 + kq]; }
   // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
   gemm_t(t, g, wlds, a.W3, LAT, a.out_w, 128, [&] {
     load_dout<false>(g, a, rc, kq);
@@ -158,11 +162,11 @@ __global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
     if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
     t_zero(t);
   });
-  relu_mask(t, a.z2 + rc * LAT, kq);
+  if (a.relu_bits) relu_mask_bits(t, mb2); else relu_mask(t, a.z2 + rc * LAT, kq);
   if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
   gemm_t(g, t, wlds, a.W2, LAT, 128, 128, [&] { t_zero(g); });
-  relu_mask(g, a.z1 + rc * LAT, kq);
+  if (a.relu_bits) relu_mask_bits(g, mb1); else relu_mask(g, a.z1 + rc * LAT, kq);
   if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
   // ---- dx_src = dz1 * W1[:, cols]  (+ d_out_eff for the residual source) -----------------------------------
   for (int di = 0; di < a.n_dx; ++di) {
@@ -308,7 +312,7 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   if (a->M < 0 || a->n_dx < 0 || a->n_dx > HGN_MAX_SRC) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad counts");
   if (a->out_w < 1 || a->out_w > 128 || (a->ln_g && (a->out_w != 128 || !a->xhat || !a->rstd)))
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad out_w / LayerNorm");
-  if ((!a->d_out && !a->agg_dout) || !a->z1 || !a->z2 || !a->W2 || !a->W3) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: null pointer");
+  if ((!a->d_out && !a->agg_dout) || (!a->relu_bits && (!a->z1 || !a->z2)) || !a->W2 || !a->W3) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: null pointer");
   if (a->agg_dout) {
     if (a->out_w != 128 || a->n_agg_ops < 1 || a->n_agg_ops > 4 || !a->agg_seg || !a->agg_rowptr || (a->ld_agg & 3) ||
         !aligned16(a->agg_dout))

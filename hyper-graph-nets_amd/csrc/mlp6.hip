@@ -75,6 +75,9 @@ __device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf
   unsigned lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const unsigned wave = threadIdx.x >> 6;
+#ifdef EXP_NO_DMA
+  return;
+#endif
 #pragma unroll
   for (unsigned i = wave; i < HALF_TILES; i += WG / 64)          // one operand tile (1 KiB) per wave instruction
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
@@ -93,6 +96,9 @@ __device__ __forceinline__ void mfma_half6(Act& acc, const bf16x8 (&xs)[3][4], c
       const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
       const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(lds + ((2 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
       f32x4 t = acc.v[ob];
+#ifdef EXP_NO_MFMA
+      continue;
+#endif
       t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, xs[0][c], t, 0, 0, 0);      // smallest terms first
       t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[2][c], t, 0, 0, 0);
       t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[1][c], t, 0, 0, 0);
@@ -106,19 +112,37 @@ __device__ __forceinline__ void mfma_half6(Act& acc, const bf16x8 (&xs)[3][4], c
 
 // acc[ob] += Wblock * b for one packed 128 x 128 block.  `between()` runs after the first half's DMA has been issued and
 // before the wait (the caller's own global loads fly with it); `b` is split after the wait, so `between` may load it.
-template <class F>
-__device__ __forceinline__ void gemm6(Act& acc, const Act& b, __bf16* __restrict__ lds, const __bf16* __restrict__ pk, F&& between) {
+// `late()` runs after the LAST wait of the block, just before the second half's MFMAs: the place for global STORES -- every
+// wait for a weight DMA is a full vmcnt(0) drain (loads and stores share the counter), so a store issued anywhere else is
+// waited for by the next DMA wait a few hundred cycles later; from here it has half a block of MFMAs, a barrier and the next
+// DMA's latency to complete.
+// `early()` runs right after the first wait (b is still live there at no register cost): the stores then have the first
+// half's MFMAs before the next drain.
+template <class F, class E, class G>
+__device__ __forceinline__ void gemm6(Act& acc, const Act& b, __bf16* __restrict__ lds, const __bf16* __restrict__ pk, F&& between,
+                                      E&& early, G&& late) {
   bf16x8 xs[3][4];
   wg_barrier_lds();
   stage_half6(lds, pk);
   between();
   __syncthreads();
+  early();
   split3(b, xs);
   mfma_half6<0>(acc, xs, lds);
   wg_barrier_lds();
   stage_half6(lds, pk + HALF_BF16);
   __syncthreads();
+  late();
   mfma_half6<1>(acc, xs, lds);
+}
+template <class F>
+__device__ __forceinline__ void gemm6(Act& acc, const Act& b, __bf16* __restrict__ lds, const __bf16* __restrict__ pk, F&& between) {
+  gemm6(acc, b, lds, pk, between, [] {}, [] {});
+}
+template <class F, class G>
+__device__ __forceinline__ void gemm6(Act& acc, const Act& b, __bf16* __restrict__ lds, const __bf16* __restrict__ pk, F&& between,
+                                      G&& late) {
+  gemm6(acc, b, lds, pk, between, [] {}, late);
 }
 
 __device__ __forceinline__ void relu6(Act& a) {
@@ -130,8 +154,11 @@ __device__ __forceinline__ void relu6(Act& a) {
 // ----------------------------------------------------------------------------------------------------------
 // forward (all sources 128-wide multiples, output 128 wide): same contract as mlp_fwd_kernel
 // ----------------------------------------------------------------------------------------------------------
+#ifndef EXP_LDS_PAD
+#define EXP_LDS_PAD 0
+#endif
 __global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16 + EXP_LDS_PAD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
@@ -160,11 +187,16 @@ __global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) 
     }
   }
   relu6(acc);
-  if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
-  gemm6(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] { t_load(b, a.b2, kq); });
+  // b := b2 + W2 * acc; the first hidden layer (acc) is stored from inside the block (see gemm6: `late`)
+  gemm6(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] { t_load(b, a.b2, kq); }, [&] {
+    if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
+    if (a.relu_bits && valid) a.relu_bits[row * 8 + kq] = relu_bits_of(acc);
+  });
   relu6(b);
-  if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
-  gemm6(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] { t_load(acc, a.b3, kq); });
+  gemm6(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] { t_load(acc, a.b3, kq); }, [&] {
+    if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
+    if (a.relu_bits && valid) a.relu_bits[row * 8 + 4 + kq] = relu_bits_of(b);
+  });
   if (a.ln_g) {
     const float mean = row_sum(acc) * (1.f / LAT);
     HGN_FOR_B(fb) {
@@ -183,7 +215,9 @@ __global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) 
     }
   }
   if (valid) {
+#ifndef EXP_NO_RES
     if (a.res) t_add(acc, a.res + row * a.ld_res, kq);
+#endif
     t_store(acc, a.out + row * a.ld_out, kq);
   }
 }
@@ -222,11 +256,14 @@ __global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) 
   const long rc = valid ? row : a.M - 1;
 
   Act g, t;
+  unsigned mb1 = 0, mb2 = 0;
+  if (a.relu_bits) { mb1 = a.relu_bits[rc * 8 + kq]; mb2 = a.relu_bits[rc * 8 + 4 + kq]; }
   // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
   gemm6(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
     load_dout<false>(g, a, rc, kq);
     if (a.ln_g) {
       t_load(t, a.xhat + rc * LAT, kq);
+#ifndef EXP_NO_LNWS
       if (a.ln_ws) {
         HGN_FOR_B(fb) {
 #pragma unroll
@@ -239,6 +276,7 @@ __global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) 
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#endif
       HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
       const float m1 = row_sum(g) * (1.f / LAT);
       float q0 = 0.f, q1 = 0.f;
@@ -253,16 +291,22 @@ __global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) 
       const float r = a.rstd[rc];
       HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
     }
+#ifndef EXP_NO_DZ_STORE
     if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
+#endif
     t_zero(t);
   });
-  relu_mask(t, a.z2 + rc * LAT, kq);
-  if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
+  if (a.relu_bits) relu_mask_bits(t, mb2); else relu_mask(t, a.z2 + rc * LAT, kq);
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
+#ifndef EXP_NO_DZ_STORE
+  if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
+#endif
   gemm6(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] { t_zero(g); });
-  relu_mask(g, a.z1 + rc * LAT, kq);
-  if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
+  if (a.relu_bits) relu_mask_bits(g, mb1); else relu_mask(g, a.z1 + rc * LAT, kq);
   // ---- dx_src = dz1 * W1[:, cols]  (+ d_out_eff for the residual source) -----------------------------------
+#ifndef EXP_NO_DZ_STORE
+  if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
+#endif
   for (int di = 0; di < a.n_dx; ++di) {
     const hgn_dx_t d = a.dx[di];
     const __bf16* pk = reinterpret_cast<const __bf16*>(d.Wpk_t);
@@ -270,7 +314,9 @@ __global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) 
       gemm6(t, g, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] { t_zero(t); });
       if (valid) {
         float* dst = d.dx + row * d.ld + k0;
+#ifndef EXP_NO_RES
         if (d.residual) load_dout<true>(t, a, rc, kq);
+#endif
         t_store(t, dst, kq);
       }
     }

@@ -13,6 +13,21 @@ __device__ __forceinline__ void relu_mask(Act& g, const float* __restrict__ zrow
   }
 }
 
+// ReLU sign pattern of the lane's 32 values as one word (bit 4*fb + u <-> unit 16*fb + 4*kq + u; hgn_mlp_fwd_t.relu_bits)
+__device__ __forceinline__ unsigned relu_bits_of(const Act& a) {
+  unsigned m = 0;
+  HGN_FOR_B(fb)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m |= (a.v[fb][u] > 0.f ? 1u : 0u) << (4 * fb + u);
+  return m;
+}
+
+__device__ __forceinline__ void relu_mask_bits(Act& g, unsigned m) {
+  HGN_FOR_B(fb)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g.v[fb][u] = (m >> (4 * fb + u)) & 1u ? g.v[fb][u] : 0.f;
+}
+
 // d_out_eff of the lane's row: d_out (optional) + the aggregation backward scattered back through the CSR row of the edge.
 template <bool ACC>
 __device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {

@@ -156,7 +156,8 @@ class GraphNet(nn.Module):
         """nodes[which] += LN(MLP([h ; agg_1 ; agg_2 ...][rows of `which`]))   (graphnet.py:47-48,107-108,123-124).
         The concatenation is never materialised: every aggregate is its own K-segment of the first Linear."""
         n_mesh = lat.n_mesh
-        srcs = [lat.nodes[which]] + [(a[:n_mesh] if which == 0 else a[n_mesh:]) for a in aggs]
+        # (no slice when there are no hyper rows: its backward would zero-fill and copy a full [N, k*128] gradient)
+        srcs = [lat.nodes[which]] + [(a if a.shape[0] == n_mesh else a[:n_mesh]) if which == 0 else a[n_mesh:] for a in aggs]
         lat.nodes[which] = fused_apply(model, srcs, residual=0)
 
     # -- GraphNet.forward (graphnet.py:72-84) --------------------------------------------------------------------

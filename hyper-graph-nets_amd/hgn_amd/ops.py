@@ -140,8 +140,8 @@ def _fill_common_fwd(a: _lib.MlpFwd, w: MLPWeights, out, res, saves):
         a.res = res.data_ptr(); a.ld_res = _ld(res)
     a.out = out.data_ptr(); a.ld_out = _ld(out)
     if saves is not None:
-        z1, z2, xhat, rstd = saves
-        a.z1 = z1.data_ptr(); a.z2 = z2.data_ptr()
+        z1, z2, xhat, rstd, bits = saves
+        a.z1 = z1.data_ptr(); a.z2 = z2.data_ptr(); a.relu_bits = bits.data_ptr()
         if xhat is not None:
             a.xhat = xhat.data_ptr(); a.rstd = rstd.data_ptr()
 
@@ -151,7 +151,8 @@ def _alloc_saves(M, has_ln, dev):
     z2 = torch.empty(M, LAT, device=dev)
     xhat = torch.empty(M, LAT, device=dev) if has_ln else None
     rstd = torch.empty(M, device=dev) if has_ln else None
-    return z1, z2, xhat, rstd
+    bits = torch.empty(M, 8, dtype=torch.int32, device=dev)      # ReLU sign patterns: what the backward chain reads instead of z1 / z2
+    return z1, z2, xhat, rstd, bits
 
 
 def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False, keep=()):
@@ -272,7 +273,7 @@ class MLPFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         srcs, wt = saved[:n_src], saved[n_src:]
         w = MLPWeights(*wt)
-        z1, z2, xhat, rstd = ctx.saves
+        z1, z2, xhat, rstd, bits = ctx.saves
         dev = d_out.device
         d_out = _rowmajor(d_out)
         L = _lib.lib()
@@ -285,7 +286,7 @@ class MLPFn(torch.autograd.Function):
         b.d_out = d_out.data_ptr(); b.ld_dout = _ld(d_out); b.out_w = out_w
         if has_ln:
             b.ln_g = w.ln_w.data_ptr(); b.xhat = xhat.data_ptr(); b.rstd = rstd.data_ptr()
-        b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr()
+        b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr(); b.relu_bits = bits.data_ptr()
         b.W3 = w.w3.data_ptr(); b.W2 = w.w2.data_ptr(); b.ldw1 = w.w1.shape[1]
         b.dz3 = dz3.data_ptr(); b.dz2 = dz2.data_ptr(); b.dz1 = dz1.data_ptr()
         dxs = [None] * n_src
@@ -424,7 +425,7 @@ class EdgeBlockFn(torch.autograd.Function):
         topo = ctx.topo
         h_all, e, *wt = ctx.saved_tensors
         w = MLPWeights(*wt)
-        z1, z2, xhat, rstd = ctx.saves
+        z1, z2, xhat, rstd, bits = ctx.saves
         agg_ops, amax, amin = ctx.agg
         L = _lib.lib()
         E, N = topo.num_edges, topo.num_nodes
@@ -453,7 +454,7 @@ class EdgeBlockFn(torch.autograd.Function):
             b.agg_argmax = amax.data_ptr() if amax is not None else None
             b.agg_argmin = amin.data_ptr() if amin is not None else None
         b.ln_g = w.ln_w.data_ptr(); b.xhat = xhat.data_ptr(); b.rstd = rstd.data_ptr()
-        b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr()
+        b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr(); b.relu_bits = bits.data_ptr()
         b.W3 = w.w3.data_ptr(); b.W2 = w.w2.data_ptr(); b.ldw1 = 3 * LAT
         b.dz3 = dz3.data_ptr(); b.dz2 = dz2.data_ptr(); b.dz1 = dz1.data_ptr()
         b.n_dx = 1

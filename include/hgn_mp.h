@@ -113,6 +113,10 @@ typedef struct {
   float* out; int64_t ld_out;
   float* z1; float* z2; float* xhat; float* rstd;   /* nullable saves [M,128] x3, [M]   */
   const void* W2pk; const void* W3pk;     /* optional packed images of W2 / W3 (forward form); see hgn_pack_bf16x3 */
+  /* optional save [M][8] words: the ReLU sign pattern of both hidden layers, so that the backward chain reads 32 bytes per
+   * row instead of the two [M,128] fp32 activations: word 4*l + q of a row (l = 0: first hidden layer, 1: second) holds,
+   * in bit 4*b + u, whether hidden unit 16*b + 4*q + u is active (> 0) */
+  uint32_t* relu_bits;
 } hgn_mlp_fwd_t;
 
 int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
@@ -169,6 +173,7 @@ typedef struct {
    * ln_ws: hgn_mlp_bwd_ln_workspace_bytes(M) bytes. */
   float* d_gamma; float* d_beta; float* ln_ws; int32_t ln_accumulate;
   const void* W3pk_t; const void* W2pk_t;   /* optional packed images of W3 / W2 (transposed form): split-bf16 kernels */
+  const uint32_t* relu_bits;                /* optional: the forward's relu_bits; z1 / z2 may be null then            */
 } hgn_mlp_bwd_t;
 
 int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes /*host*/);
