@@ -294,6 +294,8 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   const int kid = a->n_add ? 0 : 1;
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
+  if (a->seg_out && (!a->seg_ids || a->out_w != 128 || a->ld_seg_out < 128 || !hgn_mlp_fwd6_eligible(a)))
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: seg_out needs seg_ids, a 128-wide output and the split-bf16 kernel");
   if (hgn_mlp_fwd6_eligible(a)) return launch_mlp6_fwd(a, stream);
   hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   return hgn_check_launch("hgn_mlp_fwd");
@@ -330,6 +332,8 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   const int kid = (a->n_dx == 1 && a->dx[0].residual && a->dz1) ? 2 : 3;
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
+  if (a->seg_dz1 && (!a->seg_ids || a->ld_seg_dz1 < 128 || !hgn_mlp_bwd6_eligible(a)))
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: seg_dz1 needs seg_ids and the split-bf16 kernel");
   if (hgn_mlp_bwd6_eligible(a)) {
     if (launch_mlp6_bwd(a, stream) != HGN_OK) return HGN_E_LAUNCH;
   } else {

@@ -159,6 +159,7 @@ __device__ __forceinline__ void relu6(Act& a) {
 #endif
 __global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16 + EXP_LDS_PAD];
+  static_assert(HALF_BF16 * 2 >= SEG_LDS_FLOATS * 4, "the weight stage doubles as the segment-sum tile");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
@@ -187,6 +188,15 @@ __global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) 
     }
   }
   relu6(acc);
+#ifdef EXP_FWD_INPLACE
+  if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
+  if (a.relu_bits && valid) a.relu_bits[row * 8 + kq] = relu_bits_of(acc);
+  gemm6(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] { t_load(b, a.b2, kq); });
+  relu6(b);
+  if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
+  if (a.relu_bits && valid) a.relu_bits[row * 8 + 4 + kq] = relu_bits_of(b);
+  gemm6(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] { t_load(acc, a.b3, kq); });
+#else
   // b := b2 + W2 * acc; the first hidden layer (acc) is stored from inside the block (see gemm6: `late`)
   gemm6(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] { t_load(b, a.b2, kq); }, [&] {
     if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
@@ -197,6 +207,7 @@ __global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) 
     if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
     if (a.relu_bits && valid) a.relu_bits[row * 8 + 4 + kq] = relu_bits_of(b);
   });
+#endif
   if (a.ln_g) {
     const float mean = row_sum(acc) * (1.f / LAT);
     HGN_FOR_B(fb) {
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) 
 #endif
     t_store(acc, a.out + row * a.ld_out, kq);
   }
+  if (a.seg_out) tile_segment_sum(acc, reinterpret_cast<float*>(lds), a.seg_ids, a.seg_out, a.ld_seg_out, xcd_tile() * TILE_ROWS, a.M);
 }
 
 // single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
@@ -247,6 +259,7 @@ __global__ __launch_bounds__(WG, 3) void linear6_fwd_kernel(const Lin6Args a) {
 // ----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) {
   __shared__ __attribute__((aligned(16))) float ldsf[HALF_BF16 / 2 + (WG / 64) * 256];
+  static_assert(HALF_BF16 / 2 >= SEG_LDS_FLOATS, "the weight stage doubles as the segment-sum tile");
   __bf16* lds = reinterpret_cast<__bf16*>(ldsf);
   float* lnl = ldsf + HALF_BF16 / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -256,57 +269,64 @@ __global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) 
   const long rc = valid ? row : a.M - 1;
 
   Act g, t;
-  unsigned mb1 = 0, mb2 = 0;
-  if (a.relu_bits) { mb1 = a.relu_bits[rc * 8 + kq]; mb2 = a.relu_bits[rc * 8 + 4 + kq]; }
+  // (eligibility guarantees LayerNorm, its workspace and the ReLU sign words: straight-line code, no optional parts)
+  const unsigned mb1 = a.relu_bits[rc * 8 + kq], mb2 = a.relu_bits[rc * 8 + 4 + kq];
   // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
   gemm6(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
     load_dout<false>(g, a, rc, kq);
-    if (a.ln_g) {
-      t_load(t, a.xhat + rc * LAT, kq);
+    t_load(t, a.xhat + rc * LAT, kq);
 #ifndef EXP_NO_LNWS
-      if (a.ln_ws) {
-        HGN_FOR_B(fb) {
+    HGN_FOR_B(fb) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            float pb = valid ? g.v[fb][u] : 0.f;
-            float pg = row16_sum(pb * t.v[fb][u]);
-            pb = row16_sum(pb);
-            if (n == 0) { lnl[wave * 256 + 16 * fb + 4 * kq + u] = pg; lnl[wave * 256 + 128 + 16 * fb + 4 * kq + u] = pb; }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int u = 0; u < 4; ++u) {
+        float pb = valid ? g.v[fb][u] : 0.f;
+        float pg = row16_sum(pb * t.v[fb][u]);
+        pb = row16_sum(pb);
+        if (n == 0) { lnl[wave * 256 + 16 * fb + 4 * kq + u] = pg; lnl[wave * 256 + 128 + 16 * fb + 4 * kq + u] = pb; }
       }
-#endif
-      HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
-      const float m1 = row_sum(g) * (1.f / LAT);
-      float q0 = 0.f, q1 = 0.f;
-      HGN_FOR_B(fb) {
-        q0 += g.v[fb][0] * t.v[fb][0] + g.v[fb][1] * t.v[fb][1];
-        q1 += g.v[fb][2] * t.v[fb][2] + g.v[fb][3] * t.v[fb][3];
-      }
-      float qs = q0 + q1;
-      qs += __shfl_xor(qs, 16);
-      qs += __shfl_xor(qs, 32);
-      const float m2 = qs * (1.f / LAT);
-      const float r = a.rstd[rc];
-      HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#ifndef EXP_NO_DZ_STORE
+#endif
+    HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+    const float m1 = row_sum(g) * (1.f / LAT);
+    float q0 = 0.f, q1 = 0.f;
+    HGN_FOR_B(fb) {
+      q0 += g.v[fb][0] * t.v[fb][0] + g.v[fb][1] * t.v[fb][1];
+      q1 += g.v[fb][2] * t.v[fb][2] + g.v[fb][3] * t.v[fb][3];
+    }
+    float qs = q0 + q1;
+    qs += __shfl_xor(qs, 16);
+    qs += __shfl_xor(qs, 32);
+    const float m2 = qs * (1.f / LAT);
+    const float r = a.rstd[rc];
+    HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
+#if !defined(EXP_NO_DZ_STORE) && !defined(EXP_BWD_EARLY)
     if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
 #endif
     t_zero(t);
-  });
-  if (a.relu_bits) relu_mask_bits(t, mb2); else relu_mask(t, a.z2 + rc * LAT, kq);
+  }, [&] {
+#if !defined(EXP_NO_DZ_STORE) && defined(EXP_BWD_EARLY)
+    if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
+#endif
+  }, [] {});
+  relu_mask_bits(t, mb2);
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
-#ifndef EXP_NO_DZ_STORE
+#if !defined(EXP_NO_DZ_STORE) && !defined(EXP_BWD_EARLY)
   if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
 #endif
-  gemm6(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] { t_zero(g); });
-  if (a.relu_bits) relu_mask_bits(g, mb1); else relu_mask(g, a.z1 + rc * LAT, kq);
+  gemm6(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] { t_zero(g); }, [&] {
+#if !defined(EXP_NO_DZ_STORE) && defined(EXP_BWD_EARLY)
+    if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
+#endif
+  }, [] {});
+  relu_mask_bits(g, mb1);
   // ---- dx_src = dz1 * W1[:, cols]  (+ d_out_eff for the residual source) -----------------------------------
 #ifndef EXP_NO_DZ_STORE
   if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
 #endif
+  // receiver sums of dz1 while the tile is still in registers (the stage buffer is free between two blocks; the next block's
+  // opening barrier orders the reads below before its weight DMA)
+  if (a.seg_dz1) tile_segment_sum(g, ldsf, a.seg_ids, a.seg_dz1, a.ld_seg_dz1, xcd_tile() * TILE_ROWS, a.M);
   for (int di = 0; di < a.n_dx; ++di) {
     const hgn_dx_t d = a.dx[di];
     const __bf16* pk = reinterpret_cast<const __bf16*>(d.Wpk_t);
@@ -321,13 +341,11 @@ __global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) 
       }
     }
   }
-  if (a.ln_ws) {
-    __syncthreads();
-    float sum = 0.f;
+  __syncthreads();
+  float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < WG / 64; ++w) sum += lnl[w * 256 + threadIdx.x];
-    a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
-  }
+  for (int w = 0; w < WG / 64; ++w) sum += lnl[w * 256 + threadIdx.x];
+  a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
 __global__ __launch_bounds__(WG, 3) void linear6_bwd_kernel(const Lin6Args a) {
@@ -401,7 +419,7 @@ extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const voi
 }
 
 extern "C" int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* a) {
-  if (!a || a->out_w != 128 || !a->W3pk_t || !a->W2pk_t) return 0;
+  if (!a || a->out_w != 128 || !a->W3pk_t || !a->W2pk_t || !a->ln_g || !a->xhat || !a->rstd || !a->ln_ws || !a->relu_bits) return 0;
   for (int i = 0; i < a->n_dx; ++i) {
     const hgn_dx_t& d = a->dx[i];
     if (!d.Wpk_t || (d.K & 127) || (d.ld & 3) || !aligned16(d.dx)) return 0;

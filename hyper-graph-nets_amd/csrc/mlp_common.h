@@ -28,6 +28,75 @@ __device__ __forceinline__ void relu_mask_bits(Act& g, unsigned m) {
     for (int u = 0; u < 4; ++u) g.v[fb][u] = (m >> (4 * fb + u)) & 1u ? g.v[fb][u] : 0.f;
 }
 
+// Segment sums of the workgroup's 64 x 128 tile `v` (rows sorted by segment id) into out[seg][0..128): the tile goes through
+// LDS (row stride 132 floats: conflict-free 16-byte writes), then thread (half, c) walks column c down 32 rows.  Segments
+// that lie inside the tile are stored; the first / last one is added atomically when it continues in the neighbouring tile
+// (two contributions onto a zero-filled row: order independent).  The half-1 threads hand the part of a segment that began
+// in half 0 over through LDS, so every segment is written once per tile.  `ldsf`: SEG_LDS_FLOATS floats, free for use; the
+// caller must put a workgroup barrier between this call and the next write to `ldsf`.
+constexpr int SEG_LDS_FLOATS = 64 * 132 + 64 + 128;
+__device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict__ ldsf, const int32_t* __restrict__ seg_ids,
+                                                 float* __restrict__ out, long ld, long tile_row0, long M) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  int* ids = reinterpret_cast<int*>(ldsf + 64 * 132);
+  float* hp = ldsf + 64 * 132 + 64;
+  __syncthreads();                                          // every wave is done with the weight stage
+  float* wr = ldsf + (wave * WAVE_ROWS + n) * 132 + 4 * kq;
+  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(wr + 16 * fb) = v.v[fb];
+  const int rows = (int)min((long)TILE_ROWS, M - tile_row0);
+  if (threadIdx.x < 64) ids[threadIdx.x] = threadIdx.x < rows ? seg_ids[tile_row0 + threadIdx.x] : -1;
+  __syncthreads();
+  const int half = threadIdx.x >> 7, c = threadIdx.x & 127;
+  const int r0 = 32 * half, r1 = min(rows, r0 + 32);
+  const bool active = r0 < rows;
+  const bool tile_cont_prev = tile_row0 > 0 && seg_ids[tile_row0 - 1] == ids[0];
+  const bool tile_cont_next = tile_row0 + rows < M && seg_ids[tile_row0 + rows] == ids[rows - 1];
+  int cur = -1;
+  float s = 0.f;
+  bool first = true;                                        // still inside the segment my range began with
+  bool cont_prev = false;                                   // ... and that segment began before my range
+  if (active) {
+    cur = ids[r0];
+    cont_prev = half ? ids[r0 - 1] == cur : tile_cont_prev;
+    for (int rb = r0; rb < r1; rb += 8) {
+      float x[8]; int id[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = min(rb + j, r1 - 1);
+        x[j] = ldsf[r * 132 + c]; id[j] = ids[r];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (rb + j < r1) {
+          if (id[j] != cur) {
+            float* dst = out + (long)cur * ld + c;
+            if (first && cont_prev) { if (half) hp[c] = s; else unsafeAtomicAdd(dst, s); }
+            else *dst = s;
+            cur = id[j]; s = 0.f; first = false;
+          }
+          s += x[j];
+        }
+      }
+    }
+    if (half) {                                             // my open last segment is the tile's last one
+      if (first && cont_prev) hp[c] = s;                    // all my rows continue half 0's last segment
+      else {
+        float* dst = out + (long)cur * ld + c;
+        if (tile_cont_next) unsafeAtomicAdd(dst, s); else *dst = s;
+      }
+    }
+  }
+  __syncthreads();
+  if (!half && active) {
+    const bool joined = rows > 32 && ids[32] == cur;        // half 1 began inside my last segment
+    const float total = s + (joined ? hp[c] : 0.f);
+    const bool to_end = joined ? ids[rows - 1] == cur : rows <= 32;     // the segment runs to the end of the tile
+    float* dst = out + (long)cur * ld + c;
+    if ((first && cont_prev) || (to_end && tile_cont_next)) unsafeAtomicAdd(dst, total); else *dst = total;
+  }
+}
+
 // d_out_eff of the lane's row: d_out (optional) + the aggregation backward scattered back through the CSR row of the edge.
 template <bool ACC>
 __device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {

@@ -37,7 +37,7 @@ class MlpFwd(C.Structure):
                 ('W3', c_f32p), ('b3', c_f32p), ('out_w', C.c_int32), ('ln_g', c_f32p), ('ln_b', c_f32p),
                 ('res', c_f32p), ('ld_res', C.c_int64), ('out', c_f32p), ('ld_out', C.c_int64), ('z1', c_f32p),
                 ('z2', c_f32p), ('xhat', c_f32p), ('rstd', c_f32p), ('W2pk', C.c_void_p), ('W3pk', C.c_void_p),
-                ('relu_bits', C.c_void_p)]
+                ('relu_bits', C.c_void_p), ('seg_out', c_f32p), ('ld_seg_out', C.c_int64), ('seg_ids', c_i32p)]
 
 
 class Dx(C.Structure):
@@ -53,7 +53,8 @@ class MlpBwd(C.Structure):
                 ('agg_dout', c_f32p), ('ld_agg', C.c_int64), ('n_agg_ops', C.c_int32), ('agg_ops', C.c_int32 * 4),
                 ('agg_seg', c_i32p), ('agg_rowptr', c_i32p), ('agg_argmax', c_i32p), ('agg_argmin', c_i32p),
                 ('d_gamma', c_f32p), ('d_beta', c_f32p), ('ln_ws', c_f32p), ('ln_accumulate', C.c_int32),
-                ('W3pk_t', C.c_void_p), ('W2pk_t', C.c_void_p), ('relu_bits', C.c_void_p)]
+                ('W3pk_t', C.c_void_p), ('W2pk_t', C.c_void_p), ('relu_bits', C.c_void_p),
+                ('seg_dz1', c_f32p), ('ld_seg_dz1', C.c_int64), ('seg_ids', c_i32p)]
 
 
 class WTask(C.Structure):

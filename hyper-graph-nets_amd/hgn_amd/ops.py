@@ -81,6 +81,7 @@ class MLPWeights:
 # packed weight images for the split-bf16 kernels (include/hgn_mp.h: hgn_pack_bf16x3)
 # ------------------------------------------------------------------------------------------------------------
 _pack_epoch = 0
+_FUSED_SEG_MAX_ROWS = 65      # a segment of <= 65 consecutive rows touches at most two 64-row tiles
 _FP32_ONLY = bool(__import__('os').environ.get('HGN_FP32_MFMA'))
 
 
@@ -394,10 +395,17 @@ class EdgeBlockFn(torch.autograd.Function):
         a.add[1].P = P.data_ptr() + 4 * LAT; a.add[1].ld = 2 * LAT; a.add[1].idx = topo.rcv.data_ptr()
         saves = _alloc_saves(E, True, dev) if train else None
         _fill_common_fwd(a, w, out, e, saves)
+        agg, amax, amin = None, None, None
+        # `sum` aggregation inside the edge kernel itself (no second pass over e') when the segments are short enough for the
+        # in-kernel sums to be order independent (include/hgn_mp.h: seg_out)
+        fuse_agg = (agg_ops == ('sum',) and pk is not None and 0 < E and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
+                    and L.hgn_mlp_fwd6_eligible(C.byref(a)))
+        if fuse_agg:
+            agg = torch.zeros(N, LAT, device=dev)
+            a.seg_out = agg.data_ptr(); a.ld_seg_out = LAT; a.seg_ids = topo.rcv.data_ptr()
         if E > 0:
             _lib.check(L.hgn_mlp_fwd(C.byref(a), st), 'hgn_mlp_fwd')
-        agg, amax, amin = None, None, None
-        if agg_ops is not None:
+        if agg_ops is not None and not fuse_agg:
             arr, codes = _ops_array(agg_ops)
             k = len(codes)
             agg = torch.empty(N, k * LAT, device=dev)
@@ -469,6 +477,14 @@ class EdgeBlockFn(torch.autograd.Function):
         dw1, db1, dw2, db2, dw3, db3, dg, dbt = bufs
         b.d_gamma = dg.data_ptr(); b.d_beta = dbt.data_ptr(); b.ln_accumulate = accs[6]
         b.ln_ws = _ln_workspace(E, dev).data_ptr()
+        # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]; the receiver half comes out of the
+        # backward kernel itself when the segments are short (include/hgn_mp.h: seg_dz1)
+        dP = torch.empty(N, 2 * LAT, device=dev)
+        fuse_seg = (pk_t is not None and E > 0 and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
+                    and L.hgn_mlp_bwd6_eligible(C.byref(b)))
+        if fuse_seg:
+            dP[:, LAT:].zero_()
+            b.seg_dz1 = dP.data_ptr() + 4 * LAT; b.ld_seg_dz1 = 2 * LAT; b.seg_ids = topo.rcv.data_ptr()
         if E > 0:
             _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
         elif not accs[6]:
@@ -478,13 +494,12 @@ class EdgeBlockFn(torch.autograd.Function):
                  _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
                         db1.data_ptr(), accs[0])]
         _run_wgrad(tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
-        # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]
-        dP = torch.empty(N, 2 * LAT, device=dev)
         ops = (C.c_int32 * 1)(0)
         _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N,
                                             ops, 1, dP.data_ptr(), 2 * LAT, None, None, st), 'segment_reduce(senders)')
-        _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr(), N, ops, 1,
-                                            dP.data_ptr() + 4 * LAT, 2 * LAT, None, None, st), 'segment_reduce(receivers)')
+        if not fuse_seg:
+            _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr(), N, ops, 1,
+                                                dP.data_ptr() + 4 * LAT, 2 * LAT, None, None, st), 'segment_reduce(receivers)')
         tasks = [_wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr(), 2 * LAT, LAT, dw1.data_ptr(), 3 * LAT, None,
                         accs[0]),
                  _wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr() + 4 * LAT, 2 * LAT, LAT,

@@ -15,7 +15,7 @@ from . import _lib
 
 class CSR:
     """perm[j] = original position of sorted element j (stable), seg[j] = its segment id, rowptr[n..n+1] its row."""
-    __slots__ = ('perm', 'seg', 'rowptr', 'num_segments', 'num_items')
+    __slots__ = ('perm', 'seg', 'rowptr', 'num_segments', 'num_items', 'max_rows')
 
     def __init__(self, ids: torch.Tensor, num_segments: int):
         _lib.require_gpu(ids)
@@ -34,6 +34,9 @@ class CSR:
                    'hgn_csr_build')
         self.num_segments = num_segments
         self.num_items = E
+        # longest segment (hgn_csr_build has synchronised already): the fused in-kernel segment sums of the edge MLP kernels
+        # are bit-reproducible only while no segment spans more than two 64-row tiles (include/hgn_mp.h: seg_out)
+        self.max_rows = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if (E > 0 and num_segments > 0) else 0
 
 
 class EdgeTopology:

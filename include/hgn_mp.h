@@ -117,6 +117,13 @@ typedef struct {
    * row instead of the two [M,128] fp32 activations: word 4*l + q of a row (l = 0: first hidden layer, 1: second) holds,
    * in bit 4*b + u, whether hidden unit 16*b + 4*q + u is active (> 0) */
   uint32_t* relu_bits;
+  /* optional, split-bf16 kernel only (hgn_mlp_fwd6_eligible): segment sum of the OUTPUT rows in the same pass --
+   *   seg_out[seg_ids[i]][0..128) += out[i]   for rows sorted by seg_ids (the receiver-sorted edge order: this is the `sum`
+   * aggregation of graphnet.py:50-70 without a second pass over the edge latents).  seg_out must be zero-filled by the
+   * caller (segments without rows stay 0).  Segments inside one 64-row tile are stored, the two at a tile's ends are added
+   * atomically: bit-reproducible as long as no segment spans more than two tiles (always true for <= 65 rows per segment;
+   * callers with larger segments use hgn_segment_reduce_fwd). */
+  float* seg_out; int64_t ld_seg_out; const int32_t* seg_ids;
 } hgn_mlp_fwd_t;
 
 int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
@@ -174,6 +181,9 @@ typedef struct {
   float* d_gamma; float* d_beta; float* ln_ws; int32_t ln_accumulate;
   const void* W3pk_t; const void* W2pk_t;   /* optional packed images of W3 / W2 (transposed form): split-bf16 kernels */
   const uint32_t* relu_bits;                /* optional: the forward's relu_bits; z1 / z2 may be null then            */
+  /* optional, split-bf16 kernel only: seg_dz1[seg_ids[i]][0..128) += dz1[i]  (same contract as hgn_mlp_fwd_t.seg_out): the
+   * receiver half of the pre-projection gradient of the split edge layer, without re-reading dz1 */
+  float* seg_dz1; int64_t ld_seg_dz1; const int32_t* seg_ids;
 } hgn_mlp_bwd_t;
 
 int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes /*host*/);

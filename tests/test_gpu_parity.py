@@ -214,6 +214,54 @@ def test_edge_block_vs_oracle(nx, ny):
         assert H.rel_err(t.grad, sdo[n].grad) <= TOL_GRAD, n
 
 
+@pytest.mark.parametrize('N,max_deg,seed', [(50, 65, 0), (700, 20, 1), (3, 65, 2), (1200, 9, 3)])
+def test_edge_block_fused_segment_sums(N, max_deg, seed):
+    """The `sum` aggregation of e' and the receiver half of the pre-projection gradient come out of the edge kernels themselves
+    (include/hgn_mp.h: seg_out / seg_dz1).  Ragged degrees 0..max_deg (segments crossing 64-row tile ends, empty segments, a
+    partial last tile): equal to the separate segment-reduce path within fp32 summation-order noise, and bit-reproducible."""
+    from hgn_amd import ops, topology
+    gen = torch.Generator().manual_seed(seed)
+    deg = torch.randint(0, max_deg + 1, (N,), generator=gen)
+    deg[torch.randint(0, N, (1,), generator=gen)] = max_deg
+    receivers = torch.repeat_interleave(torch.arange(N), deg)
+    E = receivers.shape[0]
+    shuffle = torch.randperm(E, generator=gen)
+    receivers = receivers[shuffle]
+    senders = torch.randint(0, N, (E,), generator=gen)
+    topo = topology.EdgeTopology(senders, receivers, N, torch.device('cuda'))
+    assert topo.r.max_rows == max_deg
+    sd = _mlp_sd(384, 128, True, seed=seed)
+    w, wts = _weights(sd, True)
+    h0 = torch.randn(N, 128, generator=gen).cuda()
+    e0 = torch.randn(E, 128, generator=gen).cuda()
+    w_y = torch.randn(E, 128, generator=gen).cuda()
+    w_a = torch.randn(N, 128, generator=gen).cuda()
+
+    def run():
+        for t in wts:
+            t.grad = None
+        h, e = h0.clone().requires_grad_(True), e0.clone().requires_grad_(True)
+        y, agg = ops.edge_block(h, e, topo, w, ('sum',))
+        ((y * w_y).sum() + (agg * w_a).sum()).backward()
+        return [y.detach(), agg.detach(), h.grad, e.grad] + [t.grad.clone() for t in wts]
+
+    fused = run()
+    again = run()
+    for a, b in zip(fused, again):
+        assert torch.equal(a, b)                                  # order-independent atomics: bit-reproducible
+    keep = ops._FUSED_SEG_MAX_ROWS
+    ops._FUSED_SEG_MAX_ROWS = -1                                  # the separate segment-reduce launches
+    try:
+        plain = run()
+    finally:
+        ops._FUSED_SEG_MAX_ROWS = keep
+    assert torch.equal(fused[0], plain[0])                        # e' itself does not depend on where it is summed
+    ref = torch.zeros(N, 128, dtype=torch.float64, device='cuda').index_add_(0, topo.rcv.long(), fused[0].double())
+    assert H.rel_err(fused[1], ref) <= 2e-6 and H.rel_err(plain[1], ref) <= 2e-6
+    for a, b in zip(fused[2:], plain[2:]):
+        assert H.rel_err(a, b) <= 5e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # a4 + whole model: goldens generated by the reference, and oracle parity for every block type
 # ---------------------------------------------------------------------------------------------------------------
