@@ -248,6 +248,12 @@ __device__ __forceinline__ void wg_dma_issue6(float* __restrict__ slotA, float* 
 }
 
 __device__ __forceinline__ void split3v(const float (&v)[8], bf16x8 (&s)[3]) {
+#ifdef EXP_CHEAP_SPLIT
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[0][j] = (__bf16)v[j]; }
+  s[1] = s[0]; s[2] = s[0];
+  return;
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const __bf16 h = (__bf16)v[j];
@@ -349,6 +355,109 @@ __global__ __launch_bounds__(WGW, 2) void wgrad6_kernel(const WArgs a) {
   if (threadIdx.x < 128) slab[128 * 128 + threadIdx.x] = lds[threadIdx.x] + lds[128 + threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-bf16 weight gradients, every value split ONCE: the two operand tiles of a 32-row contraction block (A and G, 32 x 128
+// fp32 each) are loaded straight into registers -- a lane takes four features of eight consecutive rows (eight 16-byte loads,
+// a half wave covers one whole 512-byte row) --, split into three bf16 terms there and written to LDS as ready-made MFMA
+// operand vectors (eight rows of one feature = one bf16x8), layout [array][split][row group][feature] so that operand reads
+// are linear ds_read_b128.  The rows of block p+1 are in flight while block p is multiplied.  Against wgrad6_kernel (each of
+// the four waves re-reads and re-splits the whole A tile): 32 instead of 80 values split per lane and block, 30 b128 reads
+// instead of 80 b32 reads; 48 KB of LDS, three workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int OPS_VEC = 2 * 3 * 4 * 128;          // bf16x8 vectors per block: [A|G][split][row group][feature]
+
+__global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16x8 ops[OPS_VEC];                 // 48 KB
+  const WTaskDev t = a.t[a.task0 + blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kg = lane >> 4;
+  const long row_beg = (long)blockIdx.x * a.rows_per_chunk;
+  const long row_end = min(a.M, row_beg + a.rows_per_chunk);
+  float* slab = t.slab + (long)blockIdx.x * SLAB;
+  const int nblocks = row_beg < row_end ? (int)((row_end - row_beg + 31) / 32) : 0;
+  // producer role of this lane: array (waves 0,1: A; waves 2,3: G), row group of the block, feature quad
+  const int arr = wave >> 1, kgp = 2 * (wave & 1) + (lane >> 5), q = lane & 31;
+  const float* src = arr ? t.G : t.A;
+  const long ld = arr ? t.ldg : t.lda;
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};             // column sums of G (bias gradient) of this lane's quad and row group
+  f32x4 x[8];
+  auto fetch = [&](int p) {
+    const long r0 = row_beg + 32L * p + 8 * kgp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long r = min(r0 + j, a.M - 1);
+      x[j] = *reinterpret_cast<const f32x4*>(src + r * ld + 4 * q);
+    }
+  };
+  if (nblocks > 0) fetch(0);
+  for (int p = 0; p < nblocks; ++p) {
+    const long r0 = row_beg + 32L * p + 8 * kgp;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (arr) {                                      // rows past the chunk end contribute nothing
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (r0 + j >= row_end) x[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cs += x[j];
+    }
+    __builtin_amdgcn_s_barrier();                   // every wave has finished reading the operands of block p-1
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = x[j][f];
+      bf16x8 sp[3];
+      split3v(v, sp);
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) ops[((arr * 3 + sidx) * 4 + kgp) * 128 + 4 * q + f] = sp[sidx];
+    }
+    if (p + 1 < nblocks) fetch(p + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // operands of block p complete
+    bf16x8 gs[2][3];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) gs[mb][sidx] = ops[((3 + sidx) * 4 + kg) * 128 + 32 * wave + 16 * mb + m];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      bf16x8 as[3];
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) as[sidx] = ops[(sidx * 4 + kg) * 128 + 16 * nb + m];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        f32x4 c = acc[mb][nb];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][2], as[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[0], c, 0, 0, 0);
+        acc[mb][nb] = c;
+      }
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(32 * wave + 16 * mb + 4 * kg + r) * 128 + 16 * nb + m] = acc[mb][nb][r];
+  // bias gradient: the four row groups of a feature quad live in four G-producer lanes -> fixed-order sum through LDS
+  __syncthreads();
+  float* csl = reinterpret_cast<float*>(ops);
+  if (arr) *reinterpret_cast<f32x4*>(csl + kgp * 128 + 4 * q) = cs;
+  __syncthreads();
+  if (threadIdx.x < 128)
+    slab[128 * 128 + threadIdx.x] = (csl[threadIdx.x] + csl[128 + threadIdx.x]) + (csl[256 + threadIdx.x] + csl[384 + threadIdx.x]);
+}
+
 struct RTaskDev { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; };
 struct RArgs { RTaskDev t[HGN_MAX_WTASK]; };
 
@@ -415,8 +524,9 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 }
 __global__ void step_incr_kernel(int* step) { *step += 1; }
 
+constexpr int WG_CHUNKS = 512;                    // workgroups of one weight-gradient launch (768 = three per CU measured no faster)
 static int chunks_mfma(long M, int n_tasks) {
-  long c = 512 / (n_tasks > 0 ? n_tasks : 1);
+  long c = WG_CHUNKS / (n_tasks > 0 ? n_tasks : 1);
   const long by_rows = (M + 63) / 64;
   if (c > by_rows) c = by_rows;
   if (c < 1) c = 1;
@@ -435,8 +545,8 @@ using namespace hgn;
 
 extern "C" int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes) {
   if (!bytes || M < 0 || n_tasks < 0 || n_tasks > HGN_MAX_WTASK) return hgn_fail(HGN_E_INVALID, "hgn_wgrad_workspace_bytes: bad argument");
-  // MFMA tasks share 512 chunks in total, LN tasks use up to 1024 small ones each
-  size_t mf = (size_t)512 * SLAB * sizeof(float);
+  // MFMA tasks share WG_CHUNKS chunks in total, LN tasks use up to 1024 small ones each
+  size_t mf = (size_t)WG_CHUNKS * SLAB * sizeof(float);
   size_t ln = (size_t)chunks_ln(M) * SLAB * sizeof(float) * (size_t)n_tasks;
   *bytes = mf + ln + 256;
   return HGN_OK;
@@ -487,7 +597,9 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
       hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
     } else {                                    // split-bf16 products: 32-row contraction blocks
       wa.rows_per_chunk = rows_per(nch0, 2 * DT);
-      hipLaunchKernelGGL(wgrad6_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+      static const bool resplit = getenv("HGN_WGRAD_RESPLIT") != nullptr;     // the previous kernel, kept for comparison
+      if (resplit) hipLaunchKernelGGL(wgrad6_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+      else hipLaunchKernelGGL(wgrad6s_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
     }
   }
   if (ng) {
