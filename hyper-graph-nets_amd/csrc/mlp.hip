@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WG, 4) void linear_bwd_kernel(const LinArgs a) {
 
 }  // namespace hgn
 
-namespace hgn { int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream); int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream); }
+namespace hgn { int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream); int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs); }
 using namespace hgn;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -329,13 +329,13 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   for (int i = 0; i < a->n_dx; ++i)
     if (!a->dx[i].W || !a->dx[i].dx || a->dx[i].K < 1 || (a->dx[i].residual && (a->dx[i].K != 128 || a->out_w != 128)))
       return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad dx request");
-  const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+  long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;      // = LayerNorm-gradient partial slabs in ln_ws (one per workgroup)
   const int kid = (a->n_dx == 1 && a->dx[0].residual && a->dz1) ? 2 : 3;
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
   if (a->seg_dz1 && (!a->seg_ids || a->ld_seg_dz1 < 128 || !hgn_mlp_bwd6_eligible(a)))
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: seg_dz1 needs seg_ids and the split-bf16 kernel");
   if (hgn_mlp_bwd6_eligible(a)) {
-    if (launch_mlp6_bwd(a, stream) != HGN_OK) return HGN_E_LAUNCH;
+    if (launch_mlp6_bwd(a, stream, &tiles) != HGN_OK) return HGN_E_LAUNCH;
   } else {
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   }

@@ -75,17 +75,15 @@ __device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf
   unsigned lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const unsigned wave = threadIdx.x >> 6;
-#ifdef EXP_NO_DMA
-  return;
-#endif
 #pragma unroll
   for (unsigned i = wave; i < HALF_TILES; i += WG / 64)          // one operand tile (1 KiB) per wave instruction
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
                                      (__attribute__((address_space(3))) void*)(lds + i * TILE_BF16), 16, 0, 0);
 }
 
-template <int HALF>
-__device__ __forceinline__ void mfma_half6(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
+// A wave owns NS sub-tiles of 16 rows; every operand fragment read from LDS is multiplied with all of them.
+template <int HALF, int NS>
+__device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS][3][4], const __bf16* __restrict__ lds) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int cl = 0; cl < 2; ++cl) {
@@ -95,54 +93,38 @@ __device__ __forceinline__ void mfma_half6(Act& acc, const bf16x8 (&xs)[3][4], c
       const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
       const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
       const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(lds + ((2 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
-      f32x4 t = acc.v[ob];
-#ifdef EXP_NO_MFMA
-      continue;
-#endif
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, xs[0][c], t, 0, 0, 0);      // smallest terms first
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[2][c], t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[1][c], t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[0][c], t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[1][c], t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[0][c], t, 0, 0, 0);
-      acc.v[ob] = t;
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        f32x4 t = acc[u].v[ob];
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, xs[u][0][c], t, 0, 0, 0);      // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][2][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[u][1][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[u][0][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][1][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][0][c], t, 0, 0, 0);
+        acc[u].v[ob] = t;
+      }
     }
   }
 }
 
-// acc[ob] += Wblock * b for one packed 128 x 128 block.  `between()` runs after the first half's DMA has been issued and
+// acc[u][ob] += Wblock * b[u] for one packed 128 x 128 block.  `between()` runs after the first half's DMA has been issued and
 // before the wait (the caller's own global loads fly with it); `b` is split after the wait, so `between` may load it.
-// `late()` runs after the LAST wait of the block, just before the second half's MFMAs: the place for global STORES -- every
-// wait for a weight DMA is a full vmcnt(0) drain (loads and stores share the counter), so a store issued anywhere else is
-// waited for by the next DMA wait a few hundred cycles later; from here it has half a block of MFMAs, a barrier and the next
-// DMA's latency to complete.
-// `early()` runs right after the first wait (b is still live there at no register cost): the stores then have the first
-// half's MFMAs before the next drain.
-template <class F, class E, class G>
-__device__ __forceinline__ void gemm6(Act& acc, const Act& b, __bf16* __restrict__ lds, const __bf16* __restrict__ pk, F&& between,
-                                      E&& early, G&& late) {
-  bf16x8 xs[3][4];
+template <int NS, class F>
+__device__ __forceinline__ void gemm6(Act (&acc)[NS], const Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
+                                      F&& between) {
+  bf16x8 xs[NS][3][4];
   wg_barrier_lds();
   stage_half6(lds, pk);
   between();
   __syncthreads();
-  early();
-  split3(b, xs);
-  mfma_half6<0>(acc, xs, lds);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
+  mfma_half6<0, NS>(acc, xs, lds);
   wg_barrier_lds();
   stage_half6(lds, pk + HALF_BF16);
   __syncthreads();
-  late();
-  mfma_half6<1>(acc, xs, lds);
-}
-template <class F>
-__device__ __forceinline__ void gemm6(Act& acc, const Act& b, __bf16* __restrict__ lds, const __bf16* __restrict__ pk, F&& between) {
-  gemm6(acc, b, lds, pk, between, [] {}, [] {});
-}
-template <class F, class G>
-__device__ __forceinline__ void gemm6(Act& acc, const Act& b, __bf16* __restrict__ lds, const __bf16* __restrict__ pk, F&& between,
-                                      G&& late) {
-  gemm6(acc, b, lds, pk, between, [] {}, late);
+  mfma_half6<1, NS>(acc, xs, lds);
 }
 
 __device__ __forceinline__ void relu6(Act& a) {
@@ -151,87 +133,108 @@ __device__ __forceinline__ void relu6(Act& a) {
   for (int u = 0; u < 4; ++u) a.v[fb][u] = fmaxf(a.v[fb][u], 0.f);
 }
 
-// ----------------------------------------------------------------------------------------------------------
-// forward (all sources 128-wide multiples, output 128 wide): same contract as mlp_fwd_kernel
-// ----------------------------------------------------------------------------------------------------------
-#ifndef EXP_LDS_PAD
-#define EXP_LDS_PAD 0
-#endif
-__global__ __launch_bounds__(WG, 3) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16 + EXP_LDS_PAD];
-  static_assert(HALF_BF16 * 2 >= SEG_LDS_FLOATS * 4, "the weight stage doubles as the segment-sum tile");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 15, kq = lane >> 4;
-  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
-  const bool valid = row < a.M;
-  const long rc = valid ? row : a.M - 1;
+// Rows of a workgroup: NS sub-tiles of 64 consecutive rows, sub-tile u of wave w = rows 64u + 16w .. +15 of the tile (each
+// sub-tile is a contiguous 64-row block, which the in-kernel segment sums rely on).
+template <int NS>
+struct Rows {
+  long row[NS], rc[NS]; bool valid[NS]; long tile_row0;
+  __device__ __forceinline__ Rows(long M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tile_row0 = xcd_tile() * (TILE_ROWS * NS);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      row[u] = tile_row0 + u * TILE_ROWS + wave * WAVE_ROWS + (lane & 15);
+      valid[u] = row[u] < M;
+      rc[u] = valid[u] ? row[u] : M - 1;
+    }
+  }
+};
 
-  Act acc, b;
+// ----------------------------------------------------------------------------------------------------------
+// forward (output 128 wide): same contract as mlp_fwd_kernel.  NS = 2: 128-row workgroup tiles, 2 waves / SIMD -- half the
+// weight DMA, LDS operand reads and barriers per row (0.635 -> 0.554 ms for 594 048 edge rows in tools/micro/bf16x6_mlp.hip).
+// ----------------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+  static_assert(HALF_BF16 * 2 >= SEG_LDS_FLOATS * 4, "the weight stage doubles as the segment-sum tile");
+  const int kq = (threadIdx.x & 63) >> 4;
+  const Rows<NS> R(a.M);
+
+  Act acc[NS], b[NS];
   bool first = true;
   for (int si = 0; si < a.n_src; ++si) {
     const hgn_src_t s = a.src[si];
-    const long srow = s.idx ? (long)s.idx[rc] : rc;
     const __bf16* pk = reinterpret_cast<const __bf16*>(s.Wpk);
     const bool vec = ((s.ld & 3) == 0) && ((s.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
     for (int k0 = 0; k0 < s.K; k0 += 128) {
       const int kw = min(128, s.K - k0);
-      const float* xr = s.x + srow * s.ld + k0;
-      gemm6(acc, b, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
-        // narrow / unaligned sources (encoder inputs): zero-extended to the 128-wide block whose pack is zero padded
-        if (vec) { if (kw == 128) t_load(b, xr, kq); else t_load_w(b, xr, kq, kw); } else t_load_masked(b, xr, kq, kw);
-        if (first) {
-          t_load(acc, a.b1, kq);
-          for (int i = 0; i < a.n_add; ++i) t_add(acc, a.add[i].P + (long)a.add[i].idx[rc] * a.add[i].ld, kq);
-          first = false;
+      gemm6<NS>(acc, b, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          const long srow = s.idx ? (long)s.idx[R.rc[u]] : R.rc[u];
+          const float* xr = s.x + srow * s.ld + k0;
+          // narrow / unaligned sources (encoder inputs): zero-extended to the 128-wide block whose pack is zero padded
+          if (vec) { if (kw == 128) t_load(b[u], xr, kq); else t_load_w(b[u], xr, kq, kw); } else t_load_masked(b[u], xr, kq, kw);
+          if (first) {
+            t_load(acc[u], a.b1, kq);
+            for (int i = 0; i < a.n_add; ++i) t_add(acc[u], a.add[i].P + (long)a.add[i].idx[R.rc[u]] * a.add[i].ld, kq);
+          }
         }
+        first = false;
       });
     }
   }
-  relu6(acc);
-#ifdef EXP_FWD_INPLACE
-  if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
-  if (a.relu_bits && valid) a.relu_bits[row * 8 + kq] = relu_bits_of(acc);
-  gemm6(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] { t_load(b, a.b2, kq); });
-  relu6(b);
-  if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
-  if (a.relu_bits && valid) a.relu_bits[row * 8 + 4 + kq] = relu_bits_of(b);
-  gemm6(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] { t_load(acc, a.b3, kq); });
-#else
-  // b := b2 + W2 * acc; the first hidden layer (acc) is stored from inside the block (see gemm6: `late`)
-  gemm6(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] { t_load(b, a.b2, kq); }, [&] {
-    if (a.z1 && valid) t_store(acc, a.z1 + row * LAT, kq);
-    if (a.relu_bits && valid) a.relu_bits[row * 8 + kq] = relu_bits_of(acc);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    relu6(acc[u]);
+    if (a.z1 && R.valid[u]) t_store(acc[u], a.z1 + R.row[u] * LAT, kq);
+    if (a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + kq] = relu_bits_of(acc[u]);
+  }
+  gemm6<NS>(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) t_load(b[u], a.b2, kq);
   });
-  relu6(b);
-  gemm6(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] { t_load(acc, a.b3, kq); }, [&] {
-    if (a.z2 && valid) t_store(b, a.z2 + row * LAT, kq);
-    if (a.relu_bits && valid) a.relu_bits[row * 8 + 4 + kq] = relu_bits_of(b);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    relu6(b[u]);
+    if (a.z2 && R.valid[u]) t_store(b[u], a.z2 + R.row[u] * LAT, kq);
+    if (a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + 4 + kq] = relu_bits_of(b[u]);
+  }
+  gemm6<NS>(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) t_load(acc[u], a.b3, kq);
   });
-#endif
-  if (a.ln_g) {
-    const float mean = row_sum(acc) * (1.f / LAT);
-    HGN_FOR_B(fb) {
-      acc.v[fb] -= mean;
-      b.v[fb] = acc.v[fb] * acc.v[fb];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    if (a.ln_g) {
+      const float mean = row_sum(acc[u]) * (1.f / LAT);
+      HGN_FOR_B(fb) {
+        acc[u].v[fb] -= mean;
+        b[u].v[fb] = acc[u].v[fb] * acc[u].v[fb];
+      }
+      const float var = row_sum(b[u]) * (1.f / LAT);
+      const float rstd = 1.f / sqrtf(var + 1e-5f);
+      HGN_FOR_B(fb) acc[u].v[fb] *= rstd;
+      if (a.xhat && R.valid[u]) t_store(acc[u], a.xhat + R.row[u] * LAT, kq);
+      if (a.rstd && R.valid[u] && kq == 0) a.rstd[R.row[u]] = rstd;
+      HGN_FOR_B(fb) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 16 * fb + 4 * kq);
+        acc[u].v[fb] = acc[u].v[fb] * gm + bt;
+      }
     }
-    const float var = row_sum(b) * (1.f / LAT);
-    const float rstd = 1.f / sqrtf(var + 1e-5f);
-    HGN_FOR_B(fb) acc.v[fb] *= rstd;
-    if (a.xhat && valid) t_store(acc, a.xhat + row * LAT, kq);
-    if (a.rstd && valid && kq == 0) a.rstd[row] = rstd;
-    HGN_FOR_B(fb) {
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 16 * fb + 4 * kq);
-      acc.v[fb] = acc.v[fb] * gm + bt;
+    if (R.valid[u]) {
+      if (a.res) t_add(acc[u], a.res + R.row[u] * a.ld_res, kq);
+      t_store(acc[u], a.out + R.row[u] * a.ld_out, kq);
     }
   }
-  if (valid) {
-#ifndef EXP_NO_RES
-    if (a.res) t_add(acc, a.res + row * a.ld_res, kq);
-#endif
-    t_store(acc, a.out + row * a.ld_out, kq);
+  if (a.seg_out) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+      if (R.tile_row0 + u * TILE_ROWS < a.M)          // uniform over the workgroup
+        tile_segment_sum(acc[u], reinterpret_cast<float*>(lds), a.seg_ids, a.seg_out, a.ld_seg_out, R.tile_row0 + u * TILE_ROWS, a.M);
   }
-  if (a.seg_out) tile_segment_sum(acc, reinterpret_cast<float*>(lds), a.seg_ids, a.seg_out, a.ld_seg_out, xcd_tile() * TILE_ROWS, a.M);
 }
 
 // single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
@@ -239,106 +242,111 @@ struct Lin6Args { const float* x; long ldx; long M; const __bf16* pk[4]; int n_b
 
 __global__ __launch_bounds__(WG, 3) void linear6_fwd_kernel(const Lin6Args a) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 15, kq = lane >> 4;
-  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
-  const bool valid = row < a.M;
-  const long rc = valid ? row : a.M - 1;
-  Act acc, b;
+  const int kq = (threadIdx.x & 63) >> 4;
+  const Rows<1> R(a.M);
+  Act acc[1], b[1];
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    gemm6(acc, b, lds, a.pk[blk], [&] {
-      if (blk == 0) t_load(b, a.x + rc * a.ldx, kq);
-      t_zero(acc);
+    gemm6<1>(acc, b, lds, a.pk[blk], [&] {
+      if (blk == 0) t_load(b[0], a.x + R.rc[0] * a.ldx, kq);
+      t_zero(acc[0]);
     });
-    if (valid) t_store(acc, a.out + row * a.ld_out + 128 * blk, kq);
+    if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out + 128 * blk, kq);
   }
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// backward (data gradients): same contract as mlp_bwd_kernel; weights come as TRANSPOSED-form packs
+// backward (data gradients): same contract as mlp_bwd_kernel; weights come as TRANSPOSED-form packs.  Eligibility
+// guarantees LayerNorm, its workspace and the ReLU sign words: straight-line code without optional parts.
 // ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) {
+template <int NS>
+__global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) {
   __shared__ __attribute__((aligned(16))) float ldsf[HALF_BF16 / 2 + (WG / 64) * 256];
   static_assert(HALF_BF16 / 2 >= SEG_LDS_FLOATS, "the weight stage doubles as the segment-sum tile");
   __bf16* lds = reinterpret_cast<__bf16*>(ldsf);
   float* lnl = ldsf + HALF_BF16 / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
-  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
-  const bool valid = row < a.M;
-  const long rc = valid ? row : a.M - 1;
+  const Rows<NS> R(a.M);
 
-  Act g, t;
-  // (eligibility guarantees LayerNorm, its workspace and the ReLU sign words: straight-line code, no optional parts)
-  const unsigned mb1 = a.relu_bits[rc * 8 + kq], mb2 = a.relu_bits[rc * 8 + 4 + kq];
-  // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
-  gemm6(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
-    load_dout<false>(g, a, rc, kq);
-    t_load(t, a.xhat + rc * LAT, kq);
-#ifndef EXP_NO_LNWS
-    HGN_FOR_B(fb) {
+  Act g[NS], t[NS];
+  unsigned mb1[NS], mb2[NS];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float pb = valid ? g.v[fb][u] : 0.f;
-        float pg = row16_sum(pb * t.v[fb][u]);
-        pb = row16_sum(pb);
-        if (n == 0) { lnl[wave * 256 + 16 * fb + 4 * kq + u] = pg; lnl[wave * 256 + 128 + 16 * fb + 4 * kq + u] = pb; }
+  for (int u = 0; u < NS; ++u) { mb1[u] = a.relu_bits[R.rc[u] * 8 + kq]; mb2[u] = a.relu_bits[R.rc[u] * 8 + 4 + kq]; }
+  // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
+  gemm6<NS>(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      Act& xh = t[u];
+      load_dout<false>(g[u], a, R.rc[u], kq);
+      t_load(xh, a.xhat + R.rc[u] * LAT, kq);
+      HGN_FOR_B(fb) {                               // LayerNorm-affine gradient partials of this wave's rows
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float pb = R.valid[u] ? g[u].v[fb][w] : 0.f;
+          float pg = row16_sum(pb * xh.v[fb][w]);
+          pb = row16_sum(pb);
+          if (n == 0) {
+            float* dst = lnl + wave * 256 + 16 * fb + 4 * kq + w;
+            if (u == 0) { dst[0] = pg; dst[128] = pb; } else { dst[0] += pg; dst[128] += pb; }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      HGN_FOR_B(fb) g[u].v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+      const float m1 = row_sum(g[u]) * (1.f / LAT);
+      float q0 = 0.f, q1 = 0.f;
+      HGN_FOR_B(fb) {
+        q0 += g[u].v[fb][0] * xh.v[fb][0] + g[u].v[fb][1] * xh.v[fb][1];
+        q1 += g[u].v[fb][2] * xh.v[fb][2] + g[u].v[fb][3] * xh.v[fb][3];
+      }
+      float qs = q0 + q1;
+      qs += __shfl_xor(qs, 16);
+      qs += __shfl_xor(qs, 32);
+      const float m2 = qs * (1.f / LAT);
+      const float r = a.rstd[R.rc[u]];
+      HGN_FOR_B(fb) g[u].v[fb] = r * (g[u].v[fb] - m1 - xh.v[fb] * m2);
+      if (a.dz3 && R.valid[u]) t_store(g[u], a.dz3 + R.row[u] * LAT, kq);
+      t_zero(t[u]);
     }
-#endif
-    HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
-    const float m1 = row_sum(g) * (1.f / LAT);
-    float q0 = 0.f, q1 = 0.f;
-    HGN_FOR_B(fb) {
-      q0 += g.v[fb][0] * t.v[fb][0] + g.v[fb][1] * t.v[fb][1];
-      q1 += g.v[fb][2] * t.v[fb][2] + g.v[fb][3] * t.v[fb][3];
-    }
-    float qs = q0 + q1;
-    qs += __shfl_xor(qs, 16);
-    qs += __shfl_xor(qs, 32);
-    const float m2 = qs * (1.f / LAT);
-    const float r = a.rstd[rc];
-    HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
-#if !defined(EXP_NO_DZ_STORE) && !defined(EXP_BWD_EARLY)
-    if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
-#endif
-    t_zero(t);
-  }, [&] {
-#if !defined(EXP_NO_DZ_STORE) && defined(EXP_BWD_EARLY)
-    if (a.dz3 && valid) t_store(g, a.dz3 + row * LAT, kq);
-#endif
-  }, [] {});
-  relu_mask_bits(t, mb2);
+  });
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    relu_mask_bits(t[u], mb2[u]);
+    if (a.dz2 && R.valid[u]) t_store(t[u], a.dz2 + R.row[u] * LAT, kq);
+  }
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
-#if !defined(EXP_NO_DZ_STORE) && !defined(EXP_BWD_EARLY)
-  if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
-#endif
-  gemm6(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] { t_zero(g); }, [&] {
-#if !defined(EXP_NO_DZ_STORE) && defined(EXP_BWD_EARLY)
-    if (a.dz2 && valid) t_store(t, a.dz2 + row * LAT, kq);
-#endif
-  }, [] {});
-  relu_mask_bits(g, mb1);
-  // ---- dx_src = dz1 * W1[:, cols]  (+ d_out_eff for the residual source) -----------------------------------
-#ifndef EXP_NO_DZ_STORE
-  if (a.dz1 && valid) t_store(g, a.dz1 + row * LAT, kq);
-#endif
+  gemm6<NS>(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) t_zero(g[u]);
+  });
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    relu_mask_bits(g[u], mb1[u]);
+    if (a.dz1 && R.valid[u]) t_store(g[u], a.dz1 + R.row[u] * LAT, kq);
+  }
   // receiver sums of dz1 while the tile is still in registers (the stage buffer is free between two blocks; the next block's
   // opening barrier orders the reads below before its weight DMA)
-  if (a.seg_dz1) tile_segment_sum(g, ldsf, a.seg_ids, a.seg_dz1, a.ld_seg_dz1, xcd_tile() * TILE_ROWS, a.M);
+  if (a.seg_dz1) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+      if (R.tile_row0 + u * TILE_ROWS < a.M)
+        tile_segment_sum(g[u], ldsf, a.seg_ids, a.seg_dz1, a.ld_seg_dz1, R.tile_row0 + u * TILE_ROWS, a.M);
+  }
+  // ---- dx_src = dz1 * W1[:, cols]  (+ d_out_eff for the residual source) -----------------------------------
   for (int di = 0; di < a.n_dx; ++di) {
     const hgn_dx_t d = a.dx[di];
     const __bf16* pk = reinterpret_cast<const __bf16*>(d.Wpk_t);
     for (int k0 = 0; k0 < d.K; k0 += 128) {
-      gemm6(t, g, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] { t_zero(t); });
-      if (valid) {
-        float* dst = d.dx + row * d.ld + k0;
-#ifndef EXP_NO_RES
-        if (d.residual) load_dout<true>(t, a, rc, kq);
-#endif
-        t_store(t, dst, kq);
-      }
+      gemm6<NS>(t, g, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) t_zero(t[u]);
+      });
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+        if (R.valid[u]) {
+          if (d.residual) load_dout<true>(t[u], a, R.rc[u], kq);
+          t_store(t[u], d.dx + R.row[u] * d.ld + k0, kq);
+        }
     }
   }
   __syncthreads();
@@ -351,16 +359,13 @@ __global__ __launch_bounds__(WG, 3) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) 
 __global__ __launch_bounds__(WG, 3) void linear6_bwd_kernel(const Lin6Args a) {
   // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]; packs are transposed-form
   __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 15, kq = lane >> 4;
-  const long row = xcd_tile() * TILE_ROWS + wave * WAVE_ROWS + n;
-  const bool valid = row < a.M;
-  const long rc = valid ? row : a.M - 1;
-  Act acc, b;
-  t_zero(acc);
+  const int kq = (threadIdx.x & 63) >> 4;
+  const Rows<1> R(a.M);
+  Act acc[1], b[1];
+  t_zero(acc[0]);
   for (int blk = 0; blk < a.n_blocks; ++blk)
-    gemm6(acc, b, lds, a.pk[blk], [&] { t_load(b, a.x + rc * a.ldx + 128 * blk, kq); });
-  if (valid) t_store(acc, a.out + row * a.ld_out, kq);
+    gemm6<1>(acc, b, lds, a.pk[blk], [&] { t_load(b[0], a.x + R.rc[0] * a.ldx + 128 * blk, kq); });
+  if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out, kq);
 }
 
 }  // namespace hgn
@@ -395,9 +400,19 @@ extern "C" int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* a) {
 }
 
 namespace hgn {
+// HGN_TILE128 (diagnostic): two sub-tiles per wave, 128-row workgroups at 2 waves / SIMD.  Half the weight DMA and operand reads
+// per row, but measured no faster in the product (edge forward 1.18 vs 1.21 ms, backward 1.37 vs 1.34 ms at 1.19 M rows) and
+// worse on small launches (half as many workgroups), so the 64-row kernels stay the default.
+static bool tile128() { static const bool v = getenv("HGN_TILE128") != nullptr; return v; }
+
 int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
-  const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
-  hipLaunchKernelGGL(mlp6_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  if (tile128() && a->M > TILE_ROWS) {
+    const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
+    hipLaunchKernelGGL(mlp6_fwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  } else {
+    const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+    hipLaunchKernelGGL(mlp6_fwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+  }
   return hgn_check_launch("hgn_mlp_fwd (split-bf16)");
 }
 }  // namespace hgn
@@ -429,9 +444,17 @@ extern "C" int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* a) {
 }
 
 namespace hgn {
-int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream) {
-  const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
-  hipLaunchKernelGGL(mlp6_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+// *n_slabs = number of 256-float LayerNorm-gradient partials written to a->ln_ws (one per workgroup)
+int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
+  if (tile128() && a->M > TILE_ROWS) {
+    const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
+    hipLaunchKernelGGL(mlp6_bwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    *n_slabs = tiles;
+  } else {
+    const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+    hipLaunchKernelGGL(mlp6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    *n_slabs = tiles;
+  }
   return hgn_check_launch("hgn_mlp_bwd (split-bf16)");
 }
 }  // namespace hgn

@@ -135,6 +135,93 @@ __global__ __launch_bounds__(WG, 3) void mlp6_kernel(const Args a) {
   if (valid) { t_add(acc, a.e + row * LAT, kq); t_store(acc, a.out + row * LAT, kq); }
 }
 
+// ---- variant: every wave owns TWO 16-row sub-tiles (128-row workgroup tiles); each staged half block and each operand
+// fragment read from LDS serves both (half the weight DMA and LDS reads per row; 2 waves / SIMD) -------------------------
+__device__ __forceinline__ void gemm6x2(Act (&acc)[2], const bf16x8 (&xs)[2][3][4], __bf16* lds, const __bf16* wpk) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage_half(lds, wpk + (long)half * HALF_BF16);
+    __syncthreads();
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const int c = 2 * half + cl;
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+        const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+        const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(lds + ((2 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f32x4 t = acc[u].v[ob];
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, xs[u][0][c], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][2][c], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[u][1][c], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[u][0][c], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][1][c], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][0][c], t, 0, 0, 0);
+          acc[u].v[ob] = t;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(WG, 2) void mlp6x2_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  long row[2], rc[2]; bool valid[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    row[u] = (long)blockIdx.x * 128 + wave * 32 + u * 16 + n;
+    valid[u] = row[u] < a.M; rc[u] = valid[u] ? row[u] : a.M - 1;
+  }
+  Act acc[2], b[2];
+  bf16x8 xs[2][3][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    t_load(b[u], a.e + rc[u] * LAT, kq);
+    t_load(acc[u], a.b1, kq);
+    t_add(acc[u], a.P + (long)a.snd[rc[u]] * 256, kq);
+    t_add(acc[u], a.P + (long)a.rcv[rc[u]] * 256 + 128, kq);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) split3(b[u], xs[u]);
+  gemm6x2(acc, xs, lds, a.w1);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    FOR_B(fb) for (int w = 0; w < 4; ++w) acc[u].v[fb][w] = fmaxf(acc[u].v[fb][w], 0.f);
+    if (valid[u]) t_store(acc[u], a.z1 + row[u] * LAT, kq);
+    split3(acc[u], xs[u]);
+    t_load(b[u], a.b2, kq);
+  }
+  gemm6x2(b, xs, lds, a.w2);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    FOR_B(fb) for (int w = 0; w < 4; ++w) b[u].v[fb][w] = fmaxf(b[u].v[fb][w], 0.f);
+    if (valid[u]) t_store(b[u], a.z2 + row[u] * LAT, kq);
+    split3(b[u], xs[u]);
+    t_load(acc[u], a.b3, kq);
+  }
+  gemm6x2(acc, xs, lds, a.w3);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float mean = row_sum(acc[u]) * (1.f / LAT);
+    FOR_B(fb) { acc[u].v[fb] -= mean; b[u].v[fb] = acc[u].v[fb] * acc[u].v[fb]; }
+    const float rstd = 1.f / sqrtf(row_sum(b[u]) * (1.f / LAT) + 1e-5f);
+    FOR_B(fb) acc[u].v[fb] *= rstd;
+    if (valid[u]) t_store(acc[u], a.xhat + row[u] * LAT, kq);
+    FOR_B(fb) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(a.gam + 16 * fb + 4 * kq), be = *reinterpret_cast<const f32x4*>(a.bet + 16 * fb + 4 * kq);
+      acc[u].v[fb] = acc[u].v[fb] * g + be;
+    }
+    if (valid[u]) { t_add(acc[u], a.e + row[u] * LAT, kq); t_store(acc[u], a.out + row[u] * LAT, kq); }
+  }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------
 static uint16_t f2bf(float f) {           // round to nearest even
   uint32_t u; memcpy(&u, &f, 4);
@@ -197,6 +284,16 @@ int main() {
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("bf16x6 edge MLP forward: %.3f ms per launch (%ld rows); fp32-equivalent %.1f TFLOP/s\n", ms / 10, E, 98304.0 * E / (ms / 10) / 1e9);
+  {
+    const unsigned tiles2 = (unsigned)((E + 127) / 128);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(mlp6x2_kernel, dim3(tiles2), dim3(WG), 0, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(mlp6x2_kernel, dim3(tiles2), dim3(WG), 0, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("two sub-tiles per wave (128-row tiles, 2 waves/SIMD): %.3f ms per launch\n", ms / 10);
+  }
   // ---- error of a few rows against fp64 ------------------------------------------------------------------------------
   std::vector<float> ho(E * 128);
   CK(hipMemcpy(ho.data(), out, E * 512, hipMemcpyDeviceToHost));
