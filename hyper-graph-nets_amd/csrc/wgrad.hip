@@ -248,12 +248,6 @@ __device__ __forceinline__ void wg_dma_issue6(float* __restrict__ slotA, float* 
 }
 
 __device__ __forceinline__ void split3v(const float (&v)[8], bf16x8 (&s)[3]) {
-#ifdef EXP_CHEAP_SPLIT
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s[0][j] = (__bf16)v[j]; }
-  s[1] = s[0]; s[2] = s[0];
-  return;
-#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const __bf16 h = (__bf16)v[j];
@@ -461,31 +455,39 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
 struct RTaskDev { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; };
 struct RArgs { RTaskDev t[HGN_MAX_WTASK]; };
 
-__global__ void wgrad_reduce_kernel(const RArgs a) {
+// Fixed-order sum of the chunk slabs.  512 threads = 64 consecutive slab elements x 8 chunk groups: group g adds the chunks
+// c = g, g + 8, ... (four loads in flight), the eight partial sums are combined through LDS in a fixed tree -- eight times
+// the loads in flight of a one-thread-per-element loop, which at ~170 chunks per task was pure latency (60 us per launch).
+constexpr int RED_ELEMS = 64, RED_GROUPS = 8;
+__global__ __launch_bounds__(RED_ELEMS * RED_GROUPS) void wgrad_reduce_kernel(const RArgs a) {
+  __shared__ float part[RED_GROUPS][RED_ELEMS];
   const RTaskDev t = a.t[blockIdx.y];
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= SLAB) return;
+  const int el = threadIdx.x & (RED_ELEMS - 1), grp = threadIdx.x / RED_ELEMS;
+  const int e = blockIdx.x * RED_ELEMS + el;
   const bool is_bias = e >= 128 * 128;
   const int j = is_bias ? e - 128 * 128 : e >> 7, k = e & 127;
-  if (t.type == 0) {
-    if (j >= t.n_out) return;
-    if (is_bias ? (t.db == nullptr) : (k >= t.K)) return;
-  } else {
-    if (!is_bias && e >= 128) return;
+  bool live = e < SLAB;
+  if (live) {
+    if (t.type == 0) live = j < t.n_out && (is_bias ? t.db != nullptr : k < t.K);
+    else live = is_bias ? t.db != nullptr : e < 128;
   }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const float* p = t.slab + e;
-  int c = 0;
-  for (; c + 4 <= t.n_chunks; c += 4) {                      // four independent loads in flight per thread
-    s0 += p[(long)(c + 0) * SLAB]; s1 += p[(long)(c + 1) * SLAB];
-    s2 += p[(long)(c + 2) * SLAB]; s3 += p[(long)(c + 3) * SLAB];
+  if (live) {
+    const float* p = t.slab + e;
+    int c = grp;
+    for (; c + 3 * RED_GROUPS < t.n_chunks; c += 4 * RED_GROUPS) {
+      s0 += p[(long)c * SLAB]; s1 += p[(long)(c + RED_GROUPS) * SLAB];
+      s2 += p[(long)(c + 2 * RED_GROUPS) * SLAB]; s3 += p[(long)(c + 3 * RED_GROUPS) * SLAB];
+    }
+    for (; c < t.n_chunks; c += RED_GROUPS) s0 += p[(long)c * SLAB];
   }
-  for (; c < t.n_chunks; ++c) s0 += p[(long)c * SLAB];
-  const float s = (s0 + s1) + (s2 + s3);
+  part[grp][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp != 0 || !live) return;
+  const float s = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
   float* dst;
   if (t.type == 0) dst = is_bias ? t.db + j : t.dW + (long)j * t.ldw + k;
   else dst = is_bias ? t.db + j : t.dW + e;
-  if (t.type != 0 && is_bias && !t.db) return;
   *dst = t.acc ? *dst + s : s;
 }
 
@@ -610,7 +612,8 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
     wa.n_chunks = nch1; wa.rows_per_chunk = rows_per(nch1, WT_ROWS); wa.task0 = n0;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch1, (unsigned)n1), dim3(WGW), 0, (hipStream_t)stream, wa);
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + 255) / 256, (unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, ra);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + RED_ELEMS - 1) / RED_ELEMS, (unsigned)n_tasks), dim3(RED_ELEMS * RED_GROUPS), 0,
+                     (hipStream_t)stream, ra);
   return hgn_check_launch("hgn_mlp_wgrad");
 }
 
