@@ -53,7 +53,10 @@ def parse():
                          'independent of host-side launch jitter; per-kernel events are then taken in a short eager pass on the '
                          'same buffers right after the timed region (events cannot be timed inside a replayed graph).')
     ap.add_argument('--graph', action='store_true', help='(default at N=1; kept for compatibility)')
-    ap.add_argument('--no-side-stream', action='store_true', help='weight-gradient launches on the main stream (no overlap)')
+    ap.add_argument('--side-stream', action='store_true',
+                    help='weight-gradient launches on a second stream (co-run with the next data-gradient kernels); paid off while those '
+                         'kernels were MFMA bound, measured 1.7 %% slower since they are row-traffic bound')
+    ap.add_argument('--no-side-stream', action='store_true', help='(default; kept for compatibility)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
 
@@ -168,7 +171,7 @@ def main():
     torch.cuda.synchronize()
     log('first forward done')
     use_graph = not args.eager
-    trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph, wgrad_stream=not args.no_side_stream)
+    trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph, wgrad_stream=args.side_stream)
     n_params = trainer.fp.numel
 
     def barrier():

@@ -195,29 +195,33 @@ __global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
 }
 
 // Fixed-order column sum of the per-workgroup LayerNorm slabs [n_wg][256] -> dgamma[128], dbeta[128].
-// 32 blocks x 1024 threads: block b owns features [8b, 8b+8); thread (rg, f) sums rows rg, rg+128, ... with eight loads in
-// flight, then the 128 row-group partials are combined through LDS in a fixed order.
-__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ ws, long n_wg, float* __restrict__ dg,
-                                                         float* __restrict__ db, int acc) {
-  __shared__ float part[128][8];
-  const int f = threadIdx.x & 7, rg = threadIdx.x >> 3;
-  const int col = blockIdx.x * 8 + f;
+// Two steps, both with whole 1 KiB slabs read by 256 consecutive threads: LN_PARTS blocks add the slabs b, b + LN_PARTS, ...
+// (eight loads in flight) into one partial slab each (stored behind the workgroup slabs), one block adds the partials in
+// fixed order.
+constexpr int LN_PARTS = 128;
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ ws, long n_wg, float* __restrict__ part) {
+  const int c = threadIdx.x;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  long w = rg;
-  for (; w + 7 * 128 < n_wg; w += 8 * 128) {
+  long w = blockIdx.x;
+  for (; w + 7 * LN_PARTS < n_wg; w += 8 * LN_PARTS) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] += ws[(w + u * 128) * 256 + col];
+    for (int u = 0; u < 8; ++u) s[u] += ws[(w + u * LN_PARTS) * 256 + c];
   }
-  for (int u = 0; w < n_wg; w += 128, ++u) s[u & 7] += ws[w * 256 + col];
-  part[rg][f] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  __syncthreads();
-  if (threadIdx.x < 8) {
-    float t = 0.f;
-    for (int r = 0; r < 128; ++r) t += part[r][threadIdx.x];
-    const int c = blockIdx.x * 8 + threadIdx.x;
-    float* dst = c < 128 ? dg + c : db + (c - 128);
-    *dst = acc ? *dst + t : t;
+  for (int u = 0; w < n_wg; w += LN_PARTS, ++u) s[u & 7] += ws[w * 256 + c];
+  part[blockIdx.x * 256 + c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+__global__ __launch_bounds__(256) void ln_final_kernel(const float* __restrict__ part, float* __restrict__ dg, float* __restrict__ db,
+                                                       int acc) {
+  const int c = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+  for (int b = 0; b < LN_PARTS; b += 4) {
+    s0 += part[(b + 0) * 256 + c]; s1 += part[(b + 1) * 256 + c];
+    s2 += part[(b + 2) * 256 + c]; s3 += part[(b + 3) * 256 + c];
   }
+  const float t = (s0 + s1) + (s2 + s3);
+  float* dst = c < 128 ? dg + c : db + (c - 128);
+  *dst = acc ? *dst + t : t;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -304,7 +308,7 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
 extern "C" int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes) {
   if (!bytes || M < 0) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd_ln_workspace_bytes: bad argument");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
-  *bytes = (size_t)tiles * 256 * sizeof(float) + 256;
+  *bytes = ((size_t)tiles + LN_PARTS) * 256 * sizeof(float) + 256;      // workgroup slabs + the partial slabs of ln_reduce
   return HGN_OK;
 }
 
@@ -340,8 +344,10 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   }
   if (a->ln_ws) {
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3(32), dim3(1024), 0, (hipStream_t)stream, a->ln_ws, tiles, a->d_gamma, a->d_beta,
-                       a->ln_accumulate);
+    // partial slabs live behind the slabs of a 64-row tiling (hgn_mlp_bwd_ln_workspace_bytes), whatever tiling ran
+    float* part = a->ln_ws + ((a->M + TILE_ROWS - 1) / TILE_ROWS) * 256;
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3(LN_PARTS), dim3(256), 0, (hipStream_t)stream, a->ln_ws, tiles, part);
+    hipLaunchKernelGGL(ln_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, a->d_gamma, a->d_beta, a->ln_accumulate);
   }
   return hgn_check_launch("hgn_mlp_bwd");
 }

@@ -74,7 +74,7 @@ class DataParallelTrainer:
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  group: Optional[dist.ProcessGroup] = None, adam_fn: Optional[Callable] = None,
-                 device_step: bool = False, wgrad_stream: bool = True):
+                 device_step: bool = False, wgrad_stream: bool = False):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = group

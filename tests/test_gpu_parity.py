@@ -501,7 +501,7 @@ def test_trainer_flat_gradients_and_adam_match_torch():
     ref = H.hip_model('multiscale', 'pna', 2, sets, sd)
     opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
     flat = H.hip_model('multiscale', 'pna', 2, sets, sd)
-    tr = parallel.DataParallelTrainer(flat, lr=1e-3)
+    tr = parallel.DataParallelTrainer(flat, lr=1e-3, wgrad_stream=True)      # weight gradients on the second stream
     for step in range(3):
         opt.zero_grad()
         out = ref(g)
@@ -551,7 +551,8 @@ def test_hip_graph_forward_and_train_step_replay():
     target = torch.randn(N, 3, generator=torch.Generator().manual_seed(0)).cuda()
     mask = torch.ones(N, dtype=torch.bool).cuda()
     eager = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 3, ['mesh_edges'], sd), lr=1e-3)
-    captured = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 3, ['mesh_edges'], sd), lr=1e-3, device_step=True)
+    captured = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 3, ['mesh_edges'], sd), lr=1e-3, device_step=True,
+                                            wgrad_stream=True)
     for _ in range(3):                                   # GraphedTrainStep warms up with 3 eager steps + 1 captured
         eager.step(G0, target, mask)
     gs = graphs.GraphedTrainStep(captured, G0, target, mask, warmup=3)
