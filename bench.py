@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix peak
 
 
 def log(*a):
@@ -238,38 +239,50 @@ def main():
             kernels = {n: {'ms_per_launch': v['ms'] / v['count'], 'launches_per_step': v['count'] / psteps,
                            'share_of_step': v['ms'] / psteps / ms_per_step} for n, v in k.items()}
             res['kernels'] = kernels
-            # Weight-gradient launches run on a side stream and co-run with the following backward kernels, so event
-            # (and rocprof) durations of backward-pass kernels include their co-runner.  The roofline line is therefore
-            # taken from the heaviest kernel of the FORWARD pass, where nothing overlaps (same algorithmic flops per edge
-            # as the backward-data and weight-gradient kernels: 3 x 2 x 128^2).
+            # ---- roofline of the dominant kernel (largest accumulated time of the step) --------------------------------------
+            # With split-bf16 products the fused kernels are bounded by their ROW TRAFFIC, not by the matrix pipe: the line is
+            # priced against HBM (algorithmic bytes / launch time / 8 TB/s); the matrix-pipe figures ride along.  When the
+            # weight gradients run on a side stream, backward-pass event times include the co-runner and only forward
+            # kernels are eligible.
             overlapped = trainer.side is not None
             fwd_only = ('mlp_fwd_edge', 'mlp_fwd', 'linear_fwd')
-            cand = {n: v for n, v in k.items() if (n in fwd_only or not overlapped) and
-                    (n.startswith('mlp') or n.startswith('wgrad') or n.startswith('linear'))}
+            # algorithmic HBM bytes: per row of the launch, plus node-level arrays touched once per launch
+            #   edge forward : read e, write e' + z1 + z2 + x-hat (5 x 512), ReLU sign words 32, rstd 4;  P rows (N x 1024)
+            #                  gathered, fused `sum` aggregate (N x 512) written
+            #   edge backward: read d(e') + x-hat (2 x 512), sign words 32, rstd 4, write dz3 + dz2 + dz1 + de (4 x 512);
+            #                  d(agg) rows (N x 512) gathered, receiver sums of dz1 (N x 512) written
+            #   weight grads : two operand rows (2 x 512) per task and row
+            algo = {'mlp_fwd_edge': (5 * 512 + 36, 1536 * N_nodes), 'mlp_bwd_edge': (6 * 512 + 36, 1024 * N_nodes),
+                    'wgrad': (1024, 0), 'wgrad_node': (1024, 0)}
+            cand = {n: v for n, v in k.items() if n in algo and (n in fwd_only or not overlapped)}
             name, v = max(cand.items(), key=lambda kv: kv[1]['ms'])
             t_launch = v['ms'] / v['count'] * 1e-3
             rows = v['units'] / v['count']
-            # flop required from this launch per row (three 128x128 products; wgrad: one per task-row); the reference
-            # formulation's 163 840 flop/edge splits between this launch and the node pre-projection
-            per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1}.get(name, 3) * 2 * 128 * 128
-            ach = per_row * rows / t_launch / 1e12
-            # algorithmic HBM bytes of that launch (edge forward: read e, write e', z1, z2, x-hat = 5 x 512 B per row, plus the
-            # node pre-projection rows once); reported beside the matrix figure because with split-bf16 products the
-            # kernels sit between the two roofs
-            hbm_row = {'mlp_fwd_edge': 5 * 512, 'mlp_bwd_edge': 9 * 512, 'wgrad': 2 * 512}.get(name)
-            hbm = None
-            if hbm_row is not None:
-                extra = N_nodes * 1024 if name == 'mlp_fwd_edge' else 0
-                hbm = (hbm_row * rows + extra) / t_launch / 1e9
-            res['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-                               'products': 'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate '
-                                           '(fp32-accurate; flops counted once, priced against the fp32 MFMA peak)'
-                                           if not os.environ.get('HGN_FP32_MFMA') else 'fp32 MFMA',
-                               'hbm_algorithmic_GBs': hbm, 'hbm_frac': (hbm / PEAK_HBM_GBS) if hbm else None,
-                               'rows_per_launch': rows, 'ms_per_launch': t_launch * 1e3, 'flop_per_row': per_row,
-                               'selection': 'heaviest kernel whose launches do not overlap side-stream work'
-                                            if overlapped else 'largest accumulated time'}
+            bytes_launch = algo[name][0] * rows + algo[name][1]
+            ach = bytes_launch / t_launch / 1e9
+            per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1}[name] * 2 * 128 * 128
+            tf = per_row * rows / t_launch / 1e12
+            fp32_only = bool(os.environ.get('HGN_FP32_MFMA'))
+            traffic = None
+            try:        # HBM bytes per launch from the rocprofv3 PMC passes of this configuration (profiles/README.md)
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+                ent = pm.get(name)
+                if ent and int(ent['rows_per_launch']) == int(rows) and not fp32_only:
+                    traffic = ent['traffic_bytes_per_launch']
+            except Exception:
+                pass
+            res['roofline'] = {'kernel': name, 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                               'frac': ach / PEAK_HBM_GBS, 'traffic': traffic,
+                               'algorithmic_bytes_per_launch': bytes_launch, 'rows_per_launch': rows,
+                               'ms_per_launch': t_launch * 1e3,
+                               'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this configuration, '
+                                                 'profiles/r01_pmc_traffic.json' if traffic else None,
+                               'matrix_pipe': {'fp32_equivalent_TFLOPs': tf, 'flop_per_row': per_row,
+                                               'frac_of_fp32_mfma_peak': tf / PEAK_F32_MFMA_TFLOPS,
+                                               'frac_of_bf16_mfma_peak': None if fp32_only else 6 * tf / PEAK_BF16_MFMA_TFLOPS,
+                                               'products': 'fp32 MFMA' if fp32_only else
+                                               'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate'},
+                               'selection': 'largest accumulated time' + (' among forward kernels (side stream on)' if overlapped else '')}
             # whole-step matrix utilisation: algorithmic flops of every MFMA launch of the step / step time
             step_flops = sum(v2['units'] / psteps * ({'wgrad': 1, 'wgrad_node': 1, 'linear_fwd': 2, 'linear_bwd': 2}.get(n2, 3)) * 2 * 128 * 128
                              for n2, v2 in k.items() if n2.startswith(('mlp', 'wgrad', 'linear')))
