@@ -289,14 +289,19 @@ def main():
             res['roofline_step'] = {'bound': 'mfma', 'achieved': step_flops / (ms_per_step * 1e-3) / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS,
                                     'unit': 'TFLOP/s', 'frac': step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                     'note': 'lower bound: node MLPs with more than one 128-wide source do more than 3 products'}
-            s = k.get('seg_fwd_agg')
+            # the scatter-add (segment-sum) kernel vs HBM.  With `sum` aggregation the forward aggregate is formed inside the
+            # edge kernel, so the stand-alone launches left in the step are the sender sums of dz1 in the backward (same
+            # kernel, rows gathered through the sender permutation); with pna the forward aggregation launch is reported.
+            # Algorithmic bytes, sum: 4*D*E + 4*(N+1) + 4*D*N (+ 4*E for the permutation)
+            s, which = k.get('seg_fwd_agg'), 'forward aggregation'
+            if not s:
+                s, which = k.get('seg_fwd'), 'sender sums of dz1 (backward), rows gathered through the sender permutation'
             if s:
-                # the scatter-add aggregation of the forward pass (one launch per layer; the backward's sender/receiver
-                # sums use the same kernel under another id).  Algorithmic bytes, sum: 4*D*E + 4*(N+1) + 4*D*N
-                bytes_launch = 4 * 128 * E_rank + 4 * (N_nodes + 1) + 4 * 128 * N_nodes
+                n_out = 4 if (args.agg == 'pna' and which == 'forward aggregation') else 1
+                bytes_launch = 4 * 128 * E_rank + 4 * (N_nodes + 1) + 4 * 128 * N_nodes * n_out + (0 if which == 'forward aggregation' else 4 * E_rank)
                 t = s['ms'] / s['count'] * 1e-3
                 ach = bytes_launch / t / 1e9
-                res['roofline_aggregation'] = {'kernel': 'seg_fwd128 (forward aggregation)', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
+                res['roofline_aggregation'] = {'kernel': f'seg_fwd128 ({which})', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
                                                'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
                                                'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3}
         if world == 1 and not args.no_cpu_baseline:
