@@ -54,6 +54,9 @@ def parse():
                          'independent of host-side launch jitter; per-kernel events are then taken in a short eager pass on the '
                          'same buffers right after the timed region (events cannot be timed inside a replayed graph).')
     ap.add_argument('--graph', action='store_true', help='(default at N=1; kept for compatibility)')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help="'bf16': one bf16 MFMA per product instead of the six fp32-accurate split products (reduced precision: NOT the "
+                         "headline metric, outside the 1e-5 parity tolerance; BASELINE.json configs[4] asks for such an edge MLP)")
     ap.add_argument('--side-stream', action='store_true',
                     help='weight-gradient launches on a second stream (co-run with the next data-gradient kernels); paid off while those '
                          'kernels were MFMA bound, measured 1.7 %% slower since they are row-traffic bound')
@@ -136,6 +139,7 @@ def main():
     import hgn_amd
     from hgn_amd import ops, synthetic, parallel, _lib
     _lib.lib()
+    ops.set_matmul_precision(args.precision)
 
     # ---- this rank's shard of the global batch: graphs {g : g mod world == rank}, each with its own seed ----------
     B = args.batch
@@ -225,7 +229,8 @@ def main():
     if rank == 0:
         res = {'metric': 'processed edges/sec (fwd+bwd) on flag_simple mesh', 'value': value, 'unit': 'edges/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32' if args.precision == 'fp32' else 'bf16 (reduced precision run, not the headline metric)', 'data': 'synthetic',
                'config': {'workload': f'flag_simple-shape MeshGraphNets baseline: architecture {args.arch}, '
                                       f'{args.layers} MP layers, latent 128, aggregation {args.agg}, 1xMI355X config; '
                                       f'{args.nx}x{args.ny} triangulated grid per graph ({per} nodes, {E_graph} directed '

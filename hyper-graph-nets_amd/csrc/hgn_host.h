@@ -7,6 +7,7 @@ namespace hgn {
 
 int hgn_fail(int code, const char* msg);          // records msg (thread-local) and returns code
 int hgn_check_launch(const char* what);
+int matmul_products();                            // 6 (fp32-accurate split products) or 1 (single bf16 product): hgn_set_matmul_products
 extern thread_local int g_prof_tag;           // hipGetLastError() -> HGN_OK / HGN_E_LAUNCH
 
 // Records a HIP event pair around the launches issued in its scope when profiling is enabled.

@@ -9,6 +9,8 @@ namespace hgn {
 
 static thread_local char g_err[512] = "";
 thread_local int g_prof_tag = 0;
+static int g_products = 6;
+int matmul_products() { return g_products; }
 
 int hgn_fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -61,6 +63,12 @@ extern "C" int hgn_prof_enable(int on) {
   g_on = on != 0;
   return HGN_OK;
 }
+extern "C" int hgn_set_matmul_products(int n) {
+  if (n != 1 && n != 6) return hgn_fail(HGN_E_INVALID, "hgn_set_matmul_products: 6 (fp32-accurate) or 1 (single bf16 product)");
+  g_products = n;
+  return HGN_OK;
+}
+extern "C" int hgn_get_matmul_products(void) { return g_products; }
 extern "C" int hgn_prof_tag(int tag) { g_prof_tag = tag; return HGN_OK; }
 extern "C" int hgn_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -71,18 +71,20 @@ __device__ __forceinline__ void split3(const Act& x, bf16x8 (&s)[3][4]) {
     }
 }
 
+// NP = 1 (single bf16 product): only the leading split of the weights is staged (the first third of the half's tiles)
+template <int NP>
 __device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf16* __restrict__ gsrc) {
   unsigned lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const unsigned wave = threadIdx.x >> 6;
 #pragma unroll
-  for (unsigned i = wave; i < HALF_TILES; i += WG / 64)          // one operand tile (1 KiB) per wave instruction
+  for (unsigned i = wave; i < (NP == 1 ? HALF_TILES / 3 : HALF_TILES); i += WG / 64)          // one operand tile (1 KiB) per wave instruction
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
                                      (__attribute__((address_space(3))) void*)(lds + i * TILE_BF16), 16, 0, 0);
 }
 
 // A wave owns NS sub-tiles of 16 rows; every operand fragment read from LDS is multiplied with all of them.
-template <int HALF, int NS>
+template <int HALF, int NS, int NP>
 __device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS][3][4], const __bf16* __restrict__ lds) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -91,6 +93,11 @@ __device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
       const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+      if (NP == 1) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) acc[u].v[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][0][c], acc[u].v[ob], 0, 0, 0);
+        continue;
+      }
       const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
       const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(lds + ((2 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
 #pragma unroll
@@ -110,21 +117,21 @@ __device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS
 
 // acc[u][ob] += Wblock * b[u] for one packed 128 x 128 block.  `between()` runs after the first half's DMA has been issued and
 // before the wait (the caller's own global loads fly with it); `b` is split after the wait, so `between` may load it.
-template <int NS, class F>
+template <int NS, int NP, class F>
 __device__ __forceinline__ void gemm6(Act (&acc)[NS], const Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
                                       F&& between) {
   bf16x8 xs[NS][3][4];
   wg_barrier_lds();
-  stage_half6(lds, pk);
+  stage_half6<NP>(lds, pk);
   between();
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
-  mfma_half6<0, NS>(acc, xs, lds);
+  mfma_half6<0, NS, NP>(acc, xs, lds);
   wg_barrier_lds();
-  stage_half6(lds, pk + HALF_BF16);
+  stage_half6<NP>(lds, pk + HALF_BF16);
   __syncthreads();
-  mfma_half6<1, NS>(acc, xs, lds);
+  mfma_half6<1, NS, NP>(acc, xs, lds);
 }
 
 __device__ __forceinline__ void relu6(Act& a) {
@@ -154,7 +161,7 @@ struct Rows {
 // forward (output 128 wide): same contract as mlp_fwd_kernel.  NS = 2: 128-row workgroup tiles, 2 waves / SIMD -- half the
 // weight DMA, LDS operand reads and barriers per row (0.635 -> 0.554 ms for 594 048 edge rows in tools/micro/bf16x6_mlp.hip).
 // ----------------------------------------------------------------------------------------------------------
-template <int NS>
+template <int NS, int NP>
 __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
   static_assert(HALF_BF16 * 2 >= SEG_LDS_FLOATS * 4, "the weight stage doubles as the segment-sum tile");
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
     const bool vec = ((s.ld & 3) == 0) && ((s.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
     for (int k0 = 0; k0 < s.K; k0 += 128) {
       const int kw = min(128, s.K - k0);
-      gemm6<NS>(acc, b, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
+      gemm6<NS, NP>(acc, b, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
           const long srow = s.idx ? (long)s.idx[R.rc[u]] : R.rc[u];
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
     if (a.z1 && R.valid[u]) t_store(acc[u], a.z1 + R.row[u] * LAT, kq);
     if (a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + kq] = relu_bits_of(acc[u]);
   }
-  gemm6<NS>(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
+  gemm6<NS, NP>(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) t_load(b[u], a.b2, kq);
   });
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
     if (a.z2 && R.valid[u]) t_store(b[u], a.z2 + R.row[u] * LAT, kq);
     if (a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + 4 + kq] = relu_bits_of(b[u]);
   }
-  gemm6<NS>(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
+  gemm6<NS, NP>(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) t_load(acc[u], a.b3, kq);
   });
@@ -240,13 +247,14 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
 // single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
 struct Lin6Args { const float* x; long ldx; long M; const __bf16* pk[4]; int n_blocks; float* out; long ld_out; };
 
+template <int NP>
 __global__ __launch_bounds__(WG, 3) void linear6_fwd_kernel(const Lin6Args a) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
   const int kq = (threadIdx.x & 63) >> 4;
   const Rows<1> R(a.M);
   Act acc[1], b[1];
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    gemm6<1>(acc, b, lds, a.pk[blk], [&] {
+    gemm6<1, NP>(acc, b, lds, a.pk[blk], [&] {
       if (blk == 0) t_load(b[0], a.x + R.rc[0] * a.ldx, kq);
       t_zero(acc[0]);
     });
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(WG, 3) void linear6_fwd_kernel(const Lin6Args a) {
 // backward (data gradients): same contract as mlp_bwd_kernel; weights come as TRANSPOSED-form packs.  Eligibility
 // guarantees LayerNorm, its workspace and the ReLU sign words: straight-line code without optional parts.
 // ----------------------------------------------------------------------------------------------------------
-template <int NS>
+template <int NS, int NP>
 __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) {
   __shared__ __attribute__((aligned(16))) float ldsf[HALF_BF16 / 2 + (WG / 64) * 256];
   static_assert(HALF_BF16 / 2 >= SEG_LDS_FLOATS, "the weight stage doubles as the segment-sum tile");
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
 #pragma unroll
   for (int u = 0; u < NS; ++u) { mb1[u] = a.relu_bits[R.rc[u] * 8 + kq]; mb2[u] = a.relu_bits[R.rc[u] * 8 + 4 + kq]; }
   // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
-  gemm6<NS>(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
+  gemm6<NS, NP>(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       Act& xh = t[u];
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
     if (a.dz2 && R.valid[u]) t_store(t[u], a.dz2 + R.row[u] * LAT, kq);
   }
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
-  gemm6<NS>(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] {
+  gemm6<NS, NP>(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) t_zero(g[u]);
   });
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
     const hgn_dx_t d = a.dx[di];
     const __bf16* pk = reinterpret_cast<const __bf16*>(d.Wpk_t);
     for (int k0 = 0; k0 < d.K; k0 += 128) {
-      gemm6<NS>(t, g, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
+      gemm6<NS, NP>(t, g, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
 #pragma unroll
         for (int u = 0; u < NS; ++u) t_zero(t[u]);
       });
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
   a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
+template <int NP>
 __global__ __launch_bounds__(WG, 3) void linear6_bwd_kernel(const Lin6Args a) {
   // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]; packs are transposed-form
   __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(WG, 3) void linear6_bwd_kernel(const Lin6Args a) {
   Act acc[1], b[1];
   t_zero(acc[0]);
   for (int blk = 0; blk < a.n_blocks; ++blk)
-    gemm6<1>(acc, b, lds, a.pk[blk], [&] { t_load(b[0], a.x + R.rc[0] * a.ldx + 128 * blk, kq); });
+    gemm6<1, NP>(acc, b, lds, a.pk[blk], [&] { t_load(b[0], a.x + R.rc[0] * a.ldx + 128 * blk, kq); });
   if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out, kq);
 }
 
@@ -406,12 +415,13 @@ namespace hgn {
 static bool tile128() { static const bool v = getenv("HGN_TILE128") != nullptr; return v; }
 
 int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
-  if (tile128() && a->M > TILE_ROWS) {
+  if (tile128() && matmul_products() == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
-    hipLaunchKernelGGL(mlp6_fwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((mlp6_fwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   } else {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL(mlp6_fwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   }
   return hgn_check_launch("hgn_mlp_fwd (split-bf16)");
 }
@@ -429,7 +439,8 @@ extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const voi
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(7, (double)M, (hipStream_t)stream);
-  hipLaunchKernelGGL(linear6_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  if (matmul_products() == 1) hipLaunchKernelGGL(linear6_fwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(linear6_fwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_fwd6");
 }
 
@@ -446,13 +457,14 @@ extern "C" int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* a) {
 namespace hgn {
 // *n_slabs = number of 256-float LayerNorm-gradient partials written to a->ln_ws (one per workgroup)
 int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
-  if (tile128() && a->M > TILE_ROWS) {
+  if (tile128() && matmul_products() == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
-    hipLaunchKernelGGL(mlp6_bwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((mlp6_bwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     *n_slabs = tiles;
   } else {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL(mlp6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     *n_slabs = tiles;
   }
   return hgn_check_launch("hgn_mlp_bwd (split-bf16)");
@@ -471,6 +483,7 @@ extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const voi
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(8, (double)M, (hipStream_t)stream);
-  hipLaunchKernelGGL(linear6_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  if (matmul_products() == 1) hipLaunchKernelGGL(linear6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(linear6_bwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_bwd6");
 }

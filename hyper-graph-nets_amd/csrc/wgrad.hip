@@ -360,6 +360,7 @@ __global__ __launch_bounds__(WGW, 2) void wgrad6_kernel(const WArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int OPS_VEC = 2 * 3 * 4 * 128;          // bf16x8 vectors per block: [A|G][split][row group][feature]
 
+template <int NP>          // 6: fp32-accurate split products; 1: single bf16 product (hgn_set_matmul_products)
 __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
   __shared__ __attribute__((aligned(16))) bf16x8 ops[OPS_VEC];                 // 48 KB
   const WTaskDev t = a.t[a.task0 + blockIdx.y];
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
       bf16x8 sp[3];
       split3v(v, sp);
 #pragma unroll
-      for (int sidx = 0; sidx < 3; ++sidx) ops[((arr * 3 + sidx) * 4 + kgp) * 128 + 4 * q + f] = sp[sidx];
+      for (int sidx = 0; sidx < (NP == 1 ? 1 : 3); ++sidx) ops[((arr * 3 + sidx) * 4 + kgp) * 128 + 4 * q + f] = sp[sidx];
     }
     if (p + 1 < nblocks) fetch(p + 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -418,20 +419,22 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int sidx = 0; sidx < 3; ++sidx) gs[mb][sidx] = ops[((3 + sidx) * 4 + kg) * 128 + 32 * wave + 16 * mb + m];
+      for (int sidx = 0; sidx < (NP == 1 ? 1 : 3); ++sidx) gs[mb][sidx] = ops[((3 + sidx) * 4 + kg) * 128 + 32 * wave + 16 * mb + m];
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
       bf16x8 as[3];
 #pragma unroll
-      for (int sidx = 0; sidx < 3; ++sidx) as[sidx] = ops[(sidx * 4 + kg) * 128 + 16 * nb + m];
+      for (int sidx = 0; sidx < (NP == 1 ? 1 : 3); ++sidx) as[sidx] = ops[(sidx * 4 + kg) * 128 + 16 * nb + m];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         f32x4 c = acc[mb][nb];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][2], as[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[1], c, 0, 0, 0);
+        if (NP != 1) {
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][2], as[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[1], c, 0, 0, 0);
+        }
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[0], c, 0, 0, 0);
         acc[mb][nb] = c;
       }
@@ -601,7 +604,8 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
       wa.rows_per_chunk = rows_per(nch0, 2 * DT);
       static const bool resplit = getenv("HGN_WGRAD_RESPLIT") != nullptr;     // the previous kernel, kept for comparison
       if (resplit) hipLaunchKernelGGL(wgrad6_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
-      else hipLaunchKernelGGL(wgrad6s_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+      else if (matmul_products() == 1) hipLaunchKernelGGL(wgrad6s_kernel<1>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+      else hipLaunchKernelGGL(wgrad6s_kernel<6>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
     }
   }
   if (ng) {

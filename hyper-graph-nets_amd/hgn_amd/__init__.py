@@ -14,3 +14,4 @@ from .util import EdgeSet, MultiGraph, MultiGraphWithPos, NodeType, device, unso
 from .modules import (MeshGraphNet, GraphNet, HyperGraphNet, HeteroGraphNet, MultiScaleGraphNet, MultiGraphNet,  # noqa: F401
                       RepeatedGraphNet, Encoder, Processor, Decoder, LazyMLP)
 from .normalizer import Normalizer  # noqa: F401
+from .ops import set_matmul_precision, get_matmul_precision  # noqa: F401,E402

@@ -21,6 +21,20 @@ _ws_cache = {}
 _WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
 
 
+def set_matmul_precision(mode: str) -> None:
+    """'fp32' (default): every 128x128 product as six split-bf16 MFMAs, fp32 accurate -- the mode all parity claims refer to.
+    'bf16': ONE bf16 MFMA per product (operands rounded to bf16, fp32 accumulation; ~4e-3 relative error per product), the
+    reduced-precision edge/node MLP of BASELINE.json configs[4].  Opt-in, process wide (include/hgn_mp.h:
+    hgn_set_matmul_products)."""
+    if mode not in ('fp32', 'bf16'):
+        raise ValueError("matmul precision must be 'fp32' or 'bf16'")
+    _lib.check(_lib.lib().hgn_set_matmul_products(6 if mode == 'fp32' else 1), 'hgn_set_matmul_products')
+
+
+def get_matmul_precision() -> str:
+    return 'fp32' if _lib.lib().hgn_get_matmul_products() == 6 else 'bf16'
+
+
 def set_wgrad_stream(stream):
     """Run every hgn_mlp_wgrad launch on `stream` (forked from / joined to the current stream by the caller).
 

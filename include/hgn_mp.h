@@ -144,6 +144,12 @@ typedef struct {
   void* out;                       /* HGN_PACK_BLOCK_BYTES, 16-byte aligned                                 */
 } hgn_pack_t;
 int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* stream);   /* one launch for up to HGN_MAX_PACK blocks */
+/* Precision of the split-bf16 kernels, process wide.  6 (default): the six products above, fp32 accurate -- the mode every
+ * parity claim of this library refers to.  1: ONE bf16 MFMA per product (both operands rounded to bf16, fp32 accumulation,
+ * relative error ~4e-3 per product; a third of the weight traffic, a sixth of the MFMAs) -- the reduced-precision edge/node
+ * MLP of BASELINE.json configs[4]; opt-in, never a default, outside the 1e-5 parity tolerance. */
+int hgn_set_matmul_products(int n /* 6 or 1 */);
+int hgn_get_matmul_products(void);
 int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd will take the split-bf16 kernel */
 int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
                     float* out, int64_t ld_out, void* stream);

@@ -650,3 +650,45 @@ def test_split_bf16_products_are_fp32_accurate():
     for a, b, c in zip(split, plain, r64):
         e6, e32 = H.rel_err(a, c), H.rel_err(b, c)
         assert e6 <= max(1.5 * e32, 2e-6), (e6, e32)
+    # the opt-in reduced-precision mode (one bf16 MFMA per product, BASELINE.json configs[4]): really bf16-grade, still sane,
+    # and switching back restores the fp32-accurate results bit for bit
+    assert hgn_amd.get_matmul_precision() == 'fp32'
+    hgn_amd.set_matmul_precision('bf16')
+    try:
+        low = run()
+    finally:
+        hgn_amd.set_matmul_precision('fp32')
+    # (i) it computes exactly what it claims: the forward equals an fp64 evaluation whose matrix-product operands are rounded
+    #     to bf16 (fp32 accumulation, LayerNorm and residual in fp32)
+    def rb(x):
+        return x.detach().float().bfloat16().double()
+    with torch.no_grad():
+        P = {n: p.detach().double() for n, p in blk.named_parameters()}
+
+        def mlp_bf16(x, pre):
+            z = torch.relu(rb(x) @ rb(P[pre + '.0.layers.linear_0.weight']).T + P[pre + '.0.layers.linear_0.bias'])
+            z = torch.relu(rb(z) @ rb(P[pre + '.0.layers.linear_1.weight']).T + P[pre + '.0.layers.linear_1.bias'])
+            z = rb(z) @ rb(P[pre + '.0.layers.linear_2.weight']).T + P[pre + '.0.layers.linear_2.bias']
+            return torch.nn.functional.layer_norm(z, (128,), P[pre + '.1.weight'], P[pre + '.1.bias'], 1e-5)
+        snd, rcv = topo.snd.long(), topo.rcv.long()
+        h, e = h0.double(), e0.double()
+        y_e = e + mlp_bf16(torch.cat([h[snd], h[rcv], e], 1), 'edge_models.mesh_edges')
+        agg_e = torch.zeros(N, 128, dtype=torch.float64, device='cuda').index_add(0, rcv, low[0].double())
+        hn_e = h + mlp_bf16(torch.cat([h, agg_e], 1), 'node_model_cross')
+    #     mean error: a value that sits on a bf16 rounding boundary may round the other way under fp32 vs fp64 accumulation
+    #     (a 4e-3 step for that one operand), so single entries differ by up to ~1e-3 of the output range
+    for got, ref in ((low[0], y_e), (low[1], hn_e)):
+        mean_err = float((got.double() - ref).abs().mean() / ref.abs().mean())
+        assert mean_err <= 2e-5 and H.rel_err(got, ref) <= 3e-3, (mean_err, H.rel_err(got, ref))
+    # (ii) it is bf16-grade, not fp32-grade, against the exact result; gradients stay aligned with the exact ones (ReLU gates
+    #      near zero flip under the rounding, so their max-norm error is several percent)
+    errs = [H.rel_err(a, c) for a, c in zip(low, r64)]
+    assert 2e-5 <= errs[0] <= 1e-2 and 2e-5 <= errs[1] <= 1e-2 and max(errs) <= 0.25, errs
+    for a, c in zip(low[2:], r64[2:]):
+        cos = torch.nn.functional.cosine_similarity(a.double().flatten(), c.double().flatten(), dim=0)
+        assert float(cos) >= 0.99, float(cos)
+    again = run()
+    for a, b in zip(split, again):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        hgn_amd.set_matmul_precision('fp8')
