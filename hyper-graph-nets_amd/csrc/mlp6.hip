@@ -266,7 +266,7 @@ __global__ __launch_bounds__(WG, 3) void linear6_fwd_kernel(const Lin6Args a) {
 // backward (data gradients): same contract as mlp_bwd_kernel; weights come as TRANSPOSED-form packs.  Eligibility
 // guarantees LayerNorm, its workspace and the ReLU sign words: straight-line code without optional parts.
 // ----------------------------------------------------------------------------------------------------------
-template <int NS, int NP>
+template <int NS, int NP, bool PARK>
 __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) {
   __shared__ __attribute__((aligned(16))) float ldsf[HALF_BF16 / 2 + (WG / 64) * 256];
   static_assert(HALF_BF16 / 2 >= SEG_LDS_FLOATS, "the weight stage doubles as the segment-sum tile");
@@ -277,6 +277,13 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
   const Rows<NS> R(a.M);
 
   Act g[NS], t[NS];
+  // PARK (several aggregation ops, i.e. pna: d_out_eff costs ~3.5 KB of gathered reads per row -- four d(agg) slots, two
+  // arg-index rows): it is parked in the residual dx buffer once instead of being gathered a second time for the skip
+  // connection.  A separate instantiation, so that the single-op kernel keeps its register allocation.
+  float* park = nullptr; long park_ld = 0;
+  if (PARK)
+    for (int di = 0; di < a.n_dx; ++di)
+      if (a.dx[di].residual) { park = a.dx[di].dx; park_ld = a.dx[di].ld; }
   unsigned mb1[NS], mb2[NS];
 #pragma unroll
   for (int u = 0; u < NS; ++u) { mb1[u] = a.relu_bits[R.rc[u] * 8 + kq]; mb2[u] = a.relu_bits[R.rc[u] * 8 + 4 + kq]; }
@@ -286,6 +293,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
     for (int u = 0; u < NS; ++u) {
       Act& xh = t[u];
       load_dout<false>(g[u], a, R.rc[u], kq);
+      if (PARK && R.valid[u]) t_store(g[u], park + R.row[u] * park_ld, kq);
       t_load(xh, a.xhat + R.rc[u] * LAT, kq);
       HGN_FOR_B(fb) {                               // LayerNorm-affine gradient partials of this wave's rows
 #pragma unroll
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
 #pragma unroll
       for (int u = 0; u < NS; ++u)
         if (R.valid[u]) {
-          if (d.residual) load_dout<true>(t[u], a, R.rc[u], kq);
+          if (d.residual) { if (PARK) t_add(t[u], park + R.row[u] * park_ld, kq); else load_dout<true>(t[u], a, R.rc[u], kq); }
           t_store(t[u], d.dx + R.row[u] * d.ld + k0, kq);
         }
     }
@@ -459,12 +467,16 @@ namespace hgn {
 int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
   if (tile128() && matmul_products() == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
-    hipLaunchKernelGGL((mlp6_bwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((mlp6_bwd_kernel<2, 6, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     *n_slabs = tiles;
   } else {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
-    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    bool park = false;                      // several aggregation ops feeding a residual source gradient (pna edge blocks)
+    if (a->agg_dout && a->n_agg_ops > 1)
+      for (int i = 0; i < a->n_dx; ++i) park = park || a->dx[i].residual;
+    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else if (park) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, true>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     *n_slabs = tiles;
   }
   return hgn_check_launch("hgn_mlp_bwd (split-bf16)");
