@@ -2,7 +2,7 @@
 //   P0  lane (n = lane & 15, q = lane >> 4) moves 16 bytes of row n at feature 16 b + 4 q   (the MFMA register layout)
 //   P1  the same, four outputs interleaved in one [M][4][128] array
 //   P2  lane-linear: one wave instruction moves 1 KiB contiguous (two whole rows)
-//   P3  P0 with reads only / P4  P0 with writes only
+//   P3  P0 with reads only / P4  P0 with writes only / P5  P0 with non-temporal stores / P6  non-temporal loads and stores
 // hipcc --offload-arch=gfx950 -O3 tools/micro/stream_pattern.hip -o /tmp/stream_pattern && /tmp/stream_pattern
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -28,7 +28,10 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ in, float* __
   }
   const int n = lane & 15, q = lane >> 4;
   const long row = row0 + n;
-  if (P != 4) {
+  if (P == 6) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) v[b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(in + row * 128 + 16 * b + 4 * q));
+  } else if (P != 4) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) v[b] = *reinterpret_cast<const f32x4*>(in + row * 128 + 16 * b + 4 * q);
   } else {
@@ -40,6 +43,17 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ in, float* __
 #pragma unroll
     for (int b = 1; b < 8; ++b) s += v[b];
     if (s[0] == 123.456f) o0[row] = s[1];
+    return;
+  }
+  if (P == 5 || P == 6) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) __builtin_nontemporal_store(v[b], reinterpret_cast<f32x4*>(o0 + row * 128 + 16 * b + 4 * q));
+#pragma unroll
+    for (int b = 0; b < 8; ++b) __builtin_nontemporal_store(v[b] * 2.f, reinterpret_cast<f32x4*>(o1 + row * 128 + 16 * b + 4 * q));
+#pragma unroll
+    for (int b = 0; b < 8; ++b) __builtin_nontemporal_store(v[b] * 3.f, reinterpret_cast<f32x4*>(o2 + row * 128 + 16 * b + 4 * q));
+#pragma unroll
+    for (int b = 0; b < 8; ++b) __builtin_nontemporal_store(v[b] * 4.f, reinterpret_cast<f32x4*>(o3 + row * 128 + 16 * b + 4 * q));
     return;
   }
   if (P == 1) {
@@ -83,5 +97,8 @@ int main() {
   run<2>("P2 lane-linear, 1 read + 4 write streams", in, o, M, 2560);
   run<3>("P3 MFMA layout, read only", in, o, M, 512);
   run<4>("P4 MFMA layout, 4 write streams only", in, o, M, 2048);
+  run<5>("P5 P0 with non-temporal stores", in, o, M, 2560);
+  run<6>("P6 P0 with non-temporal loads and stores", in, o, M, 2560);
+  run<0>("P0 again", in, o, M, 2560);
   return 0;
 }
