@@ -1,11 +1,14 @@
 // Weight / bias / LayerNorm-affine gradients of the fused MLPs, plus the flat Adam step.
 //
-// dW[j][k] = sum_i G[i][j] * A[i][k] contracts over ROWS (edges / nodes), so both MFMA operands are read with the
-// lane on the feature axis straight out of row-major LDS tiles (conflict-free ds_read_b32, no transposes):
-//   A-operand lane (m, h): G[2t+h][32*wave + m]      B-operand lane (n, h): A[2t+h][32*kb + n]
-// Each workgroup owns a contiguous chunk of rows and keeps its 32x128 slice-per-wave of dW in accumulators
-// across the whole chunk; chunk partials go to slabs that a second kernel adds in fixed order (deterministic,
-// no float atomics -- MI355X global float atomics run at ~1.3 TB/s and are order dependent).
+// dW[j][k] = sum_i G[i][j] * A[i][k] contracts over ROWS (edges / nodes).  Each workgroup owns a contiguous chunk of rows and
+// keeps its 32x128 slice-per-wave of dW in accumulators across the whole chunk; chunk partials go to slabs that a second
+// kernel adds in fixed order (deterministic, no float atomics -- MI355X global float atomics run at ~1.3 TB/s and are order
+// dependent).  Kernels, in the order they are tried for a task:
+//   wgrad6s_kernel   (default) split-bf16 products; operand rows loaded into registers, split ONCE and handed to all waves as
+//                    ready-made bf16x8 operand vectors through LDS
+//   wgrad6_kernel    the previous form (LDS-DMA ring of fp32 tiles, every wave splits what it reads; HGN_WGRAD_RESPLIT=1)
+//   wgrad_dma_kernel plain fp32 MFMAs from an LDS-DMA ring (HGN_FP32_MFMA=1)
+//   wgrad_kernel     register-staged fp32 fallback for narrow / gathered operands (encoder inputs) and LayerNorm-affine tasks
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "hgn_host.h"
