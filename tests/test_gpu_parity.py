@@ -214,7 +214,7 @@ def test_edge_block_vs_oracle(nx, ny):
         assert H.rel_err(t.grad, sdo[n].grad) <= TOL_GRAD, n
 
 
-@pytest.mark.parametrize('N,max_deg,seed', [(50, 65, 0), (700, 20, 1), (3, 65, 2), (1200, 9, 3), (300, 17, 4), (5, 3, 5)])
+@pytest.mark.parametrize('N,max_deg,seed', [(50, 65, 0), (700, 20, 1), (3, 65, 2), (1200, 9, 3), (300, 17, 4), (5, 3, 5), (200000, 12, 6)])
 def test_edge_block_fused_segment_sums(N, max_deg, seed):
     """The `sum` aggregation of e' and the receiver half of the pre-projection gradient come out of the edge kernels themselves
     (include/hgn_mp.h: seg_out / seg_dz1).  Ragged degrees 0..max_deg (segments crossing 64-row tile ends, empty segments, a
