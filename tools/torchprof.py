@@ -7,15 +7,17 @@ for p in (ROOT, os.path.join(ROOT, 'hyper-graph-nets_amd')):
 import torch
 import hgn_amd
 from hgn_amd import synthetic, parallel
-ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=128); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=128)
+ap.add_argument('--arch', default='none'); ap.add_argument('--agg', default='sum'); ap.add_argument('--layers', type=int, default=15)
+ap.add_argument('--clusters', type=int, default=0); a = ap.parse_args()
 dev = torch.device('cuda')
-big = synthetic.batch([synthetic.grid_graph(seed=i % 4) for i in range(a.batch)])
+big = synthetic.batch([synthetic.grid_graph(seed=i % 4, clusters=a.clusters) for i in range(a.batch)])
 graph = hgn_amd.MultiGraph([x.to(dev) for x in big.node_features],
                            [hgn_amd.EdgeSet(e.name, e.features.to(dev), e.senders.to(dev), e.receivers.to(dev)) for e in big.edge_sets])
 N = graph.node_features[0].shape[0]
 target = torch.randn(N, 3, device=dev); mask = torch.ones(N, dtype=torch.bool, device=dev)
 torch.manual_seed(0)
-model = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 15, 'none', ['mesh_edges']).to(dev)
+model = hgn_amd.MeshGraphNet(3, 128, 2, a.agg, a.layers, a.arch, [e.name for e in graph.edge_sets]).to(dev)
 with torch.no_grad():
     model(graph)
 tr = parallel.DataParallelTrainer(model, wgrad_stream=False)
