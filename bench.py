@@ -120,6 +120,45 @@ def cpu_baseline(args, graph1):
                       f'{dt:.3f} s/iter, torch {torch.__version__} CPU fp32'}
 
 
+def cpu_baseline_forward(state_dict, graph1, arch, agg, iters=5):
+    """cpu_baseline leg for the rollout regime (tools/rolloutbench.py): the oracle's forward of ONE graph on the host cores.
+    -> (ms per forward, threads, output tensor)"""
+    from oracle import mgn_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+    og = O.MultiGraph(list(graph1.node_features), [O.EdgeSet(*e) for e in graph1.edge_sets])
+    with torch.no_grad():
+        out = O.mesh_graph_net(sd, og, arch, agg)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.mesh_graph_net(sd, og, arch, agg)
+    return (time.perf_counter() - t0) / iters * 1e3, cores, out
+
+
+def cpu_baseline_features(frames, iters=10):
+    """cpu_baseline leg for the frame -> graph rows (tools/featbench.py): the oracle's FlagModel.build_graph and
+    build_graph + hierarchical connect (16 clusters of 100 nodes) per frame on the host cores."""
+    from oracle import features_oracle as FO
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ff = FO.FlagFeatures()
+    n_nodes = frames[0]['world_pos'].shape[0]
+    lab = [i // 100 for i in range(n_nodes)]
+    clusters = [torch.tensor([i for i in range(n_nodes) if lab[i] == k]) for k in range(max(lab) + 1)]
+    g = ff.build_graph(frames[0], True)
+    nb = FO.neighboring_clusters(g['edge_sets'][0].senders, g['edge_sets'][0].receivers, lab)
+    t0 = time.perf_counter()
+    for i in range(iters):
+        g = ff.build_graph(frames[i % len(frames)], True)
+    t1 = time.perf_counter()
+    for i in range(iters):
+        g = ff.build_graph(frames[i % len(frames)], True)
+        FO.hierarchical_connect(g, clusters, nb, ff.intra_edge, ff.inter_edge, ff.hyper_node, True)
+    t2 = time.perf_counter()
+    return {'cores': cores, 'build_graph ms/frame': (t1 - t0) / iters * 1e3, 'build_graph+connect ms/frame': (t2 - t1) / iters * 1e3}
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))

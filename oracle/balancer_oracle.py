@@ -7,7 +7,7 @@ are rounded when stored into the float32 matrices (ricci.py:152-197, 199-270).
 
 Pinning: tests/golden/balancer.pt, produced by running the reference's own code -- its two numba-CUDA kernel bodies executed
 thread by thread on the CPU (tools/oracle_shims/numba), its SDRF loop, RandomGraphBalancer and FlagModel.expand_graph with a
-balancer -- in the build container (generator tools/gen_golden_balancer.py).
+balancer -- in the build container (generator tests/golden/gen_golden_balancer.py).
 """
 from __future__ import annotations
 

@@ -7,7 +7,7 @@ reference's arithmetic, fp64 gives the reference value to compare fp32 implement
 cites the reference lines it follows (paths relative to /root/reference/src).
 
 Pinning: tests/golden/feat_*.pt, produced by running the reference's own FlagModel / CylinderModel /
-RemoteMessagePassing / util.triangles_to_edges in the build container (generator tools/gen_golden_features.py).
+RemoteMessagePassing / util.triangles_to_edges in the build container (generator tests/golden/gen_golden_features.py).
 """
 from __future__ import annotations
 

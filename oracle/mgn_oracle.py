@@ -6,13 +6,13 @@ baseline, never as the product).
 
 It is a plain-PyTorch (CPU, fp32 or fp64) *restatement* of the reference algorithm, written functionally
 over a ``state_dict`` that uses the reference's own key names, so that weights exported by the reference
-(tools/gen_golden.py) can be fed in unchanged.  Every function cites the reference lines it follows
+(tests/golden/gen_golden.py) can be fed in unchanged.  Every function cites the reference lines it follows
 (paths relative to /root/reference).  It keeps the reference's op sequence (two gathers + cat + three
 Linear + LayerNorm + residual; id broadcast + one scatter pass per aggregate) so that timing it on host
 cores measures "the reference's CPU path", not an optimised CPU variant.
 
 Pinning: checked against golden vectors produced by running the *reference itself* in the build container
-(tests/golden/*.pt, generator tools/gen_golden.py).  The reference's segment reductions come from the
+(tests/golden/*.pt, generator tests/golden/gen_golden.py).  The reference's segment reductions come from the
 third-party wheel ``torch-scatter==2.0.9`` which is absent from the image; its published semantics are
 restated in :func:`segment_reduce` (zero-initialised output, empty segment -> 0, mean = sum/max(cnt,1),
 max/min route gradients to the first arg).  For that primitive alone parity is "unpinned" (the reference

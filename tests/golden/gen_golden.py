@@ -4,7 +4,7 @@ Run in the build container only (the reference never travels):
 
     cd /root/reference && PYTHONDONTWRITEBYTECODE=1 PYTHONHASHSEED=0 \
       PYTHONPATH=/root/repo/tools/oracle_shims:/root/reference \
-      python /root/repo/tools/gen_golden.py --out /root/repo/tests/golden
+      python /root/repo/tests/golden/gen_golden.py --out /root/repo/tests/golden
 
 What is stored is data only: inputs, weights (reference key names), outputs, losses, gradients.
 The third-party torch_scatter wheel is replaced by tools/oracle_shims/torch_scatter (restated semantics).
@@ -15,7 +15,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from oracle import mgn_oracle as O            # only for init_state_dict / synthetic inputs (build-owned code)
 from tests import synth                        # build-owned synthetic graph generator
 

@@ -1,5 +1,5 @@
 """Pins oracle/balancer_oracle.py to outputs of the reference's own graph-balancer code (tests/golden/balancer.pt, generator
-tools/gen_golden_balancer.py: numba-CUDA kernel bodies emulated thread by thread, SDRF loop, random balancing, FlagModel
+tests/golden/gen_golden_balancer.py: numba-CUDA kernel bodies emulated thread by thread, SDRF loop, random balancing, FlagModel
 with a balancer).  CPU only."""
 import os
 

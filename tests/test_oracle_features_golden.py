@@ -1,6 +1,6 @@
 """Pins oracle/features_oracle.py (frame -> graph features, remote-graph assembly) to outputs of the reference's own
 FlagModel / CylinderModel / RemoteMessagePassing / util.triangles_to_edges (tests/golden/feat_*.pt, generator
-tools/gen_golden_features.py).  CPU only."""
+tests/golden/gen_golden_features.py).  CPU only."""
 import os
 
 import pytest

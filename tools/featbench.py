@@ -111,27 +111,8 @@ def main():
     res['cells_to_edges (64 meshes, 194 688 cells) ms'] = (time.perf_counter() - t0) / 5 * 1e3
 
     if not a.no_cpu:
-        from oracle import features_oracle as FO
-        from bench import host_cores
-        cores = host_cores()
-        torch.set_num_threads(cores)
-        ff = FO.FlagFeatures()
-        import numpy as np
-        lab = (np.arange(1600) // 100).tolist()
-        clusters = [torch.tensor([i for i in range(1600) if lab[i] == k]) for k in range(16)]
-        g = ff.build_graph(frames[0], True)
-        nb = FO.neighboring_clusters(g['edge_sets'][0].senders, g['edge_sets'][0].receivers, lab)
-        t0 = time.perf_counter()
-        n = 10
-        for i in range(n):
-            g = ff.build_graph(frames[i % 4], True)
-        t1 = time.perf_counter()
-        for i in range(n):
-            g = ff.build_graph(frames[i % 4], True)
-            FO.hierarchical_connect(g, clusters, nb, ff.intra_edge, ff.inter_edge, ff.hyper_node, True)
-        t2 = time.perf_counter()
-        res['cpu oracle'] = {'cores': cores, 'build_graph ms/frame': (t1 - t0) / n * 1e3,
-                             'build_graph+connect ms/frame': (t2 - t1) / n * 1e3}
+        from bench import cpu_baseline_features          # the oracle is timed by bench.py's cpu_baseline code only
+        res['cpu oracle'] = cpu_baseline_features(frames)
     print(json.dumps(res))
 
 

@@ -3,7 +3,7 @@
 The reference imports ``torch_scatter`` at ``src/util.py:5`` and calls ``scatter_add / scatter_max /
 scatter_mean / scatter_min`` at ``src/util.py:117-127``.  The wheel is not installed in this image and
 cannot be fetched, so this module restates its *published* CPU semantics so that the reference can be
-imported to generate golden vectors (tools/gen_golden.py):
+imported to generate golden vectors (tests/golden/gen_golden.py):
 
 * output is zero-initialised with ``dim_size`` rows; empty segments stay 0 for all four ops;
 * ``mean`` = sum / max(count, 1);

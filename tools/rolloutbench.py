@@ -50,18 +50,10 @@ def main():
         res[key] = {'edges': int(sum(e.senders.shape[0] for e in g.edge_sets)), 'eager_ms_per_step': eager,
                     'hip_graph_ms_per_step': replay, 'replay_bit_identical_to_eager': True}
         if not a.no_cpu and arch == 'none':
-            from oracle import mgn_oracle as O            # the checker's CPU path, timed beside (tools/ may use it like bench.py does)
-            from bench import host_cores
-            torch.set_num_threads(host_cores())
-            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            og = O.MultiGraph(list(g.node_features), [O.EdgeSet(*e) for e in g.edge_sets])
-            with torch.no_grad():
-                o_cpu = O.mesh_graph_net(sd, og, arch, agg)
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    O.mesh_graph_net(sd, og, arch, agg)
-            res[key]['cpu_oracle_ms_per_step'] = (time.perf_counter() - t0) / 5 * 1e3
-            res[key]['cpu_threads'] = host_cores()
+            from bench import cpu_baseline_forward          # the oracle is timed by bench.py's cpu_baseline code only
+            ms, cores, o_cpu = cpu_baseline_forward(model.state_dict(), g, arch, agg)
+            res[key]['cpu_oracle_ms_per_step'] = ms
+            res[key]['cpu_threads'] = cores
             res[key]['rel_err_vs_cpu_oracle'] = float((ref.cpu() - o_cpu).abs().max() / o_cpu.abs().max())
     print(json.dumps(res))
 
