@@ -262,6 +262,51 @@ def test_edge_block_fused_segment_sums(N, max_deg, seed):
         assert H.rel_err(a, b) <= 5e-6
 
 
+_VARIANT_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {pkg!r})
+from hgn_amd import ops, topology
+from tests import synth
+from tests.test_gpu_parity import _mlp_sd, _weights
+g = synth.grid_graph(seed=5, nx=30, ny=17)
+es = g.edge_sets[0]
+N, E = 30 * 17, es.senders.shape[0]
+topo = topology.EdgeTopology(es.senders, es.receivers, N, torch.device('cuda'))
+w, wts = _weights(_mlp_sd(384, 128, True, seed=5), True)
+wn, wnts = _weights(_mlp_sd(256, 128, True, seed=6), True)
+gen = torch.Generator().manual_seed(9)
+h = torch.randn(N, 128, generator=gen).cuda().requires_grad_(True)
+e = torch.randn(E, 128, generator=gen).cuda().requires_grad_(True)
+y, agg = ops.edge_block(h, e, topo, w, ('sum',))
+hn = ops.fused_mlp([h, agg], wn, None, 0)
+(hn.square().sum() + y.square().sum()).backward()
+torch.save([t.detach().cpu() for t in [y, agg, hn, h.grad, e.grad] + [p.grad for p in wts + wnts]], {out!r})
+"""
+
+
+def test_kernel_variants_behind_environment_switches(tmp_path):
+    """The diagnostic kernel variants kept in the library (HGN_TILE128: two sub-tiles per wave; HGN_WGRAD_RESPLIT: the previous
+    weight-gradient kernel) compute the same function as the defaults: one child process per setting (the switches are read
+    once per process), edge block + node MLP forward / backward compared with the default build of the same inputs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, 'hyper-graph-nets_amd')
+    outs = {}
+    for name, env in (('default', {}), ('tile128', {'HGN_TILE128': '1'}), ('resplit', {'HGN_WGRAD_RESPLIT': '1'})):
+        out = str(tmp_path / (name + '.pt'))
+        code = _VARIANT_SNIPPET.format(root=root, pkg=pkg, out=out)
+        r = subprocess.run([sys.executable, '-c', code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = torch.load(out)
+    for a, b in zip(outs['default'], outs['tile128']):
+        assert H.rel_err(a, b) <= 1e-6
+    for a, b in zip(outs['default'][:5], outs['tile128'][:5]):
+        assert torch.equal(a, b)                               # same arithmetic per row, only the tiling differs
+    for a, b in zip(outs['default'], outs['resplit']):
+        assert H.rel_err(a, b) <= 1e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # a4 + whole model: goldens generated by the reference, and oracle parity for every block type
 # ---------------------------------------------------------------------------------------------------------------
