@@ -1,6 +1,9 @@
 """Headline benchmark: processed edges/sec (fwd+bwd) on flag_simple-shape meshes (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N>1 without WORLD_SIZE in the environment: this process starts `python -m torch.distributed.run --nproc-per-node N
+        bench.py ...` as a CHILD (before anything touches the GPU) and exits with its code; under torch.distributed.run
+        (WORLD_SIZE set) it is one rank of the job: one process per GPU, RCCL over xGMI.
 
 A "step" is one full training step on this rank's batch of synthetic flag_simple-shape graphs: forward of the 15-layer
 MeshGraphNet (architecture none, latent 128, sum aggregation), masked-MSE loss, backward, gradient all-reduce (N>1)
@@ -12,6 +15,8 @@ bounded sample: one graph, full depth).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,8 +40,8 @@ def log(*a):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=128,
                     help='graphs per GPU (weak scaling: fixed per-GPU work); 128 = the saturating batch of SURVEY 8d')
     ap.add_argument('--layers', type=int, default=15)
@@ -159,11 +164,30 @@ def cpu_baseline_features(frames, iters=10):
     return {'cores': cores, 'build_graph ms/frame': (t1 - t0) / iters * 1e3, 'build_graph+connect ms/frame': (t2 - t1) / iters * 1e3}
 
 
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 outside a launcher: run the N ranks as children of this (GPU-untouched) process.  Rank 0 of the job prints
+    the JSON line on the shared stdout; a failed rank makes the launcher, and therefore this process, exit non-zero."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f'--gpus {args.gpus}: starting {args.gpus} ranks: {" ".join(cmd)}')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))                       # nothing above this line initialises the GPU
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        log(f'note: --gpus {args.gpus} but the launcher started {world} rank(s); reporting the {world} that run')
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     local = local % torch.cuda.device_count()          # several ranks may share a GPU only in a gloo rehearsal
     torch.cuda.set_device(local)
@@ -275,7 +299,10 @@ def main():
                                       f'{args.nx}x{args.ny} triangulated grid per graph ({per} nodes, {E_graph} directed '
                                       f'edges); full training step fwd+loss+bwd+allreduce+Adam',
                           'graphs_per_gpu': B, 'global_batch': B * world, 'edges_per_step': E_rank * world,
-                          'params': n_params, 'parallelism': f'dp{world}', 'loss': float(loss), 'hip_graph': bool(use_graph)}}
+                          'params': n_params, 'parallelism': f'dp{world}', 'loss': float(loss), 'hip_graph': bool(use_graph),
+                          'ranks': dist.get_world_size() if world > 1 else 1,
+                          'collective_backend': (dist.get_backend() if world > 1 else None),
+                          'gpus_visible_per_rank': torch.cuda.device_count()}}
         if prof:
             k = ops.prof_collect()
             log('profile collected')

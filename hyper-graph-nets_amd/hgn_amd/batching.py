@@ -9,39 +9,47 @@ Index mapping.  Node rows of the union are ordered [mesh rows of all graphs ; hy
 mis-mapping for batch sizes >= 2 (an id is treated as a hyper id only if it is >= ``B*n_mesh``, MeshSimulator.py:196,
 206-208) -- pinned by golden G6 -- for parity runs only.
 """
-from typing import Sequence
+from typing import Optional, Sequence
 
 import torch
 
 from .util import EdgeSet, MultiGraph
 
 
-def batch_graphs(graphs: Sequence[MultiGraph], reference_compat: bool = False) -> MultiGraph:
+def batch_graphs(graphs: Sequence[MultiGraph], reference_compat: bool = False, batch_size: Optional[int] = None) -> MultiGraph:
+    """``batch_size``: the configured batch size when it differs from ``len(graphs)`` (the last, shorter batch of a trajectory:
+    the reference offsets hyper ids by the CONFIGURED size, MeshSimulator.py:196); only used with ``reference_compat``."""
     B = len(graphs)
     if B == 0:
         raise ValueError('need at least one graph')
+    Bc = B if batch_size is None else int(batch_size)
     names = [e.name for e in graphs[0].edge_sets]
+    n_parts = len(graphs[0].node_features)
     n_mesh = graphs[0].node_features[0].shape[0]
-    n_hyp = graphs[0].node_features[1].shape[0] if len(graphs[0].node_features) > 1 else 0
+    n_hyp = graphs[0].node_features[1].shape[0] if n_parts > 1 else 0
     for g in graphs:
-        if [e.name for e in g.edge_sets] != names or g.node_features[0].shape[0] != n_mesh:
+        if [e.name for e in g.edge_sets] != names or g.node_features[0].shape[0] != n_mesh or len(g.node_features) != n_parts \
+                or (n_parts > 1 and g.node_features[1].shape[0] != n_hyp):
             raise ValueError('graphs of one batch must share edge-set names and node counts (the reference batches '
-                             'consecutive time steps of one trajectory)')
+                             'consecutive time steps of one trajectory; its offsets are i * num_nodes, MeshSimulator.py:191-196)')
     sets = []
     for k, name in enumerate(names):
         feats = torch.cat([g.edge_sets[k].features for g in graphs], dim=0)
+        # per-graph edge counts may differ (plate `world_edges`, `balance`, sampled remote sets vary per frame; the reference
+        # concatenates per-graph lists, MeshSimulator.py:186-231): graph index per edge instead of a [B, E] stack
+        lens = torch.tensor([g.edge_sets[k].senders.shape[0] for g in graphs])
         out = []
         for which in ('senders', 'receivers'):
-            idx = torch.stack([getattr(g.edge_sets[k], which).long() for g in graphs], dim=0)       # [B, E]
-            i = torch.arange(B, device=idx.device, dtype=idx.dtype).unsqueeze(1)
+            idx = torch.cat([getattr(g.edge_sets[k], which).long().reshape(-1) for g in graphs], dim=0)
+            i = torch.repeat_interleave(torch.arange(B, dtype=idx.dtype), lens).to(idx.device)
             mesh = idx + i * n_mesh
             if reference_compat:
-                hyp = idx + (B - 1) * n_mesh + i * n_hyp
-                res = torch.where(idx < B * n_mesh, mesh, hyp)
+                hyp = idx + (Bc - 1) * n_mesh + i * n_hyp
+                res = torch.where(idx < Bc * n_mesh, mesh, hyp)
             else:
                 hyp = (idx - n_mesh) + B * n_mesh + i * n_hyp
                 res = torch.where(idx < n_mesh, mesh, hyp)
-            out.append(res.reshape(-1))
+            out.append(res)
         sets.append(EdgeSet(name, feats, out[0], out[1]))
-    nodes = [torch.cat([g.node_features[j] for g in graphs], dim=0) for j in range(len(graphs[0].node_features))]
+    nodes = [torch.cat([g.node_features[j] for g in graphs], dim=0) for j in range(n_parts)]
     return MultiGraph(nodes, sets)

@@ -82,13 +82,15 @@ class GraphedTrainStep:
         if target is not None:
             self.target.copy_(target, non_blocking=True)
         self.graph.replay()
+        from . import ops
+        ops.invalidate_packs()      # the replayed Adam kernel rewrote the parameters: an eager forward must re-pack them
         return self.loss
 
 
 class GraphedShardStep:
     """Data-parallel step with the collectives OUTSIDE the graph: forward + local masked squared-error sum + backward of
-    this rank's shard are captured once and replayed; the two all-reduces (NORMAL-node count, flat gradient), the scaling to
-    the GLOBAL mean (flag.py:150-152 semantics over the whole batch) and the fused Adam stay eager.  Works for any world
+    this rank's shard are captured once and replayed; the single all-reduce ([flat gradient | NORMAL-node count]), the scaling
+    to the GLOBAL mean (flag.py:150-152 semantics over the whole batch) and the fused Adam stay eager.  Works for any world
     size (world 1: no collective), keeps the measured step independent of host-side launch jitter, and needs no support for
     capturing RCCL calls."""
 
@@ -126,21 +128,12 @@ class GraphedShardStep:
             torch.cuda.current_stream().wait_stream(tr.side)
         return s.detach()
 
-    def __call__(self) -> torch.Tensor:
-        import torch.distributed as dist
-        from . import ops
+    def __call__(self, node_features=None, edge_features: Optional[Dict[str, torch.Tensor]] = None, target=None) -> torch.Tensor:
         tr = self.trainer
-        self.graph.replay()
-        n_global = self.n_local.clone()
-        if tr.world > 1:
-            dist.all_reduce(n_global, group=tr.group)
-            dist.all_reduce(tr.fp.grad, group=tr.group)                       # ONE collective for all gradients
-        inv = 1.0 / (n_global * self.width)
-        tr.fp.grad.mul_(inv)                                                  # gradient of the global mean
-        tr.t += 1
-        if tr.t_dev is not None:
-            ops.adam_step_dev(tr.fp.flat, tr.fp.grad, tr.m, tr.v, tr.lr, tr.betas[0], tr.betas[1], tr.eps, tr.t_dev)
-        else:
-            tr.adam_fn(tr.fp.flat, tr.fp.grad, tr.m, tr.v, tr.lr, tr.betas[0], tr.betas[1], tr.eps, tr.t)
-        ops.invalidate_packs()
-        return (self.sq_sum * inv).squeeze(0)
+        if node_features is not None:
+            _copy_in(self.static, node_features, edge_features or {})
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        self.graph.replay()                                   # zero_grad + forward + local squared-error sum + backward
+        tr.fp.count.copy_(self.n_local)
+        return tr.reduce_and_update(self.sq_sum, self.width)  # one all-reduce (world > 1), global-mean scaling, Adam

@@ -170,7 +170,17 @@ def _alloc_saves(M, has_ln, dev):
     return z1, z2, xhat, rstd, bits
 
 
+def _zero_unaccumulated(bufs, accs):
+    """Rows == 0 (an empty edge set, e.g. plate `world_edges` with no obstacle in range): nothing to reduce.  Gradient buffers
+    that would have been OVERWRITTEN by the launch become zero; accumulating (flat-buffer) targets are left untouched."""
+    for b, acc in zip(bufs, accs):
+        if not acc:
+            b.zero_()
+
+
 def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False, keep=()):
+    if M == 0:          # operands of an empty set have null data pointers; the callers zero what the launch would have written
+        return
     side = _WGRAD_STREAM
     if side is not None:
         side.wait_stream(torch.cuda.current_stream())
@@ -344,6 +354,8 @@ class MLPFn(torch.autograd.Function):
                                     dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * (cols[i] + k0), ldw1,
                                     db1.data_ptr() if first else None, accs[0]))
                 first = False
+        if M == 0:
+            _zero_unaccumulated(bufs[:6], accs[:6])
         _run_wgrad(tasks, M, dev, keep=[z1, z2, dz1, dz2, dz3, *srcs])
         # ---- un-gather source gradients -----------------------------------------------------------------------
         for i in range(n_src):
@@ -507,6 +519,8 @@ class EdgeBlockFn(torch.autograd.Function):
                  _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2]),
                  _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
                         db1.data_ptr(), accs[0])]
+        if E == 0:      # dW1's node-row column blocks are written by the node-level launch below (from dP = 0)
+            _zero_unaccumulated(bufs[:6], accs[:6])
         _run_wgrad(tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
         ops = (C.c_int32 * 1)(0)
         _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N,

@@ -4,11 +4,12 @@ The reference has no distributed code at all; what must 
 single-process step on the concatenated batch (MeshSimulator.py:141-152 with FlagModel.training_step, flag.py:146-154):
 
   * graphs are independent, so the batch shards at graph granularity with NO collective on the data path;
-  * the loss is a mean over all NORMAL nodes of the *global* batch, so each rank back-propagates
-    sum(sq_err_local) / (n_global * out_dim)  (n_global is all-reduced once per step, a single scalar);
-  * gradients live in ONE flat fp32 buffer (parameter .grad tensors are views into it), summed with a single
-    all-reduce -- 9.3 MB for the 15-layer model; xGMI is point-to-point, so one large collective per step beats
-    many small ones -- and consumed by one fused Adam launch on the flat parameter buffer;
+  * the loss is a mean over all NORMAL nodes of the *global* batch: each rank back-propagates its local SUM of squared
+    errors, the NORMAL-node count rides in a spare slot behind the gradients, and after the all-reduce everything is scaled
+    by 1 / (n_global * out_dim) -- the gradient of the global mean, with no collective between forward and backward;
+  * gradients live in ONE flat fp32 buffer (parameter .grad tensors are views into it), summed -- together with that
+    count -- by a SINGLE all-reduce per step: 9.3 MB for the 15-layer model; xGMI is point-to-point, so one large
+    collective per step beats many small ones -- and consumed by one fused Adam launch on the flat parameter buffer;
   * Normalizer statistics are sum-reduced across ranks at every accumulate (normalizer.py:53-63) so all replicas
     normalise identically.
 """
@@ -42,7 +43,10 @@ class FlatParams:
             total += (p.numel() + 3) // 4 * 4
         dev = params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        # gradients + one spare 16-byte slot: [grad (total) | NORMAL-node count | 0 0 0] travel in ONE collective
+        self.grad_ext = torch.zeros(total + 4, dtype=torch.float32, device=dev)
+        self.grad = self.grad_ext[:total]
+        self.count = self.grad_ext[total:total + 1]
         for p, off in zip(params, self.offsets):
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
@@ -52,7 +56,7 @@ class FlatParams:
         self.numel = total
 
     def zero_grad(self):
-        self.grad.zero_()
+        self.grad_ext.zero_()
         for p, off in zip(self.params, self.offsets):     # autograd may have replaced .grad (e.g. after set_to_none)
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
@@ -100,18 +104,22 @@ class DataParallelTrainer:
             self.side.wait_stream(torch.cuda.current_stream())      # the zeroed gradient buffer is visible to the side stream
             ops.set_wgrad_stream(self.side)
         out = self.model(graph)
-        n_local = mask.sum().to(torch.float32).reshape(1)
-        n_global = n_local.clone()
-        if self.world > 1:
-            dist.all_reduce(n_global, group=self.group)
         diff = (out - target) * mask.unsqueeze(1).to(out.dtype)       # masked without boolean indexing: no host sync, capturable
-        loss = diff.square().sum() / (n_global * out.shape[1]).squeeze(0)     # this rank's share of the global mean
-        loss.backward()
+        sq = diff.square().sum()                                      # local SUM; scaled to the global mean after the collective
+        sq.backward()
         if self.side is not None:
             ops.set_wgrad_stream(None)
             torch.cuda.current_stream().wait_stream(self.side)      # join: all weight gradients are in the flat buffer
+        self.fp.count.copy_(mask.sum().to(torch.float32).reshape(1))
+        return self.reduce_and_update(sq.detach(), out.shape[1])
+
+    def reduce_and_update(self, sq_local: torch.Tensor, width: int) -> torch.Tensor:
+        """[gradients of the local squared-error sum | local NORMAL-node count] -> ONE all-reduce -> scale to the gradient of the
+        global mean (flag.py:150-152 over the whole batch) -> fused Adam.  Returns this rank's share of the global-mean loss."""
         if self.world > 1:
-            dist.all_reduce(self.fp.grad, group=self.group)                    # ONE collective for all gradients
+            dist.all_reduce(self.fp.grad_ext, group=self.group)               # the only collective of the step
+        inv = 1.0 / (self.fp.count * width)
+        self.fp.grad.mul_(inv)
         self.t += 1
         if self.t_dev is not None:
             from . import ops
@@ -121,7 +129,7 @@ class DataParallelTrainer:
         if self.fp.flat.is_cuda:
             from . import ops
             ops.invalidate_packs()                  # the Adam kernel rewrote the parameters behind torch's version counters
-        return loss.detach()
+        return (sq_local * inv).squeeze(0)
 
 
 def attach_normalizer_sync(normalizers: Iterable, group: Optional[dist.ProcessGroup] = None):

@@ -19,3 +19,18 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Parity figures recorded by tests.helpers.report -> gpurun_out/parity_report.jsonl (copied into profiles/ by hand)."""
+    try:
+        from tests import helpers as H
+        if H._REPORT:
+            import json
+            d = os.path.join(ROOT, 'gpurun_out')
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, 'parity_report.jsonl'), 'w') as f:
+                for r in H._REPORT:
+                    f.write(json.dumps(r) + '\n')
+    except Exception:
+        pass

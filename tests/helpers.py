@@ -17,6 +17,38 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
 
 
+def elem_err(a: torch.Tensor, b: torch.Tensor, atol_frac: float = 1e-2) -> float:
+    """Element-wise companion of rel_err: max_i |a_i - b_i| / (|b_i| + atol_frac * max|b|), i.e. the smallest rtol for which
+    torch.allclose(a, b, rtol, atol = rtol * atol_frac * max|b|) holds.  An element 100x below the tensor's scale is still
+    judged relative to 1 % of that scale; fp32 arithmetic (the reference's own included) cannot resolve less."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    if a.numel() == 0:
+        return 0.0
+    scale = max(float(b.abs().max()), 1e-30)
+    return float(((a - b).abs() / (b.abs() + atol_frac * scale)).max())
+
+
+_REPORT = []
+
+
+def report(test: str, what: str, got: torch.Tensor, exact: torch.Tensor, ref32: torch.Tensor = None):
+    """Record norm-wise and element-wise error of the HIP result (and, when given, of the reference's own fp32 arithmetic =
+    the oracle run in fp32) against the fp64 oracle; written to gpurun_out/parity_report.jsonl at the end of the session."""
+    rec = {'test': test, 'what': what, 'norm': rel_err(got, exact), 'elem': elem_err(got, exact)}
+    if ref32 is not None:
+        rec.update(ref_fp32_norm=rel_err(ref32, exact), ref_fp32_elem=elem_err(ref32, exact))
+    _REPORT.append(rec)
+    print('parity', rec)
+    return rec
+
+
+def worst_grad(grads, grads_exact):
+    """(norm-wise, element-wise) worst case over all parameters with a non-zero exact gradient."""
+    ks = [k for k in grads_exact if float(grads_exact[k].abs().max()) > 0]
+    return (max(rel_err(grads[k], grads_exact[k]) for k in ks), max(elem_err(grads[k], grads_exact[k]) for k in ks))
+
+
 def graph_from_fixture(fx):
     return O.MultiGraph([x.clone() for x in fx['graph']['node_features']],
                         [O.EdgeSet(n, f.clone(), s.clone(), r.clone()) for n, f, s, r in fx['graph']['edge_sets']])

@@ -276,6 +276,33 @@ def test_batcher_matches_reference_golden_g6():
             assert torch.equal(a.senders, b.senders) and torch.equal(a.receivers, b.receivers)
 
 
+def test_batcher_ragged_edge_counts_and_configured_batch_size():
+    """Per-graph edge counts may differ inside a batch (the reference concatenates per-graph lists, MeshSimulator.py:186-231);
+    a shorter last batch keeps the CONFIGURED batch size in the reference's hyper-id offset (MeshSimulator.py:196)."""
+    from hgn_amd import batching, util
+    def graph(n_edges, seed):
+        gen = torch.Generator().manual_seed(seed)
+        s = torch.randint(0, 6, (n_edges,), generator=gen)
+        r = torch.randint(0, 6, (n_edges,), generator=gen)
+        up_s, up_r = torch.arange(4), 4 + torch.arange(4) % 2
+        return util.MultiGraph([torch.randn(4, 2, generator=gen), torch.randn(2, 3, generator=gen)],
+                               [util.EdgeSet('mesh_edges', torch.randn(n_edges, 3, generator=gen), s, r),
+                                util.EdgeSet('intra_cluster_to_cluster', torch.randn(4, 3, generator=gen), up_s, up_r)])
+    graphs = [graph(3, 0), graph(4, 1), graph(0, 2)]
+    for compat in (False, True):
+        got = batching.batch_graphs(graphs, reference_compat=compat)
+        ora = O.batch_graphs([O.MultiGraph(g.node_features, [O.EdgeSet(*e) for e in g.edge_sets]) for g in graphs], reference_compat=compat)
+        for a, b in zip(got.edge_sets, ora.edge_sets):
+            assert torch.equal(a.senders, b.senders) and torch.equal(a.receivers, b.receivers) and torch.equal(a.features, b.features)
+        assert all(torch.equal(a, b) for a, b in zip(got.node_features, ora.node_features))
+    # last batch of a trajectory: 2 graphs under a configured batch size of 3 -> hyper threshold 3 * n_mesh = 12 (never reached)
+    short = batching.batch_graphs(graphs[:2], reference_compat=True, batch_size=3)
+    assert short.edge_sets[1].receivers.tolist() == [4, 5, 4, 5, 8, 9, 8, 9]
+    with pytest.raises(ValueError):
+        bad = util.MultiGraph([graphs[0].node_features[0], torch.zeros(3, 3)], graphs[0].edge_sets)     # differing n_hyper
+        batching.batch_graphs([graphs[0], bad])
+
+
 def test_shard_indices_partition():
     from hgn_amd import parallel
     for n, w in ((8, 8), (21, 8), (3, 2), (64, 4)):
