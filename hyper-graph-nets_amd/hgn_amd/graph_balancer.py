@@ -232,12 +232,17 @@ class GraphBalancer:
 
 
 def get_balancer(config) -> GraphBalancer:
-    """get_graph_balancer.py:11-27."""
+    """get_graph_balancer.py:11-15."""
     name = str(config['graph_balancer']['algorithm']).lower()
+    return GraphBalancer(get_balancer_algorithm(name, config))
+
+
+def get_balancer_algorithm(name: str, config):
+    """get_graph_balancer.py:18-27."""
     if name == 'ricci':
-        return GraphBalancer(Ricci(config))
+        return Ricci(config)
     if name == 'random':
-        return GraphBalancer(RandomGraphBalancer(config))
+        return RandomGraphBalancer(config)
     if name == 'none':
-        return GraphBalancer(None)
+        return None
     raise NotImplementedError('Implement your balancing algorithms here!')

@@ -374,26 +374,35 @@ class RemoteMessagePassing:
 
 
 def get_rmp(config) -> RemoteMessagePassing:
-    """get_rmp.py:20-98."""
+    """get_rmp.py:19-26."""
     rmp = config['rmp']
-    name, connector = str(rmp['clustering']).lower(), str(rmp['connector']).lower()
+    clustering = get_clustering_algorithm(str(rmp['clustering']).lower(), config)
+    connector = get_connector(str(rmp['connector']).lower(), config)
+    return RemoteMessagePassing(clustering, connector)
+
+
+def get_clustering_algorithm(name: str, config) -> Optional[AbstractClusteringAlgorithm]:
+    """get_rmp.py:29-81.  HDBSCAN (a third-party wheel in the reference, get_rmp.py:68-69) is not provided."""
+    rmp = config['rmp']
     samp = rmp.get('intra_cluster_sampling', {})
     args = (rmp['num_clusters'], samp.get('enabled', False), samp.get('alpha', 0.5), samp.get('spotter_threshold', 0))
     table = {'random': RandomClustering, 'spectral': SpectralClustering, 'gmm': GaussianMixtureClustering,
              'kmeans': KMeansClustering, 'k-means': KMeansClustering}
     if name == 'none':
-        clustering = None
-    elif name in table:
-        clustering = table[name](*args)
-    else:
-        raise NotImplementedError('Implement your clustering algorithms here!')
+        return None
+    if name in table:
+        return table[name](*args)
+    raise NotImplementedError('Implement your clustering algorithms here!')
+
+
+def get_connector(name: str, config) -> Optional[AbstractConnector]:
+    """get_rmp.py:84-96."""
+    rmp = config['rmp']
     noise = None if rmp['hyper_noise'] == 'none' else rmp['hyper_noise']
-    if connector in ('hyper', 'hetero', 'multiscale'):
-        conn = HierarchicalConnector(rmp['fully_connect'], noise, rmp['hyper_node_features'])
-    elif connector == 'multi':
-        conn = MultigraphConnector(rmp['fully_connect'], noise, rmp['hyper_node_features'])
-    elif connector in ('none', 'repeated'):
-        conn = None
-    else:
-        raise NotImplementedError('Implement your connectors here!')
-    return RemoteMessagePassing(clustering, conn)
+    if name in ('hyper', 'hetero', 'multiscale'):
+        return HierarchicalConnector(rmp['fully_connect'], noise, rmp['hyper_node_features'])
+    if name == 'multi':
+        return MultigraphConnector(rmp['fully_connect'], noise, rmp['hyper_node_features'])
+    if name in ('none', 'repeated'):
+        return None
+    raise NotImplementedError('Implement your connectors here!')

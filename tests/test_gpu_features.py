@@ -126,7 +126,8 @@ def test_normalizer_statistics_full_size_and_device_gate():
 # ----------------------------------------------------------------------------------------------------------------
 # FlagModel / CylinderModel build_graph, targets, update
 # ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('name', ['flag_none', 'flag_hyper_k5', 'flag_hyper_k3_full', 'flag_hyper_k4_sampled'])
+@pytest.mark.parametrize('name', ['flag_none', 'flag_hyper_k5', 'flag_hyper_k3_full', 'flag_hyper_k4_sampled',
+                                  'flag_hyper_k6_spectral', 'flag_hyper_k4_gmm'])
 def test_flag_model_features_match_reference_golden(name):
     from hgn_amd import system_model, util
     fx = load(name)
@@ -586,3 +587,53 @@ def test_flag_build_graph_batch_equals_per_frame_graphs():
         torch.testing.assert_close(na._acc_sum_squared, nb._acc_sum_squared, rtol=1e-5, atol=1e-4)
     out = b(got)
     assert out.shape == (B * 63, 3)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# config surface: every YAML of the reference constructs its system model (tests/golden/configs_model_sections.json =
+# the parsed `model` sections, generated by tests/golden/gen_config_fixture.py) and runs one training step
+# ----------------------------------------------------------------------------------------------------------------
+import json                                                                                         # noqa: E402
+
+CONFIGS = json.load(open(os.path.join(GOLDEN, 'configs_model_sections.json')))
+# parameter counts of the reference's own classes for these settings (probed through the reference)
+REF_PARAM_COUNTS = {'flag': 4196867, 'minimal': 1030659, 'plateCluster': 6112515}
+
+
+@pytest.mark.parametrize('name', sorted(CONFIGS))
+def test_get_model_constructs_from_every_reference_config(name):
+    """get_model(config) (src/model/get_model.py:13-22) with the reference's own key set (configs/*.yaml: flag -- spectral /
+    hyper K=16 --, minimal, plate, plateCluster -- spectral / hetero K=31 --, hyper, baseline, cylinder): constructs, expands
+    the remote graph with the configured clustering, and takes one training step; parameter counts equal the reference's."""
+    import random
+    import numpy as np
+    from hgn_amd import system_model
+    cfg = CONFIGS[name]
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    model = system_model.get_model({'task': cfg['task'], 'model': cfg['model']})
+    ds = cfg['task']['dataset']
+    if 'flag' in ds:
+        fr, want = synth.flag_frame(seed=1, nx=12, ny=10), system_model.FlagModel
+    elif 'plate' in ds:
+        fr, want = synth.plate_frame(seed=1), system_model.PlateModel
+    else:
+        fr, want = synth.cylinder_frame(seed=1, nx=10, ny=8), system_model.CylinderModel
+    assert type(model) is want
+    r = cfg['model']['rmp']
+    remote = r['clustering'] != 'none' and r['connector'] != 'none'
+    assert model.learned_model._message_passing_steps == cfg['model']['message_passing_steps']
+    assert model.learned_model._message_passing_aggregator == cfg['model']['aggregation']
+    assert type(model.learned_model.processor.graphnet_blocks[0]).__name__ == {
+        'hyper': 'HyperGraphNet', 'hetero': 'HeteroGraphNet', 'none': 'GraphNet'}[r['connector'] if remote else 'none']
+    g = model.build_graph(cuda_frame(fr), True)
+    mg = model.expand_graph(g, 0, 10, True)
+    if remote:
+        assert len(mg.node_features) == 2 and mg.node_features[1].shape[0] == r['num_clusters']
+        assert type(model._remote_graph._clustering_algorithm).__name__ == {
+            'spectral': 'SpectralClustering', 'kmeans': 'KMeansClustering'}[r['clustering']]
+    loss = model.training_step(mg, cuda_frame(fr))
+    loss.backward()
+    assert bool(torch.isfinite(loss))
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.learned_model.parameters())
+    if name in REF_PARAM_COUNTS:
+        assert sum(p.numel() for p in model.learned_model.parameters()) == REF_PARAM_COUNTS[name]

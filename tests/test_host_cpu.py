@@ -2,6 +2,7 @@
 validation answers with status codes (no compute), the module tree / state_dict contract, loud failure without a GPU,
 and the data-parallel host logic over gloo with world_size 2."""
 import ctypes as C
+import json
 import os
 import re
 import sys
@@ -153,18 +154,26 @@ def test_synthetic_edges_and_batcher():
         assert torch.equal(ea.senders, eb.senders) and torch.equal(ea.receivers, eb.receivers)
 
 
-def test_clustering_host_logic_matches_reference_labels():
-    """Cluster labels stay on scikit-learn (host, once per trajectory): same labels and neighbour pairs as the
-    reference produced for the golden frames (tests/golden/feat_flag_hyper_k5.pt)."""
+@pytest.mark.parametrize('fixture,cls,K', [('feat_flag_hyper_k5', 'KMeansClustering', 5),
+                                           ('feat_flag_hyper_k6_spectral', 'SpectralClustering', 6),
+                                           ('feat_flag_hyper_k4_gmm', 'GaussianMixtureClustering', 4)])
+def test_clustering_host_logic_matches_reference_labels(fixture, cls, K):
+    """Cluster labels stay on scikit-learn (host, once per trajectory): same labels, member lists and neighbour pairs as the
+    reference produced for the golden frames -- k-means (k_means_clustering.py:27-33), spectral on the edge-length affinity
+    (spectral_clustering.py:26-64: what flag.yaml / minimal.yaml / plateCluster.yaml configure) and Gaussian mixture
+    (gaussian_mixture.py:24-30).  `random` has no fixture: the reference's RandomClustering.run never sets
+    `neigboring_clusters`, so RemoteMessagePassing.create_graph raises at remote_message_passing.py:78."""
     from hgn_amd import rmp, util
-    fx = torch.load(os.path.join(ROOT, 'tests', 'golden', 'feat_flag_hyper_k5.pt'), weights_only=False)
+    fx = torch.load(os.path.join(ROOT, 'tests', 'golden', fixture + '.pt'), weights_only=False)
     fr, ex, ref = fx['frames'][0], fx['expanded'][0], fx['graphs'][0]
-    es = ref['edge_sets'][0]
+    es, ue = ref['edge_sets'][0], ref['unnormalized_edges']
     g = util.MultiGraphWithPos(node_features=ref['node_features'][0],
                                edge_sets=[util.EdgeSet('mesh_edges', es['features'], es['senders'], es['receivers'])],
                                target_feature=fr['world_pos'], mesh_features=fr['mesh_pos'], model_type='flag',
-                               node_dynamic=None, unnormalized_edges=None, obstacle_nodes=None)
-    alg = rmp.KMeansClustering(5, False, 0.1, 0)
+                               node_dynamic=None,
+                               unnormalized_edges=util.EdgeSet(ue['name'], ue['features'], ue['senders'], ue['receivers']),
+                               obstacle_nodes=None)
+    alg = getattr(rmp, cls)(K, False, 0.1, 0)
     clusters = alg.run(g)
     assert alg._labels == ex['labels']
     assert all(torch.equal(a, b) for a, b in zip(clusters, ex['clusters']))
@@ -301,6 +310,31 @@ def test_batcher_ragged_edge_counts_and_configured_batch_size():
     with pytest.raises(ValueError):
         bad = util.MultiGraph([graphs[0].node_features[0], torch.zeros(3, 3)], graphs[0].edge_sets)     # differing n_hyper
         batching.batch_graphs([graphs[0], bad])
+
+
+def test_random_clustering_formula_and_get_rmp_surface():
+    """random_clustering.py:38-39: label = int(rand * K) per node from numpy's global generator; get_rmp.py's three functions
+    exist with the reference's names and accept the reference's config keys (incl. every clustering / connector name)."""
+    import numpy as np
+    from hgn_amd import rmp, util
+    g = util.MultiGraphWithPos(None, [util.EdgeSet('mesh_edges', None, torch.tensor([0, 1, 2]), torch.tensor([1, 2, 3]))],
+                               torch.zeros(9, 3), None, 'flag', None, None, None)
+    np.random.seed(3)
+    want = [int(x) for x in np.random.rand(9) * 4]
+    np.random.seed(3)
+    assert rmp.RandomClustering(4, False, 0.1, 0)._cluster(g) == want
+    cfgs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'configs_model_sections.json')))
+    for name, cfg in cfgs.items():
+        r = cfg['model']['rmp']
+        alg = rmp.get_clustering_algorithm(str(r['clustering']).lower(), cfg['model'])
+        conn = rmp.get_connector(str(r['connector']).lower(), cfg['model'])
+        assert (alg is None) == (r['clustering'] == 'none') and (conn is None) == (r['connector'] in ('none', 'repeated')), name
+    for cl in ('random', 'spectral', 'gmm', 'kmeans', 'k-means', 'none'):
+        rmp.get_clustering_algorithm(cl, cfgs['flag']['model'])
+    with pytest.raises(NotImplementedError):
+        rmp.get_clustering_algorithm('hdbscan', cfgs['flag']['model'])        # third-party wheel in the reference; not provided
+    with pytest.raises(NotImplementedError):
+        rmp.get_connector('multigraph', cfgs['flag']['model'])                # get_rmp.py:92 rejects it too (SURVEY section 9-6)
 
 
 def test_shard_indices_partition():
