@@ -33,6 +33,42 @@ __global__ void csr_rowptr_kernel(const int* __restrict__ seg, long E, long N, i
   rowptr[n] = (int)lo;
 }
 
+// longest CSR row (the fused in-kernel segment sums need it, include/hgn_mp.h: seg_out) -> flag[1], read back with the range flag
+__global__ void csr_max_rows_kernel(const int* __restrict__ rowptr, long N, int* __restrict__ flag) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int len = n < N ? rowptr[n + 1] - rowptr[n] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
+  if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(flag + 1, len);
+}
+
+// Order-independent 64-bit fingerprints of two int64 index arrays (position-salted splitmix64, summed mod 2^64 with integer
+// atomics): the key under which a topology built from EQUAL index content is found again (topology cache of the host side).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void index_fingerprint_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, long n,
+                                                                unsigned long long* __restrict__ out) {
+  unsigned long long ha = 0, hb = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned long long salt = (unsigned long long)i * 0xd6e8feb86659fd93ull;
+    ha += mix64((unsigned long long)a[i] ^ salt);
+    if (b) hb += mix64((unsigned long long)b[i] + salt);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ha += __shfl_xor(ha, o);
+    hb += __shfl_xor(hb, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, ha);
+    atomicAdd(out + 1, hb);
+  }
+}
+
 __global__ void narrow_gather_kernel(const int64_t* __restrict__ src, const int* __restrict__ perm, long n,
                                      int* __restrict__ dst) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -240,7 +276,7 @@ extern "C" int hgn_csr_workspace_bytes(int64_t E, int64_t N, size_t* bytes) {
 }
 
 extern "C" int hgn_csr_build(const int64_t* ids, int64_t E, int64_t N, int32_t* perm, int32_t* seg, int32_t* rowptr,
-                             void* workspace, size_t ws_bytes, void* stream_) {
+                             void* workspace, size_t ws_bytes, int32_t* max_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   size_t need = 0;
   if (hgn_csr_workspace_bytes(E, N, &need) != HGN_OK) return HGN_E_INVALID;
@@ -263,12 +299,34 @@ extern "C" int hgn_csr_build(const int64_t* ids, int64_t E, int64_t N, int32_t* 
   }
   hipLaunchKernelGGL(csr_rowptr_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, stream, seg, (long)E, (long)N,
                      rowptr);
-  int host_flag = 0;
-  if (hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+  if (max_rows && N > 0)
+    hipLaunchKernelGGL(csr_max_rows_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, rowptr, (long)N, flag);
+  int host_flag[2] = {0, 0};
+  if (hipMemcpyAsync(host_flag, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
       hipStreamSynchronize(stream) != hipSuccess)
     return hgn_check_launch("hgn_csr_build readback");
-  if (host_flag) return hgn_fail(HGN_E_RANGE, "hgn_csr_build: segment id outside [0, num_segments)");
+  if (host_flag[0]) return hgn_fail(HGN_E_RANGE, "hgn_csr_build: segment id outside [0, num_segments)");
+  if (max_rows) *max_rows = host_flag[1];
   return hgn_check_launch("hgn_csr_build");
+}
+
+extern "C" int hgn_index_fingerprint(const int64_t* a, const int64_t* b, int64_t n, uint64_t* out_dev, uint64_t* out_host,
+                                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!out_dev || n < 0 || (n > 0 && !a)) return hgn_fail(HGN_E_INVALID, "hgn_index_fingerprint: bad argument");
+  if (hipMemsetAsync(out_dev, 0, 16, stream) != hipSuccess) return hgn_check_launch("hgn_index_fingerprint memset");
+  if (n > 0) {
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(index_fingerprint_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, b, (long)n,
+                       reinterpret_cast<unsigned long long*>(out_dev));
+  }
+  if (out_host) {
+    if (hipMemcpyAsync(out_host, out_dev, 16, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+      return hgn_check_launch("hgn_index_fingerprint readback");
+  }
+  return hgn_check_launch("hgn_index_fingerprint");
 }
 
 extern "C" int hgn_narrow_gather_i64(const int64_t* src, const int32_t* perm, int64_t n, int32_t* dst, void* stream) {

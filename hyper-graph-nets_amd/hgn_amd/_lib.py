@@ -73,7 +73,8 @@ _SIGS = {
     'hgn_version': (C.c_int, []),
     'hgn_csr_workspace_bytes': (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     'hgn_csr_build': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_size_t, C.c_void_p]),
+                                C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]),
+    'hgn_index_fingerprint': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     'hgn_narrow_gather_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'hgn_segment_reduce_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int64, C.c_void_p,

@@ -13,7 +13,23 @@ from typing import Optional, Sequence
 
 import torch
 
+from . import topology
 from .util import EdgeSet, MultiGraph
+
+
+class _UnionKey:
+    """Topology key of "B copies of ONE per-graph edge list": holds the per-graph index tensors (so their identity stays
+    meaningful) plus everything else the batched ids depend on.  Equal keys <=> equal batched index content."""
+    __slots__ = ('s', 'r', 'extra')
+
+    def __init__(self, s, r, extra):
+        self.s, self.r, self.extra = s, r, (s._version, r._version) + tuple(extra)
+
+    def __hash__(self):
+        return hash((id(self.s), id(self.r), self.extra))
+
+    def __eq__(self, o):
+        return isinstance(o, _UnionKey) and o.s is self.s and o.r is self.r and o.extra == self.extra
 
 
 def batch_graphs(graphs: Sequence[MultiGraph], reference_compat: bool = False, batch_size: Optional[int] = None) -> MultiGraph:
@@ -50,6 +66,12 @@ def batch_graphs(graphs: Sequence[MultiGraph], reference_compat: bool = False, b
                 hyp = (idx - n_mesh) + B * n_mesh + i * n_hyp
                 res = torch.where(idx < n_mesh, mesh, hyp)
             out.append(res)
+        # all graphs of the batch share ONE edge-index tensor pair (frames of one trajectory: the system models hand out the
+        # cached two-way edges of the mesh): the union's topology is named by (that pair, B, ...) -- level 2 of the topology
+        # cache, no fingerprint pass and no sort when the next batch of the trajectory comes by
+        s0, r0 = graphs[0].edge_sets[k].senders, graphs[0].edge_sets[k].receivers
+        if all(g.edge_sets[k].senders is s0 and g.edge_sets[k].receivers is r0 for g in graphs):
+            topology.tag_topology(out[0], out[1], _UnionKey(s0, r0, (B, Bc, n_mesh, n_hyp, bool(reference_compat))))
         sets.append(EdgeSet(name, feats, out[0], out[1]))
     nodes = [torch.cat([g.node_features[j] for g in graphs], dim=0) for j in range(n_parts)]
     return MultiGraph(nodes, sets)

@@ -52,7 +52,16 @@ int hgn_version(void);
  * ---------------------------------------------------------------------------------------------------- */
 int hgn_csr_workspace_bytes(int64_t num_edges, int64_t num_segments, size_t* bytes /*host*/);
 int hgn_csr_build(const int64_t* ids, int64_t num_edges, int64_t num_segments, int32_t* perm, int32_t* seg,
-                  int32_t* rowptr, void* workspace, size_t workspace_bytes, void* stream);
+                  int32_t* rowptr, void* workspace, size_t workspace_bytes,
+                  int32_t* max_rows /*host, nullable: length of the longest row, from the same read-back as the range check*/,
+                  void* stream);
+/* Fingerprints of index CONTENT (two 64-bit words: one per array; b may be null): equal arrays give equal words whatever
+ * tensor object holds them.  The reference builds fresh batched index tensors for every batch (MeshSimulator.py:159-234) although
+ * all batches of a trajectory share one mesh: the host keys its topology cache on these words, so the sorts run once per
+ * mesh, not once per step.  out_dev: 16 bytes of device scratch; out_host (nullable): the words are copied there and the
+ * stream is synchronised (like hgn_csr_build: topology preprocessing). */
+int hgn_index_fingerprint(const int64_t* a, const int64_t* b, int64_t n, uint64_t* out_dev, uint64_t* out_host /*host*/,
+                          void* stream);
 /* dst[i] = (int32) src[perm ? perm[i] : i]   (reorders the *other* endpoint list into sorted order) */
 int hgn_narrow_gather_i64(const int64_t* src, const int32_t* perm, int64_t n, int32_t* dst, void* stream);
 

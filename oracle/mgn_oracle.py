@@ -37,29 +37,59 @@ PNA_OPS = ('sum', 'mean', 'max', 'min')                                         
 # a2: unsorted_segment_operation (src/util.py:92-134) on top of restated torch_scatter semantics
 # --------------------------------------------------------------------------------------------------------
 class _FirstArgReduce(torch.autograd.Function):
-    """scatter_max / scatter_min with torch_scatter's CPU tie rule (strict compare -> first element wins)."""
+    """scatter_max / scatter_min with torch_scatter's CPU tie rule (strict compare -> the first element wins; empty -> 0,
+    arg = E).  Built on a STABLE SORT by segment id and a scan inside the sorted runs -- deliberately not the construction of
+    the import stand-in (tools/oracle_shims/torch_scatter: scatter_reduce + candidate indices) nor of the brute-force loops
+    (oracle/scatter_loops.py); tests/test_oracle_golden.py checks the three against each other and against golden G1."""
 
     @staticmethod
     def forward(ctx, src, index, num_segments, is_max):
         E = src.shape[0]
-        init = src.new_zeros((num_segments,) + tuple(src.shape[1:]))
-        val = init.scatter_reduce(0, index, src, reduce='amax' if is_max else 'amin', include_self=False)
-        hit = src == val.gather(0, index)
-        eid = torch.arange(E).view((E,) + (1,) * (src.dim() - 1)).expand_as(src)
-        cand = torch.where(hit, eid, torch.full_like(eid, E))
-        arg = torch.full(init.shape, E, dtype=torch.long).scatter_reduce(0, index, cand, reduce='amin',
-                                                                         include_self=True)
+        D = 1
+        for n in src.shape[1:]:
+            D *= int(n)
+        flat = src.reshape(E, D)
+        ids = index.reshape(E, D)
+        out = flat.new_zeros(num_segments, D)
+        arg = torch.full((num_segments, D), E, dtype=torch.long)
+        if E > 0 and D > 0:
+            key = flat if is_max else -flat
+            # every column independently (2-D sorts along dim 0): rank the elements by (segment asc, value desc, original
+            # position asc) with three stable sorts; the head of each run of equal segment ids is that segment's FIRST maximum
+            order = torch.sort(ids, dim=0, stable=True).indices                  # original order kept inside a segment
+            sseg, sval = ids.gather(0, order), key.gather(0, order)
+            o2 = torch.sort(sval, dim=0, stable=True, descending=True).indices
+            o3 = torch.sort(sseg.gather(0, o2), dim=0, stable=True).indices
+            lead = o2.gather(0, o3)
+            seg_sorted = sseg.gather(0, lead)
+            head = torch.ones(E, D, dtype=torch.bool)
+            head[1:] = seg_sorted[1:] != seg_sorted[:-1]
+            winners = order.gather(0, lead)[head]                                # original element ids of the winners
+            cols = torch.arange(D).expand(E, D)[head]
+            rows = seg_sorted[head]
+            out[rows, cols] = flat[winners, cols]
+            arg[rows, cols] = winners
+        shape = (num_segments,) + tuple(src.shape[1:])
+        arg = arg.reshape(shape)
         ctx.save_for_backward(arg)
         ctx.E = E
         ctx.mark_non_differentiable(arg)
-        return val, arg
+        return out.reshape(shape), arg
 
     @staticmethod
     def backward(ctx, gval, _):
         (arg,) = ctx.saved_tensors
-        g = gval.new_zeros((ctx.E + 1,) + tuple(gval.shape[1:]))
-        g.scatter_(0, arg, gval)
-        return g[:ctx.E], None, None, None
+        E = ctx.E
+        D = 1
+        for n in gval.shape[1:]:
+            D *= int(n)
+        g = gval.new_zeros(E, D)
+        a2, gv = arg.reshape(-1, D), gval.reshape(-1, D)
+        live = a2 < E
+        cols = torch.arange(D).expand_as(a2)
+        g[a2[live], cols[live]] = gv[live]
+        g = g.reshape((E,) + tuple(gval.shape[1:]))
+        return g, None, None, None
 
 
 def segment_reduce(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: int, operation: str,

@@ -17,6 +17,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from oracle import mgn_oracle as O            # only for init_state_dict / synthetic inputs (build-owned code)
+from oracle import scatter_loops as SL         # brute-force element loops: the third, independent statement of torch_scatter
 from tests import synth                        # build-owned synthetic graph generator
 
 from src.migration.meshgraphnet import MeshGraphNet          # noqa: E402  (the reference)
@@ -80,6 +81,7 @@ def hash_name(s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', required=True)
+    ap.add_argument('--only-g1', action='store_true')
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(4)
@@ -102,7 +104,38 @@ def main():
             w = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
             (y * w).sum().backward()
             g1['out'][f'{op}_{nm}'] = {'y': y.detach().clone(), 'w': w, 'gx': x.grad.clone()}
+    # Adversarial cases + a brute-force evaluation (oracle/scatter_loops.py: per-element Python loops restating torch-scatter
+    # 2.0.9's documented semantics -- zero-filled empty segments, mean = sum / max(count, 1), strict compare so the FIRST of
+    # equal values wins, gradient to that single element).  The reference's outputs above and below come through the import
+    # stand-in tools/oracle_shims/torch_scatter; 'bf' is computed independently of it, so a wrong empty-segment or tie rule in
+    # the stand-in (and in the oracle, which is a third construction) shows up as a mismatch against 'bf'.
+    gen2 = torch.Generator().manual_seed(11)
+    adv = {}
+    quant = (torch.randn(60, 8, generator=gen2) * 2).round()                  # few distinct values: ties in every segment
+    adv['ties'] = (quant, torch.randint(0, 6, (60,), generator=gen2), 9)       # segments 6..8 empty
+    adv['all_equal'] = (torch.full((12, 4), -1.5), torch.tensor([2, 2, 2, 0, 0, 0, 0, 5, 5, 2, 0, 5]), 6)
+    adv['single_and_empty'] = (torch.randn(3, 5, generator=gen2), torch.tensor([4, 4, 1]), 7)
+    adv['negatives_only'] = (-torch.rand(20, 3, generator=gen2) - 0.5, torch.randint(0, 4, (20,), generator=gen2), 5)
+    adv['one_d_ties'] = ((torch.randn(40, generator=gen2)).round(), torch.randint(0, 5, (40,), generator=gen2), 6)
+    g1['adversarial'] = {}
+    for cname, (dat, cid, n) in list(adv.items()) + [('g1_2d', (data2, ids, N)), ('g1_1d', (data1, ids, N))]:
+        rec = {'data': dat, 'ids': cid, 'num_segments': n, 'ref': {}, 'bf': {}}
+        for op in ('sum', 'mean', 'max', 'min'):
+            x = dat.clone().requires_grad_(True)
+            y = ref_util.unsorted_segment_operation(x, cid, n, op)
+            w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3))
+            (y * w).sum().backward()
+            rec['ref'][op] = {'y': y.detach().clone(), 'w': w, 'gx': x.grad.clone()}
+            o, arg, gx = SL.segment_op(dat, cid, n, op, w)
+            rec['bf'][op] = {'y': o, 'arg': arg, 'gx': gx}
+            # the generator itself refuses to write a fixture in which the reference-through-stand-in and the loops disagree
+            assert torch.allclose(y.detach().double(), o.double(), rtol=1e-6, atol=1e-6), (cname, op)
+            assert torch.allclose(x.grad.double(), gx, rtol=1e-6, atol=1e-6), (cname, op)
+        g1['adversarial'][cname] = rec
     torch.save(g1, os.path.join(a.out, 'g1_segment_ops.pt'))
+    if a.only_g1:
+        print('G1 done')
+        return
 
     # ---- G2-G4: model-level goldens ---------------------------------------------------------------------
     set_order = list({'mesh_edges', 'world_edges'})      # iteration order under this PYTHONHASHSEED
