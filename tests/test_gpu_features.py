@@ -634,6 +634,11 @@ def test_get_model_constructs_from_every_reference_config(name):
     loss = model.training_step(mg, cuda_frame(fr))
     loss.backward()
     assert bool(torch.isfinite(loss))
-    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.learned_model.parameters())
+    # (the hyper-row update of the LAST hetero block feeds nothing the decoder reads: those parameters get no gradient, in
+    #  the reference as well -- heterographnet.py:29-32 + meshgraphnet.py:50)
+    named = list(model.learned_model.named_parameters())
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for _, p in named)
+    last = f'graphnet_blocks.{cfg["model"]["message_passing_steps"] - 1}.hyper_node_model_cross'
+    assert all(p.grad is not None for k, p in named if last not in k), [k for k, p in named if p.grad is None and last not in k]
     if name in REF_PARAM_COUNTS:
         assert sum(p.numel() for p in model.learned_model.parameters()) == REF_PARAM_COUNTS[name]
