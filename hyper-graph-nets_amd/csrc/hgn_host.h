@@ -10,6 +10,13 @@ int hgn_check_launch(const char* what);
 int matmul_products();                            // 6 (fp32-accurate split products) or 1 (single bf16 product): hgn_set_matmul_products
 extern thread_local int g_prof_tag;           // hipGetLastError() -> HGN_OK / HGN_E_LAUNCH
 
+// Fixed-order reductions shared between translation units (wgrad.hip / mlp.hip own the kernels).
+//   slab reduce: dW[j][k] (+)= sum over chunks c of slab[c * chunk_stride + j * 128 + k], db[j] (+)= ... slab[c * chunk_stride + 128 * 128 + j]
+struct SlabReduceTask { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; long chunk_stride; };
+int launch_slab_reduce(const SlabReduceTask* tasks, int n_tasks, hipStream_t stream);                 // n_tasks <= HGN_MAX_WTASK
+//   LayerNorm-affine gradients from n_slabs per-workgroup slabs of 256 floats; `part`: LN_PARTS * 256 floats of scratch
+int launch_ln_reduce(const float* ws, long n_slabs, float* part, float* d_gamma, float* d_beta, int accumulate, hipStream_t stream);
+
 // Records a HIP event pair around the launches issued in its scope when profiling is enabled.
 struct ProfScope {
   int kid; hipStream_t stream; bool on; int slot;

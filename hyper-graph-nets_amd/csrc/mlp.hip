@@ -263,6 +263,12 @@ __global__ __launch_bounds__(WG, 4) void linear_bwd_kernel(const LinArgs a) {
   if (valid) t_store(acc, a.out + row * a.ld_out, kq);
 }
 
+int launch_ln_reduce(const float* ws, long n_slabs, float* part, float* d_gamma, float* d_beta, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(LN_PARTS), dim3(256), 0, stream, ws, n_slabs, part);
+  hipLaunchKernelGGL(ln_final_kernel, dim3(1), dim3(256), 0, stream, part, d_gamma, d_beta, accumulate);
+  return hgn_check_launch("LayerNorm gradient reduce");
+}
+
 }  // namespace hgn
 
 namespace hgn { int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream); int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs); }

@@ -1,0 +1,118 @@
+// Device building blocks of the split-bf16 kernels (csrc/mlp6.hip, csrc/fused_bwd.hip): operand-tile geometry of the packed
+// weights (hgn_pack_bf16x3), the 3-way bf16 split, LDS-DMA staging of half a packed block and the six-product MFMA sweep.
+#pragma once
+#include "hgn_device.h"
+#include "mlp_common.h"
+
+namespace hgn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int TILE_BF16 = 512;                     // one 16 x 32 operand tile: 64 lanes x 8 bf16 = 1 KiB
+constexpr int HALF_TILES = 3 * 2 * 8;              // splits x contraction blocks of the half x output blocks
+constexpr int HALF_BF16 = HALF_TILES * TILE_BF16;  // 48 KB
+constexpr int BLOCK_BF16 = 2 * HALF_BF16;          // one packed 128 x 128 block: 96 KB (= HGN_PACK_BLOCK_BYTES)
+
+// ----------------------------------------------------------------------------------------------------------
+// device building blocks
+// ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(const Act& x, bf16x8 (&s)[3][4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = x.v[2 * c + (j >> 2)][j & 3];
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 m = (__bf16)r1;
+      const float r2 = r1 - (float)m;
+      s[0][c][j] = h; s[1][c][j] = m; s[2][c][j] = (__bf16)r2;
+    }
+}
+
+// NP = 1 (single bf16 product): only the leading split of the weights is staged (the first third of the half's tiles)
+template <int NP>
+__device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf16* __restrict__ gsrc) {
+  unsigned lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  const unsigned wave = threadIdx.x >> 6;
+#pragma unroll
+  for (unsigned i = wave; i < (NP == 1 ? HALF_TILES / 3 : HALF_TILES); i += WG / 64)          // one operand tile (1 KiB) per wave instruction
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
+                                     (__attribute__((address_space(3))) void*)(lds + i * TILE_BF16), 16, 0, 0);
+}
+
+// A wave owns NS sub-tiles of 16 rows; every operand fragment read from LDS is multiplied with all of them.
+template <int HALF, int NS, int NP>
+__device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS][3][4], const __bf16* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl) {
+    const int c = 2 * HALF + cl;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+      if (NP == 1) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) acc[u].v[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][0][c], acc[u].v[ob], 0, 0, 0);
+        continue;
+      }
+      const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+      const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(lds + ((2 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        f32x4 t = acc[u].v[ob];
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, xs[u][0][c], t, 0, 0, 0);      // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][2][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[u][1][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[u][0][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][1][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][0][c], t, 0, 0, 0);
+        acc[u].v[ob] = t;
+      }
+    }
+  }
+}
+
+// acc[u][ob] += Wblock * b[u] for one packed 128 x 128 block.  `between()` runs after the first half's DMA has been issued and
+// before the wait (the caller's own global loads fly with it); `b` is split after the wait, so `between` may load it.
+template <int NS, int NP, class F>
+__device__ __forceinline__ void gemm6(Act (&acc)[NS], const Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
+                                      F&& between) {
+  bf16x8 xs[NS][3][4];
+  wg_barrier_lds();
+  stage_half6<NP>(lds, pk);
+  between();
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
+  mfma_half6<0, NS, NP>(acc, xs, lds);
+  wg_barrier_lds();
+  stage_half6<NP>(lds, pk + HALF_BF16);
+  __syncthreads();
+  mfma_half6<1, NS, NP>(acc, xs, lds);
+}
+
+__device__ __forceinline__ void relu6(Act& a) {
+  HGN_FOR_B(fb)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a.v[fb][u] = fmaxf(a.v[fb][u], 0.f);
+}
+
+// Rows of a workgroup: NS sub-tiles of 64 consecutive rows, sub-tile u of wave w = rows 64u + 16w .. +15 of the tile (each
+// sub-tile is a contiguous 64-row block, which the in-kernel segment sums rely on).
+template <int NS>
+struct Rows {
+  long row[NS], rc[NS]; bool valid[NS]; long tile_row0;
+  __device__ __forceinline__ Rows(long M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tile_row0 = xcd_tile() * (TILE_ROWS * NS);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      row[u] = tile_row0 + u * TILE_ROWS + wave * WAVE_ROWS + (lane & 15);
+      valid[u] = row[u] < M;
+      rc[u] = valid[u] ? row[u] : M - 1;
+    }
+  }
+};
+
+}  // namespace hgn

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
     slab[128 * 128 + threadIdx.x] = (csl[threadIdx.x] + csl[128 + threadIdx.x]) + (csl[256 + threadIdx.x] + csl[384 + threadIdx.x]);
 }
 
-struct RTaskDev { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; };
+struct RTaskDev { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; long stride; };
 struct RArgs { RTaskDev t[HGN_MAX_WTASK]; };
 
 // Fixed-order sum of the chunk slabs.  512 threads = 64 consecutive slab elements x 8 chunk groups: group g adds the chunks
@@ -481,11 +481,12 @@ __global__ __launch_bounds__(RED_ELEMS * RED_GROUPS) void wgrad_reduce_kernel(co
   if (live) {
     const float* p = t.slab + e;
     int c = grp;
+    const long st = t.stride;
     for (; c + 3 * RED_GROUPS < t.n_chunks; c += 4 * RED_GROUPS) {
-      s0 += p[(long)c * SLAB]; s1 += p[(long)(c + RED_GROUPS) * SLAB];
-      s2 += p[(long)(c + 2 * RED_GROUPS) * SLAB]; s3 += p[(long)(c + 3 * RED_GROUPS) * SLAB];
+      s0 += p[(long)c * st]; s1 += p[(long)(c + RED_GROUPS) * st];
+      s2 += p[(long)(c + 2 * RED_GROUPS) * st]; s3 += p[(long)(c + 3 * RED_GROUPS) * st];
     }
-    for (; c < t.n_chunks; c += RED_GROUPS) s0 += p[(long)c * SLAB];
+    for (; c < t.n_chunks; c += RED_GROUPS) s0 += p[(long)c * st];
   }
   part[grp][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -547,6 +548,18 @@ static int chunks_ln(long M) {
   return (int)c;
 }
 
+int launch_slab_reduce(const SlabReduceTask* tasks, int n_tasks, hipStream_t stream) {
+  if (!tasks || n_tasks < 1 || n_tasks > HGN_MAX_WTASK) return hgn_fail(HGN_E_INVALID, "launch_slab_reduce: bad task list");
+  RArgs ra;
+  for (int i = 0; i < n_tasks; ++i) {
+    const SlabReduceTask& t = tasks[i];
+    ra.t[i] = {t.type, t.K, t.n_out, t.acc, t.n_chunks, t.dW, t.ldw, t.db, t.slab, t.chunk_stride};
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + RED_ELEMS - 1) / RED_ELEMS, (unsigned)n_tasks), dim3(RED_ELEMS * RED_GROUPS), 0,
+                     stream, ra);
+  return hgn_check_launch("slab reduce");
+}
+
 }  // namespace hgn
 
 using namespace hgn;
@@ -588,7 +601,7 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
       return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad task");
     const int nch = q < n0 ? nch0 : nch1;
     wa.t[q] = {t.type, t.A, (long)t.lda, t.K, t.idxA, t.G, (long)t.ldg, slab + off};
-    ra.t[q] = {t.type, t.K, t.n_out, t.accumulate ? 1 : 0, nch, t.dW, (long)t.ldw, t.db, slab + off};
+    ra.t[q] = {t.type, t.K, t.n_out, t.accumulate ? 1 : 0, nch, t.dW, (long)t.ldw, t.db, slab + off, (long)SLAB};
     off += (size_t)nch * SLAB;
   }
   auto rows_per = [&](int nch, int mult) {

@@ -14,10 +14,10 @@ HGN_MAX_ADD = 2
 HGN_MAX_WTASK = 16
 PACK_BLOCK_BYTES = 98304
 HGN_MAX_PACK = 32
-NUM_KERNEL_IDS = 14
+NUM_KERNEL_IDS = 15
 OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
 KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
-                'linear_bwd', 'adam', 'csr', 'wgrad_node', 'seg_fwd_agg', 'features']
+                'linear_bwd', 'adam', 'csr', 'wgrad_node', 'seg_fwd_agg', 'features', 'edge_bwd_fused']
 
 c_f32p = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 c_i32p = C.c_void_p
@@ -63,6 +63,11 @@ class WTask(C.Structure):
                 ('db', c_f32p), ('accumulate', C.c_int32)]
 
 
+class WFuse(C.Structure):
+    _fields_ = [('z2', c_f32p), ('z1', c_f32p), ('x', c_f32p), ('ldx', C.c_int64), ('dW3', c_f32p), ('db3', c_f32p),
+                ('dW2', c_f32p), ('db2', c_f32p), ('dW1', c_f32p), ('ldw1', C.c_int64), ('db1', c_f32p), ('accumulate', C.c_int32)]
+
+
 class Pack(C.Structure):
     _fields_ = [('W', c_f32p), ('ldw', C.c_int64), ('n_out', C.c_int32), ('n_in', C.c_int32), ('transposed', C.c_int32),
                 ('out', C.c_void_p)]
@@ -94,6 +99,9 @@ _SIGS = {
                                   C.c_void_p]),
     'hgn_mlp_bwd_ln_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     'hgn_mlp_bwd': (C.c_int, [C.POINTER(MlpBwd), C.c_void_p]),
+    'hgn_edge_bwd_fused_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
+    'hgn_edge_bwd_fused_eligible': (C.c_int, [C.POINTER(MlpBwd)]),
+    'hgn_edge_bwd_fused': (C.c_int, [C.POINTER(MlpBwd), C.POINTER(WFuse), C.c_void_p, C.c_size_t, C.c_void_p]),
     'hgn_wgrad_workspace_bytes': (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
     'hgn_mlp_wgrad': (C.c_int, [C.POINTER(WTask), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     'hgn_linear_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_int64,

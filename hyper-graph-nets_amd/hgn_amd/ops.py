@@ -19,6 +19,13 @@ _ws_cache = {}
 
 
 _WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
+_FUSED_EDGE_BWD = True        # edge blocks: data gradients and weight gradients in one pass (hgn_edge_bwd_fused)
+
+
+def set_fused_edge_backward(on: bool) -> None:
+    """Diagnostic switch: False restores the two-launch edge backward (hgn_mlp_bwd + hgn_mlp_wgrad)."""
+    global _FUSED_EDGE_BWD
+    _FUSED_EDGE_BWD = bool(on)
 
 
 def set_matmul_precision(mode: str) -> None:
@@ -506,22 +513,39 @@ class EdgeBlockFn(torch.autograd.Function):
         # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]; the receiver half comes out of the
         # backward kernel itself when the segments are short (include/hgn_mp.h: seg_dz1)
         dP = torch.empty(N, 2 * LAT, device=dev)
-        fuse_seg = (pk_t is not None and E > 0 and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
+        # One pass for data gradients AND weight gradients (include/hgn_mp.h: hgn_edge_bwd_fused): dz3 / dz2 never reach memory.
+        fused = (_FUSED_EDGE_BWD and pk_t is not None and E > 0 and _WGRAD_STREAM is None
+                 and bool(L.hgn_edge_bwd_fused_eligible(C.byref(b))))
+        fuse_seg = (not fused and pk_t is not None and E > 0 and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
                     and L.hgn_mlp_bwd6_eligible(C.byref(b)))
         if fuse_seg:
             dP[:, LAT:].zero_()
             b.seg_dz1 = dP.data_ptr() + 4 * LAT; b.ld_seg_dz1 = 2 * LAT; b.seg_ids = topo.rcv.data_ptr()
-        if E > 0:
+        if fused:
+            wf = _lib.WFuse()
+            wf.z2 = z2.data_ptr(); wf.z1 = z1.data_ptr(); wf.x = e.data_ptr(); wf.ldx = _ld(e)
+            wf.dW3 = dw3.data_ptr(); wf.db3 = db3.data_ptr(); wf.dW2 = dw2.data_ptr(); wf.db2 = db2.data_ptr()
+            wf.dW1 = dw1.data_ptr() + 4 * 2 * LAT; wf.ldw1 = 3 * LAT; wf.db1 = db1.data_ptr()
+            if accs[0] != accs[2] or accs[0] != accs[4]:
+                raise _lib.HgnError('edge block: mixed accumulate / overwrite gradient targets')
+            wf.accumulate = accs[0]
+            b.dz3 = None; b.dz2 = None
+            nb = C.c_size_t(0)
+            _lib.check(L.hgn_edge_bwd_fused_workspace_bytes(E, C.byref(nb)), 'hgn_edge_bwd_fused_workspace_bytes')
+            ws = _workspace(dev, nb.value, 'fused')
+            _lib.check(L.hgn_edge_bwd_fused(C.byref(b), C.byref(wf), ws.data_ptr(), ws.numel(), st), 'hgn_edge_bwd_fused')
+        elif E > 0:
             _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
         elif not accs[6]:
             dg.zero_(); dbt.zero_()
-        tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, LAT, dw3.data_ptr(), LAT, db3.data_ptr(), accs[4]),
-                 _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2]),
-                 _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
-                        db1.data_ptr(), accs[0])]
-        if E == 0:      # dW1's node-row column blocks are written by the node-level launch below (from dP = 0)
-            _zero_unaccumulated(bufs[:6], accs[:6])
-        _run_wgrad(tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
+        if not fused:
+            tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, LAT, dw3.data_ptr(), LAT, db3.data_ptr(), accs[4]),
+                     _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2]),
+                     _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
+                            db1.data_ptr(), accs[0])]
+            if E == 0:      # dW1's node-row column blocks are written by the node-level launch below (from dP = 0)
+                _zero_unaccumulated(bufs[:6], accs[:6])
+            _run_wgrad(tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
         ops = (C.c_int32 * 1)(0)
         _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N,
                                             ops, 1, dP.data_ptr(), 2 * LAT, None, None, st), 'segment_reduce(senders)')

@@ -1048,3 +1048,44 @@ def test_config4_shape_cylinder_hyper_L25_balance_vs_oracle(steps):
     assert H.rel_err(loss_b, loss_o) <= 5e-2
     out_again, _, _, _ = H.hip_run(model, graph, target, mask)
     assert torch.equal(out_again, out)                     # switching back restores the fp32-accurate results bit for bit
+
+
+@pytest.mark.parametrize('agg,nx,ny', [('sum', 7, 5), ('sum', 40, 40), ('pna', 23, 17), ('max', 9, 9)])
+def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
+    """hgn_edge_bwd_fused (data gradients + weight gradients of an edge block in one persistent kernel, dz3 / dz2 never written)
+    against the two-launch path it replaces (hgn_mlp_bwd + hgn_mlp_wgrad) on the same inputs: same products, other summation
+    order over rows -> 1e-6; both are held to the oracle by every model-level test (the fused path is the default).
+    Sizes: fewer tiles than workgroups, the 146-tile benchmark graph, a ragged last tile."""
+    import hgn_amd
+    from hgn_amd import ops
+    graph = synth.grid_graph(seed=3, nx=nx, ny=ny)
+    shapes = O.param_shapes('none', agg, 2, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=12)
+    N = nx * ny
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(3))
+    mask = torch.ones(N, dtype=torch.bool); mask[:3] = False
+    model = H.hip_model('none', agg, 2, ['mesh_edges'], sd)
+    res = {}
+    for fused in (True, False):
+        ops.set_fused_edge_backward(fused)
+        try:
+            ops.prof_reset(); ops.prof_enable(True)
+            res[fused] = H.hip_run(model, graph, target, mask)
+            k = ops.prof_collect()
+        finally:
+            ops.prof_enable(False)
+            ops.set_fused_edge_backward(True)
+        assert ('edge_bwd_fused' in k) == fused and ('mlp_bwd_edge' in k) == (not fused), sorted(k)
+    (out_f, loss_f, g_f, ig_f), (out_u, loss_u, g_u, ig_u) = res[True], res[False]
+    assert torch.equal(out_f, out_u)
+    for kname in g_u:
+        if float(g_u[kname].abs().max()) > 0:
+            assert H.rel_err(g_f[kname], g_u[kname]) <= 2e-6, kname
+        else:
+            assert float(g_f[kname].abs().max()) == 0, kname
+    assert H.rel_err(ig_f['node'][0], ig_u['node'][0]) <= 2e-6
+    assert H.rel_err(ig_f['edge']['mesh_edges'], ig_u['edge']['mesh_edges']) <= 2e-6
+    # bit-reproducible: fixed-order reductions over per-workgroup partials
+    ops.set_fused_edge_backward(True)
+    again = H.hip_run(model, graph, target, mask)
+    assert all(torch.equal(again[2][kname], g_f[kname]) for kname in g_f)
