@@ -37,6 +37,8 @@ struct FusedArgs {
   const float* A[3]; long ldA[3];               // other operand of dW3, dW2, dW1e: z2, z1, e
   float* slabs;                                 // [gridDim.x][3][FSLAB]
   long tiles;                                   // 64-row tiles
+  int dbg;                                      // diagnostic ablations (HGN_FUSED_DBG): 1 no G writes, 2 no A publish, 4 no chain MFMA,
+                                                // 8 no wgrad MFMA, 16 no weight DMA, 32 no row loads in the LayerNorm prologue
 };
 
 __device__ __forceinline__ void bar_lds() {     // every wave's LDS traffic issued so far is complete; global traffic stays in flight
@@ -162,11 +164,11 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       const unsigned mb1 = a.relu_bits[rc * 8 + kq], mb2 = a.relu_bits[rc * 8 + 4 + kq];
       // ---- layer 3: LayerNorm backward -> dz3 (g); t = W3^T dz3 ------------------------------------------------------
       bar_lds();
-      stage_half6<NP>(wst, pk3);
+      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk3);
       {
         Act& xh = t[0];
-        load_dout<false>(gout, a, rc, kq);
-        t_load(xh, a.xhat + rc * LAT, kq);
+        if (!(fa.dbg & 32)) { load_dout<false>(gout, a, rc, kq); t_load(xh, a.xhat + rc * LAT, kq); }
+        else { t_zero(gout); t_zero(xh); }
         HGN_FOR_B(fb) {                               // LayerNorm-affine gradient partials of this wave's rows
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
@@ -192,43 +194,43 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
         HGN_FOR_B(fb) g[0].v[fb] = r * (g[0].v[fb] - m1 - xh.v[fb] * m2);
       }
       split3(g[0], xs[0]);
-      write_gops<NP>(gbase, xs[0]);
       t_zero(t[0]);
       bar_all();
+      if (!(fa.dbg & 1)) write_gops<NP>(gbase, xs[0]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) lnacc[k] += lnl[wave * 256 + lane + 64 * k];      // this wave's own partials of this tile
-      mfma_half6<0, 1, NP>(t, xs, wst);
+      if (!(fa.dbg & 4)) mfma_half6<0, 1, NP>(t, xs, wst);
       bar_lds();
-      stage_half6<NP>(wst, pk3 + HALF_BF16);
+      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk3 + HALF_BF16);
       bar_all();
-      mfma_half6<1, 1, NP>(t, xs, wst);
+      if (!(fa.dbg & 4)) mfma_half6<1, 1, NP>(t, xs, wst);
       relu_mask_bits(t[0], mb2);                      // dz2
       // ---- layer 2: g = W2^T dz2 -------------------------------------------------------------------------------------
       bar_lds();
-      stage_half6<NP>(wst, pk2);
+      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk2);
       split3(t[0], xs[0]);
-      write_gops<NP>(gbase, xs[0]);
       t_zero(g[0]);
       bar_all();
-      mfma_half6<0, 1, NP>(g, xs, wst);
+      if (!(fa.dbg & 1)) write_gops<NP>(gbase, xs[0]);
+      if (!(fa.dbg & 4)) mfma_half6<0, 1, NP>(g, xs, wst);
       bar_lds();
-      stage_half6<NP>(wst, pk2 + HALF_BF16);
+      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk2 + HALF_BF16);
       bar_all();
-      mfma_half6<1, 1, NP>(g, xs, wst);
+      if (!(fa.dbg & 4)) mfma_half6<1, 1, NP>(g, xs, wst);
       relu_mask_bits(g[0], mb1);                      // dz1
       if (a.dz1 && valid) t_store(g[0], a.dz1 + row * LAT, kq);
       // ---- layer 1: de = d_out_eff + dz1 W1e -------------------------------------------------------------------------
       bar_lds();
-      stage_half6<NP>(wst, pk1);
+      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk1);
       split3(g[0], xs[0]);
-      write_gops<NP>(gbase, xs[0]);
       t[0] = gout;                                    // the skip connection is the accumulator's start value
       bar_all();
-      mfma_half6<0, 1, NP>(t, xs, wst);
+      if (!(fa.dbg & 1)) write_gops<NP>(gbase, xs[0]);
+      if (!(fa.dbg & 4)) mfma_half6<0, 1, NP>(t, xs, wst);
       bar_lds();
-      stage_half6<NP>(wst, pk1 + HALF_BF16);
+      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk1 + HALF_BF16);
       bar_all();
-      mfma_half6<1, 1, NP>(t, xs, wst);
+      if (!(fa.dbg & 4)) mfma_half6<1, 1, NP>(t, xs, wst);
       if (valid) t_store(t[0], d.dx + row * d.ld, kq);
     }
 #pragma unroll
@@ -287,18 +289,25 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
         }
       }
     };
+    // Interleaving with the chain (same four barriers per layer; the matrix pipe alternates between the two kinds of wave):
+    //   chain:  VALU (next dz, split) | write G(l), product half 0 | wait for weight half 1 | product half 1
+    //   wgrad:  dW(l+1) block 1       | publish A(l)               | dW(l) block 0          | -
+    // G(l) / A(l) are written between the 2nd and 3rd barrier and last read before the 2nd barrier of the NEXT layer.
+    bool pending = false;                             // block 1 of the previous layer still to be multiplied
     for (long tile = t_beg; tile < t_end; ++tile) {
 #pragma unroll
       for (int l = 0; l < 3; ++l) {                   // layer 3 (A = z2), layer 2 (A = z1), layer 1 (A = e)
         bar_lds();
-        publish(l, tile);
+        if (pending && !(fa.dbg & 8)) wgrad_block<NP>(acc[(l + 2) % 3], cs[(l + 2) % 3], gp, ap, 1);
         bar_lds();
-        wgrad_block<NP>(acc[l], cs[l], gp, ap, 0);
+        if (!(fa.dbg & 2)) publish(l, tile);
         bar_lds();
+        if (!(fa.dbg & 8)) wgrad_block<NP>(acc[l], cs[l], gp, ap, 0);
         bar_lds();
-        wgrad_block<NP>(acc[l], cs[l], gp, ap, 1);
+        pending = true;
       }
     }
+    if (pending && !(fa.dbg & 8)) wgrad_block<NP>(acc[2], cs[2], gp, ap, 1);
     bar_lds();                                        // (E)
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
@@ -381,6 +390,8 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   fa.A[2] = w->x; fa.ldA[2] = w->ldx;
   fa.slabs = (float*)workspace;
   fa.tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+  static const int dbg = getenv("HGN_FUSED_DBG") ? atoi(getenv("HGN_FUSED_DBG")) : 0;
+  fa.dbg = dbg;
   ProfScope ps(14, (double)a->M, stream);
   if (matmul_products() == 1) hipLaunchKernelGGL(edge_bwd_fused_kernel<1>, dim3((unsigned)G), dim3(FT), 0, stream, fa);
   else hipLaunchKernelGGL(edge_bwd_fused_kernel<6>, dim3((unsigned)G), dim3(FT), 0, stream, fa);

@@ -19,11 +19,15 @@ _ws_cache = {}
 
 
 _WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
-_FUSED_EDGE_BWD = True        # edge blocks: data gradients and weight gradients in one pass (hgn_edge_bwd_fused)
+# edge blocks: data gradients and weight gradients in one pass (hgn_edge_bwd_fused).  Opt-in (HGN_FUSED_BWD=1 or
+# set_fused_edge_backward(True)): it moves 2.5 KB per edge and layer less than the two launches it replaces, but with one
+# persistent 8-wave workgroup per CU its load / DMA latencies are exposed -- measured 2.58 ms against 1.29 + 0.73 ms at 1.19 M rows
+# (DESIGN.md section 5.6), so the two-launch path stays the default.
+_FUSED_EDGE_BWD = bool(__import__('os').environ.get('HGN_FUSED_BWD'))
 
 
 def set_fused_edge_backward(on: bool) -> None:
-    """Diagnostic switch: False restores the two-launch edge backward (hgn_mlp_bwd + hgn_mlp_wgrad)."""
+    """True: edge-block backward through hgn_edge_bwd_fused; False (default): hgn_mlp_bwd + hgn_mlp_wgrad."""
     global _FUSED_EDGE_BWD
     _FUSED_EDGE_BWD = bool(on)
 

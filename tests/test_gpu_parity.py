@@ -1054,7 +1054,7 @@ def test_config4_shape_cylinder_hyper_L25_balance_vs_oracle(steps):
 def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
     """hgn_edge_bwd_fused (data gradients + weight gradients of an edge block in one persistent kernel, dz3 / dz2 never written)
     against the two-launch path it replaces (hgn_mlp_bwd + hgn_mlp_wgrad) on the same inputs: same products, other summation
-    order over rows -> 1e-6; both are held to the oracle by every model-level test (the fused path is the default).
+    order over rows -> 2e-6, and the fused path against the fp64 oracle at the usual tolerances (it is opt-in: measured slower).
     Sizes: fewer tiles than workgroups, the 146-tile benchmark graph, a ragged last tile."""
     import hgn_amd
     from hgn_amd import ops
@@ -1074,7 +1074,7 @@ def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
             k = ops.prof_collect()
         finally:
             ops.prof_enable(False)
-            ops.set_fused_edge_backward(True)
+            ops.set_fused_edge_backward(False)
         assert ('edge_bwd_fused' in k) == fused and ('mlp_bwd_edge' in k) == (not fused), sorted(k)
     (out_f, loss_f, g_f, ig_f), (out_u, loss_u, g_u, ig_u) = res[True], res[False]
     assert torch.equal(out_f, out_u)
@@ -1085,7 +1085,14 @@ def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
             assert float(g_f[kname].abs().max()) == 0, kname
     assert H.rel_err(ig_f['node'][0], ig_u['node'][0]) <= 2e-6
     assert H.rel_err(ig_f['edge']['mesh_edges'], ig_u['edge']['mesh_edges']) <= 2e-6
-    # bit-reproducible: fixed-order reductions over per-workgroup partials
+    # bit-reproducible (fixed-order reductions over per-workgroup partials), and within the parity tolerances of the oracle
     ops.set_fused_edge_backward(True)
-    again = H.hip_run(model, graph, target, mask)
+    try:
+        again = H.hip_run(model, graph, target, mask)
+    finally:
+        ops.set_fused_edge_backward(False)
     assert all(torch.equal(again[2][kname], g_f[kname]) for kname in g_f)
+    if nx * ny <= 400:
+        out_o, _, g_o, _ = H.oracle_run(sd, graph, 'none', agg, target, mask)
+        assert H.rel_err(out_f, out_o) <= TOL_OUT
+        assert max(H.rel_err(g_f[kname], g_o[kname]) for kname in g_o if float(g_o[kname].abs().max()) > 0) <= TOL_GRAD
