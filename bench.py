@@ -53,6 +53,7 @@ def parse():
     ap.add_argument('--world-edges', type=int, default=0, help='extra world edges per graph (plate-style second edge set)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cold', action='store_true', help='skip the cold-step (fresh index tensors) figures')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary configurations (pna; plate-shape hetero K=31)')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-kernel HIP events in the timed region')
     ap.add_argument('--eager', action='store_true',
                     help='N=1: launch every kernel from the host in the timed region (per-kernel HIP events recorded live). '
@@ -69,6 +70,44 @@ def parse():
     ap.add_argument('--no-side-stream', action='store_true', help='(default; kept for compatibility)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
+
+
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp, sorted): stamps PMC-derived figures so that a number measured on
+    other kernel code is never reported as current (tools/make_traffic_json.py writes the same stamp)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'hyper-graph-nets_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h')) + glob.glob(os.path.join(d, '*.cpp'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def secondary_configs(args):
+    """Driver-visible secondary figures: the YAML default aggregation (pna, flag.yaml:32) and the deforming_plate-shape
+    HyperGraphNets configuration of BASELINE.json configs[2] (hetero block, K = 31 hyper nodes, 5 MP layers, mesh + world + three
+    remote edge sets) -- each a short run of this same script as a CHILD process (never exec: the parent holds the GPU)."""
+    out = {}
+    base = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '2', '--no-cold', '--no-cpu-baseline', '--no-prof',
+            '--no-secondary', '--batch', str(args.batch)]
+    for name, extra in (('flag_simple_shape_pna_L15', ['--agg', 'pna']),
+                        ('deforming_plate_shape_hetero_pna_L5_K31', ['--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31',
+                                                                      '--world-edges', '300'])):
+        try:
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode == 0 and line:
+                d = json.loads(line[-1])
+                out[name] = {'edges_per_s': d['value'], 'ms_per_step': d['ms_per_step'], 'edges_per_step': d['config']['edges_per_step'],
+                             'steps': d['steps'], 'workload': d['config']['workload']}
+            else:
+                out[name] = {'error': (r.stderr or '')[-300:]}
+        except Exception as ex:                             # a secondary figure must never cost the headline line
+            out[name] = {'error': f'{type(ex).__name__}: {ex}'}
+        log(f'secondary {name}: {out[name]}')
+    return out
 
 
 def host_cores() -> int:
@@ -354,31 +393,42 @@ def main():
             #   edge backward: read d(e') + x-hat (2 x 512), sign words 32, rstd 4, write dz3 + dz2 + dz1 + de (4 x 512);
             #                  d(agg) rows (N x 512) gathered, receiver sums of dz1 (N x 512) written
             #   weight grads : two operand rows (2 x 512) per task and row
+            #   fused backward (opt-in): read d(e') + x-hat + z2 + z1 + e (5 x 512), sign words, rstd, write dz1 + de (2 x 512)
             algo = {'mlp_fwd_edge': (5 * 512 + 36, 1536 * N_nodes), 'mlp_bwd_edge': (6 * 512 + 36, 1024 * N_nodes),
-                    'wgrad': (1024, 0), 'wgrad_node': (1024, 0)}
+                    'wgrad': (1024, 0), 'wgrad_node': (1024, 0), 'edge_bwd_fused': (7 * 512 + 36, 512 * N_nodes)}
+            # bytes the arithmetic NEEDS: without the dz3 / dz2 / dz1 hand-off to the weight-gradient launch
+            necessary = {'mlp_bwd_edge': (3 * 512 + 36, 1024 * N_nodes)}
             cand = {n: v for n, v in k.items() if n in algo and (n in fwd_only or not overlapped)}
             name, v = max(cand.items(), key=lambda kv: kv[1]['ms'])
             t_launch = v['ms'] / v['count'] * 1e-3
             rows = v['units'] / v['count']
             bytes_launch = algo[name][0] * rows + algo[name][1]
             ach = bytes_launch / t_launch / 1e9
-            per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1}[name] * 2 * 128 * 128
+            per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1, 'edge_bwd_fused': 6}[name] * 2 * 128 * 128
             tf = per_row * rows / t_launch / 1e12
             fp32_only = bool(os.environ.get('HGN_FP32_MFMA'))
-            traffic = None
+            traffic, traffic_note = None, None
+            sha = kernel_source_sha()
             try:        # HBM bytes per launch from the rocprofv3 PMC passes of this configuration (profiles/README.md)
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
                 ent = pm.get(name)
-                if ent and int(ent['rows_per_launch']) == int(rows) and not fp32_only:
+                if pm.get('kernel_source_sha') != sha:
+                    traffic_note = (f"profiles/pmc_traffic.json was measured on kernel sources {pm.get('kernel_source_sha')} "
+                                    f"(commit {pm.get('commit')}); sources now {sha}: dropped as stale")
+                elif ent and int(ent['rows_per_launch']) == int(rows) and not fp32_only:
                     traffic = ent['traffic_bytes_per_launch']
-            except Exception:
-                pass
+                    traffic_note = (f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes of this configuration at commit "
+                                    f"{pm.get('commit')}, kernel sources {sha}: profiles/pmc_traffic.json")
+            except Exception as ex:
+                traffic_note = f'no PMC record ({type(ex).__name__})'
             res['roofline'] = {'kernel': name, 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                'frac': ach / PEAK_HBM_GBS, 'traffic': traffic,
                                'algorithmic_bytes_per_launch': bytes_launch, 'rows_per_launch': rows,
                                'ms_per_launch': t_launch * 1e3,
-                               'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this configuration, '
-                                                 'profiles/r01_pmc_traffic.json' if traffic else None,
+                               'traffic_source': traffic_note, 'kernel_source_sha': sha,
+                               'necessary_bytes_per_launch': (necessary[name][0] * rows + necessary[name][1]) if name in necessary else bytes_launch,
+                               'frac_on_necessary_bytes': ((necessary[name][0] * rows + necessary[name][1]) if name in necessary
+                                                           else bytes_launch) / t_launch / 1e9 / PEAK_HBM_GBS,
                                'matrix_pipe': {'fp32_equivalent_TFLOPs': tf, 'flop_per_row': per_row,
                                                'frac_of_fp32_mfma_peak': tf / PEAK_F32_MFMA_TFLOPS,
                                                'frac_of_bf16_mfma_peak': None if fp32_only else 6 * tf / PEAK_BF16_MFMA_TFLOPS,
@@ -408,6 +458,8 @@ def main():
                                                'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3}
         if cold is not None:
             res['cold_step'] = cold
+        if world == 1 and not args.no_secondary:
+            res['secondary'] = secondary_configs(args)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, synthetic.grid_graph(seed=1000, nx=args.nx, ny=args.ny, clusters=args.clusters,
                                                                           world=args.world_edges))

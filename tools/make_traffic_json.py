@@ -1,8 +1,11 @@
-"""Builds profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes of bench.py (FETCH_SIZE, WRITE_SIZE; separate runs, as
-/opt/skills/guides/MI355X_MICROARCH.md prescribes): per-launch HBM-side bytes of the edge kernels.
-    python tools/make_traffic_json.py FETCH_DIR WRITE_DIR ROWS_PER_LAUNCH > profiles/r01_pmc_traffic.json
+"""Builds profiles/pmc_traffic.json from two rocprofv3 PMC passes of bench.py (FETCH_SIZE, WRITE_SIZE; separate runs, as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes): per-launch HBM-side bytes of the big kernels, stamped with the commit and
+the sha of the kernel sources they were measured on (bench.py drops the figure when the sources have changed since).
+    python tools/make_traffic_json.py FETCH_DIR WRITE_DIR ROWS_PER_LAUNCH NODE_ROWS COMMIT > profiles/pmc_traffic.json
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 
 def means(d, counter):
     acc = collections.defaultdict(lambda: [0.0, 0])
@@ -13,18 +16,28 @@ def means(d, counter):
                 acc[k][0] += float(r['Counter_Value']); acc[k][1] += 1
     return {k: (s / n, n) for k, (s, n) in acc.items()}
 
+
 fetch, write = means(sys.argv[1], 'FETCH_SIZE'), means(sys.argv[2], 'WRITE_SIZE')
-rows = int(sys.argv[3])
-out = {}
-for bench_name, kern in (('mlp_fwd_edge', 'mlp6_fwd_kernel'), ('mlp_bwd_edge', 'mlp6_bwd_kernel')):
+rows, node_rows = int(sys.argv[3]), int(sys.argv[4])
+import bench
+out = {'commit': sys.argv[5] if len(sys.argv) > 5 else None, 'kernel_source_sha': bench.kernel_source_sha(),
+       'counters': 'FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64 bytes) + WRITE_SIZE, KiB, mean over the launches of '
+                   'that (kernel, grid) in `bench.py --steps 2 --warmup 1`'}
+per_step = 0.0
+for bench_name, kern, launches_per_step, big in (('mlp_fwd_edge', 'mlp6_fwd_kernel', 15, True), ('mlp_bwd_edge', 'mlp6_bwd_kernel', 15, True),
+                                                 ('wgrad', 'wgrad6s_kernel', 15, True), ('edge_bwd_fused', 'edge_bwd_fused_kernel', 15, True),
+                                                 ('seg_fwd', 'seg_fwd128_kernel', 15, True)):
     keys = [k for k in fetch if kern in k[0]]
     if not keys:
         continue
-    k = max(keys, key=lambda kk: kk[1])                       # the edge launches have the largest grid
+    k = max(keys, key=lambda kk: (kk[1], fetch[kk][1]))       # the edge launches have the largest grid
     f_kib, n = fetch[k]
-    w_kib = write[k][0]
+    w_kib = write.get(k, (0.0, 0))[0]
+    r = node_rows if bench_name == 'seg_fwd' else rows
     out[bench_name] = {'kernel': k[0], 'grid_threads': k[1], 'launches_averaged': n, 'rows_per_launch': rows,
                        'FETCH_SIZE_KiB': f_kib, 'WRITE_SIZE_KiB': w_kib,
                        'traffic_bytes_per_launch': (2 * f_kib + w_kib) * 1024,
-                       'read_bytes_per_row': 2 * f_kib * 1024 / rows, 'write_bytes_per_row': w_kib * 1024 / rows}
+                       'read_bytes_per_edge_row': 2 * f_kib * 1024 / rows, 'write_bytes_per_edge_row': w_kib * 1024 / rows}
+    per_step += (2 * f_kib + w_kib) * 1024 / rows
+out['edge_level_bytes_per_edge_and_layer'] = per_step
 print(json.dumps(out, indent=1))

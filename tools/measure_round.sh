@@ -1,0 +1,22 @@
+#!/bin/bash
+# Measurement set of a round (one gpurun call):  bash tools/measure_round.sh r02 <commit>
+# default bench line, kernel trace + per-launch split, PMC traffic passes (separate runs), other configurations, N=2 rehearsal.
+R=${1:-r02}; COMMIT=${2:-unknown}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/$R; mkdir -p $O
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default done rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-cold --no-secondary > $O/bench_under_rocprof.json 2> $O/trace.err; echo "trace done rc=$?"
+python tools/kernel_split.py $O/trace > $O/kernel_split.csv
+cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cold --no-secondary > $O/pmc_f.json 2> $O/pmc_f.err; echo "pmc fetch rc=$?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cold --no-secondary > $O/pmc_w.json 2> $O/pmc_w.err; echo "pmc write rc=$?"
+python tools/make_traffic_json.py $O/pmc_f $O/pmc_w 1188096 204800 $COMMIT > $O/pmc_traffic.json; echo "traffic json rc=$?"
+for cfg in "pna --agg pna" "hyper --arch hyper --agg pna --layers 5 --clusters 16" "hetero --arch hetero --agg pna --layers 5 --clusters 31 --world-edges 300" "b1 --batch 1" "b8 --batch 8" "b21 --batch 21" "b64 --batch 64" "b256 --batch 256" "eager --eager" "bf16 --precision bf16"; do
+  set -- $cfg; n=$1; shift
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 "$@" > $O/bench_$n.json 2> $O/bench_$n.err || echo "config $n failed"
+  python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true
+done
+HGN_FUSED_BWD=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 > $O/bench_fused_bwd.json 2> $O/bench_fused_bwd.err
+timeout -k 10 600 python bench.py --gpus 2 --backend gloo --no-cold --no-secondary --steps 10 --warmup 3 --batch 64 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2_gloo.err; echo "gpus2 rc=$?"
+rm -rf $O/trace/*/*.db $O/pmc_f/*/*.db $O/pmc_w/*/*.db 2>/dev/null
+python -c "import json;d=json.load(open('$O/bench_default.json'));print('default', d['ms_per_step'], d['value'], json.dumps(d['roofline']), json.dumps(d.get('cpu_baseline')), json.dumps(d.get('cold_step')), json.dumps(d.get('secondary')))"
