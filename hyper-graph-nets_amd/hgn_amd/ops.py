@@ -189,10 +189,49 @@ def _zero_unaccumulated(bufs, accs):
             b.zero_()
 
 
-def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False, keep=()):
+# Deferred node-level weight gradients.  A node MLP hands over 4 tasks of N rows, the pre-projection of an edge block 2 more:
+# launched one by one that is ~33 launches per step of a kernel whose fixed costs (slab reduction, tail of a 200 k-row grid)
+# are a third of its time.  Weight gradients are consumed by nobody before the optimiser, so tasks that ACCUMULATE into a flat
+# gradient buffer (parallel.FlatParams) are queued per row count and launched 16 at a time; whatever is left goes out when the
+# autograd engine finishes the backward pass (queue_callback), i.e. before `backward()` returns -- also under HIP-graph capture.
+_DEFER_NODE_WGRAD = not bool(__import__('os').environ.get('HGN_NO_DEFERRED_WGRAD'))
+_wq = {}                      # (M, device) -> [tasks, tensors kept alive]
+_wq_callback_armed = False
+
+
+def flush_wgrad() -> None:
+    """Launch every queued weight-gradient task now."""
+    global _wq_callback_armed
+    _wq_callback_armed = False
+    for (M, dev), (tasks, keep) in list(_wq.items()):
+        if tasks:
+            _run_wgrad_here(tasks, M, dev, False)
+    _wq.clear()
+
+
+def _defer_wgrad(tasks, M, dev, keep):
+    global _wq_callback_armed
+    q = _wq.setdefault((M, dev), [[], []])
+    if len(q[0]) + len(tasks) > _lib.HGN_MAX_WTASK:
+        _run_wgrad_here(q[0], M, dev, False)
+        q[0], q[1] = [], []
+    q[0] += tasks
+    q[1] += list(keep)
+    if not _wq_callback_armed:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad)
+            _wq_callback_armed = True
+        except RuntimeError:                 # not inside an engine run (backward called by hand): nothing to wait for
+            flush_wgrad()
+
+
+def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False, keep=(), defer: bool = False):
     if M == 0:          # operands of an empty set have null data pointers; the callers zero what the launch would have written
         return
     side = _WGRAD_STREAM
+    if defer and _DEFER_NODE_WGRAD and side is None and all(t.accumulate for t in tasks):
+        _defer_wgrad(tasks, M, dev, keep)
+        return
     if side is not None:
         side.wait_stream(torch.cuda.current_stream())
         for t in keep:                       # operands were allocated on the main stream: keep them alive for the side stream
@@ -367,7 +406,8 @@ class MLPFn(torch.autograd.Function):
                 first = False
         if M == 0:
             _zero_unaccumulated(bufs[:6], accs[:6])
-        _run_wgrad(tasks, M, dev, keep=[z1, z2, dz1, dz2, dz3, *srcs])
+        # (gathered / narrow sources = encoders: few launches, operands of E rows: not worth keeping alive)
+        _run_wgrad(tasks, M, dev, keep=[z1, z2, dz1, dz2, dz3, *srcs], defer=all(i is None for i in idxs) and pk_t is not None)
         # ---- un-gather source gradients -----------------------------------------------------------------------
         for i in range(n_src):
             if dxs[i] is not None and idxs[i] is not None:
@@ -560,7 +600,7 @@ class EdgeBlockFn(torch.autograd.Function):
                         accs[0]),
                  _wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr() + 4 * LAT, 2 * LAT, LAT,
                         dw1.data_ptr() + 4 * LAT, 3 * LAT, None, accs[0])]
-        _run_wgrad(tasks, N, dev, keep=[h_all, dP])
+        _run_wgrad(tasks, N, dev, keep=[h_all, dP], defer=True)
         dh = None
         if ctx.needs_input_grad[3]:
             dh = torch.empty(N, LAT, device=dev)

