@@ -86,14 +86,15 @@ def kernel_source_sha() -> str:
 
 
 def secondary_configs(args):
-    """Driver-visible secondary figures: the YAML default aggregation (pna, flag.yaml:32) and the deforming_plate-shape
-    HyperGraphNets configuration of BASELINE.json configs[2] (hetero block, K = 31 hyper nodes, 5 MP layers, mesh + world + three
-    remote edge sets) -- each a short run of this same script as a CHILD process (never exec: the parent holds the GPU)."""
+    """Driver-visible secondary figures: the YAML default aggregation (pna, flag.yaml:32) and the edge-set structure of the
+    deforming_plate HyperGraphNets configuration of BASELINE.json configs[2] / plateCluster.yaml (hetero block, K = 31 hyper
+    nodes, 5 MP layers, pna; mesh + world + three remote edge sets) on the same 40x40 grids -- each a short run of this same
+    script as a CHILD process (never exec: the parent holds the GPU)."""
     out = {}
     base = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '2', '--no-cold', '--no-cpu-baseline', '--no-prof',
             '--no-secondary', '--batch', str(args.batch)]
     for name, extra in (('flag_simple_shape_pna_L15', ['--agg', 'pna']),
-                        ('deforming_plate_shape_hetero_pna_L5_K31', ['--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31',
+                        ('plate_config_edge_sets_hetero_pna_L5_K31_on_40x40_grids', ['--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31',
                                                                       '--world-edges', '300'])):
         try:
             r = subprocess.run(base + extra, capture_output=True, text=True, timeout=240)

@@ -16,6 +16,7 @@ from ._lib import OP_CODES
 
 LAT = 128
 _ws_cache = {}
+_GATE_LOG = None              # tests only: when a list, every training forward appends (first-layer weight ptr, ReLU sign words, row index)
 
 
 _WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
@@ -333,6 +334,8 @@ class MLPFn(torch.autograd.Function):
         _fill_common_fwd(a, w, out, res, saves)
         if M > 0:
             _lib.check(_lib.lib().hgn_mlp_fwd(C.byref(a), _lib.stream_ptr()), 'hgn_mlp_fwd')
+        if train and _GATE_LOG is not None:
+            _GATE_LOG.append((wt[0].data_ptr(), saves[4], idxs[0]))
         if train:
             ctx.meta = (n_src, idxs, residual, has_ln, cols, M)
             ctx.saves = saves
@@ -495,6 +498,8 @@ class EdgeBlockFn(torch.autograd.Function):
                                                 agg.data_ptr(), k * LAT, amax.data_ptr() if amax is not None else None,
                                                 amin.data_ptr() if amin is not None else None, st), 'hgn_segment_reduce_fwd')
             L.hgn_prof_tag(0)
+        if train and _GATE_LOG is not None:
+            _GATE_LOG.append((wt[0].data_ptr(), saves[4], topo.r.perm))
         if train:
             ctx.set_materialize_grads(False)
             ctx.topo = topo

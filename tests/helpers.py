@@ -102,3 +102,73 @@ def digest(grads, seed):
         gg = g.detach().double().cpu()
         d[k] = {'proj': (R * gg).flatten(1).sum(1), 'l2': gg.norm(), 'sum': gg.sum()}
     return d
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Gate transfer: the fp64 oracle evaluated with the ReLU gates the HIP forward chose.
+# At 40 M ReLU inputs a handful sit within fp32 rounding of zero; a gate that falls the other way than in fp64 is not an error
+# of the arithmetic (the reference's own fp32 does the same, at other positions) but it moves every gradient upstream of it by
+# 1e-4..1e-3.  With the gates transferred, what is left is the arithmetic itself.
+# ------------------------------------------------------------------------------------------------------------------
+def hip_gates(model, log):
+    """ops._GATE_LOG of one training forward -> {oracle MLP prefix: [(mask hidden 1, mask hidden 2), ...]} in oracle row order."""
+    prefix_of = {}
+    for k, p in model.named_parameters():
+        if k.endswith('.layers.linear_0.weight'):
+            pre = k[:-len('.layers.linear_0.weight')]
+            prefix_of[p.data_ptr()] = pre[:-2] if pre.endswith('.0') else pre
+    out = {}
+    shifts = torch.arange(32, dtype=torch.int64)
+    for ptr, bits, idx in log:
+        b = bits.detach().cpu().to(torch.int64) & 0xffffffff                     # [M, 8] words: 4 * layer + q
+        M = b.shape[0]
+        pair = []
+        for layer in (0, 1):
+            m = torch.zeros(M, 128, dtype=torch.bool)
+            for q in range(4):
+                w = ((b[:, 4 * layer + q].unsqueeze(1) >> shifts) & 1).bool()      # bit 4 * blk + u <-> unit 16 * blk + 4 * q + u
+                for blk in range(8):
+                    m[:, 16 * blk + 4 * q: 16 * blk + 4 * q + 4] = w[:, 4 * blk: 4 * blk + 4]
+            if idx is not None:                                                     # row i of the kernel = source row idx[i]
+                u = torch.zeros_like(m)
+                u[idx.detach().cpu().long()] = m
+                m = u
+            pair.append(m)
+        out.setdefault(prefix_of[ptr], []).append(tuple(pair))
+    return out
+
+
+class GateTransfer:
+    """Context manager: inside it the oracle's ReLUs use the given gates; counts where they differ from the oracle's own."""
+
+    def __init__(self, gates):
+        self.gates = {k: list(v) for k, v in gates.items()}
+        self.flipped, self.total, self.max_abs_at_flip = 0, 0, 0.0
+
+    def __enter__(self):
+        self._mlp, self._relu = O.mlp, torch.relu
+        state = {'pair': None, 'layer': 0}
+
+        def mlp(sd, prefix, x, layer_norm=True):
+            state['pair'] = self.gates[prefix].pop(0)
+            state['layer'] = 0
+            return self._mlp(sd, prefix, x, layer_norm)
+
+        def relu(x):
+            m = state['pair'][state['layer']]
+            state['layer'] += 1
+            assert m.shape == x.shape, (m.shape, x.shape)
+            own = x.detach() > 0
+            diff = own != m
+            self.total += m.numel()
+            n = int(diff.sum())
+            if n:
+                self.flipped += n
+                self.max_abs_at_flip = max(self.max_abs_at_flip, float(x.detach().abs()[diff].max()))
+            return x * m.to(x.dtype)
+        O.mlp, torch.relu = mlp, relu
+        return self
+
+    def __exit__(self, *exc):
+        O.mlp, torch.relu = self._mlp, self._relu
+        return False
