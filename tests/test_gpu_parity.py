@@ -547,7 +547,7 @@ def test_headline_graph_40x40_L15_vs_oracle_fp64(agg):
         assert gt.total == 2 * 128 * (15 * (1600 + 9282) + 2 * 1600 + 9282)
         assert gt.flipped <= 200 and gt.max_abs_at_flip <= 1e-5, (gt.flipped, gt.max_abs_at_flip)
         assert H.rel_err(out, out_g) <= TOL_OUT
-        assert gn <= 5e-5, gn
+        assert gn <= 1e-5, gn                               # measured 6.1e-7 (7 of 45 M gates differ from fp64's, each at |z| < 1e-6)
     # ---- the benchmark batch: 128 graphs, graph k's rows == the single-graph result ---------------------------------
     graphs = [graph] + [synth.grid_graph(seed=s) for s in (1, 2, 3)]
     members = [graphs[(i * 7) % 4] if i != 77 else graph for i in range(128)]
