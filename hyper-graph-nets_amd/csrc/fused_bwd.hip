@@ -34,8 +34,8 @@ constexpr int FUSED_LDS = HALF_BF16 * 2 + 2 * OPS64 * 16 + 4 * 256 * 4;
 
 struct FusedArgs {
   hgn_mlp_bwd_t b;                              // the data-gradient chain (n_dx == 1, residual, LayerNorm, ReLU sign words)
-  const float* A[3]; long ldA[3];               // other operand of dW3, dW2, dW1e: z2, z1, e
-  float* slabs;                                 // [gridDim.x][3][FSLAB]
+  const float* A[2]; long ldA[2];               // other operand of dW3, dW2: z2, z1
+  float* slabs;                                 // [gridDim.x][2][FSLAB]
   long tiles;                                   // 64-row tiles
   int dbg;                                      // diagnostic ablations (HGN_FUSED_DBG): 1 no G writes, 2 no A publish, 4 no chain MFMA,
                                                 // 8 no wgrad MFMA, 16 no weight DMA, 32 no row loads in the LayerNorm prologue
@@ -127,13 +127,59 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], 
   }
 }
 
-template <int NP>
+// mfma_half6 of mlp6_device.h with the operand fragments of one output block at a time (scheduling barrier per block): at the
+// 256-register budget of this kernel the unconstrained scheduler hoists dozens of fragment reads and then spills.
+template <int HALFI, int NP>
+__device__ __forceinline__ void mfma_half6_sb(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl) {
+    const int c = 2 * HALFI + cl;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+      f32x4 t = acc.v[ob];
+      if (NP == 1) {
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[0][c], t, 0, 0, 0);
+      } else {
+        const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+        const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(lds + ((2 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, xs[0][c], t, 0, 0, 0);      // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[2][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[1][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[0][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[1][c], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[0][c], t, 0, 0, 0);
+      }
+      acc.v[ob] = t;
+      if (ob == 3 || ob == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// Row access with a UNIFORM base pointer and a 32-bit per-lane byte offset (eligibility bounds the arrays to 4 GiB): the
+// address stays one VGPR next to a scalar base instead of a hoisted 64-bit pointer per array that the allocator then spills.
+__device__ __forceinline__ void t_load32(Act& a, const float* __restrict__ base, unsigned byte_off) {
+  const char* p = reinterpret_cast<const char*>(base);
+  HGN_FOR_B(fb) a.v[fb] = *reinterpret_cast<const f32x4*>(p + (byte_off + 64u * fb));
+}
+__device__ __forceinline__ void t_store32(const Act& a, float* __restrict__ base, unsigned byte_off) {
+  char* p = reinterpret_cast<char*>(base);
+  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + (byte_off + 64u * fb)) = a.v[fb];
+}
+
+// Counted wait: everything but the `keep` most recently issued vector-memory operations has completed (they retire in order).
+template <int KEEP>
+__device__ __forceinline__ void bar_keep() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <int NP, int DBG>          // DBG: compile-time ablation mask of the diagnostic instantiation (HGN_FUSED_DBG), 0 in the product
 __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs fa) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[FUSED_LDS];
   __bf16* wst = reinterpret_cast<__bf16*>(smem);
-  bf16x8* gops = reinterpret_cast<bf16x8*>(smem + HALF_BF16 * 2);
-  bf16x8* aops = gops + OPS64;
-  float* lnl = reinterpret_cast<float*>(aops + OPS64);
+  float* lnl = reinterpret_cast<float*>(smem + HALF_BF16 * 2 + 2 * OPS64 * 16);
   const hgn_mlp_bwd_t& a = fa.b;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the role split is a scalar branch
@@ -146,34 +192,64 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
 
   if (wave < 4) {
     // ================================= data-gradient chain =================================
-    const int n = lane & 15, kq = lane >> 4;
     const hgn_dx_t d = a.dx[0];
     const __bf16* pk3 = reinterpret_cast<const __bf16*>(a.W3pk_t);
     const __bf16* pk2 = reinterpret_cast<const __bf16*>(a.W2pk_t);
     const __bf16* pk1 = reinterpret_cast<const __bf16*>(d.Wpk_t);
+    const bool has_dout = a.d_out != nullptr;
     Act g[1], t[1], gout;
+    // next tile's d(e') and x-hat rows are loaded into gout / g while this tile's last product runs (both are dead by then)
+    unsigned pf_m1 = 0, pf_m2 = 0;
     bf16x8 xs[1][3][4];
-    // row n of this wave = row group 2 * wave + n / 8, element n % 8 of the G vectors; features 4 kq + ... of every 16-block
-    unsigned char* gbase = smem + opaque((unsigned)(HALF_BF16 * 2 + ((2 * wave + (n >> 3)) * 128 + 4 * kq) * 16 + (n & 7) * 2));
-    float* lnw = reinterpret_cast<float*>(smem + opaque((unsigned)(HALF_BF16 * 2 + 2 * OPS64 * 16 + (wave * 256 + 4 * kq) * 4)));
+    int n = lane & 15, kq = lane >> 4;
+    // LayerNorm-affine gradient partials: the 16-row sums of a tile go through 1 KB of LDS per wave (written BEFORE the layer's
+    // weight DMA is issued: the compiler waits for a pending LDS-DMA before any LDS access it cannot tell apart from the stage)
+    // and are accumulated over the tiles in four registers per lane
     float lnacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float* lnw = nullptr;
+    const unsigned ld_dout4 = (unsigned)a.ld_dout * 4u;
+    unsigned char* gbase = nullptr;
+    auto prefetch = [&](long tile) {                  // 8 (+ 8 with d_out) row loads and 2 sign-word loads
+      const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
+      const unsigned rc = (unsigned)(row < M ? row : M - 1);
+      t_load32(g[0], a.xhat, rc * (LAT * 4u) + 16u * kq);
+      if (has_dout) t_load32(gout, a.d_out, rc * ld_dout4 + 16u * kq);
+      const unsigned* bits = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.relu_bits) + (rc * 32u + 4u * kq));
+      pf_m1 = bits[0];
+      pf_m2 = bits[4];
+    };
+    if (t_beg < t_end && !(DBG & 32)) prefetch(t_beg);
     for (long tile = t_beg; tile < t_end; ++tile) {
+      // everything per-lane is re-derived from an opaque lane id inside the loop: otherwise the compiler hoists two dozen loop-
+      // invariant 64-bit addresses and the 32 LayerNorm weights of the lane out of the loop and spills them
+      const int lane_i = (int)opaque((unsigned)lane);
+      n = lane_i & 15; kq = lane_i >> 4;
+      // row n of this wave = row group 2 * wave + n / 8, element n % 8 of the G vectors; features 4 kq + ... of every 16-block
+      gbase = smem + (unsigned)(HALF_BF16 * 2 + ((2 * wave + (n >> 3)) * 128 + 4 * kq) * 16 + (n & 7) * 2);
+      lnw = reinterpret_cast<float*>(smem + (unsigned)(HALF_BF16 * 2 + 2 * OPS64 * 16 + (wave * 256 + 4 * kq) * 4));
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       const bool valid = row < M;
       const long rc = valid ? row : M - 1;
-      const unsigned mb1 = a.relu_bits[rc * 8 + kq], mb2 = a.relu_bits[rc * 8 + 4 + kq];
       // ---- layer 3: LayerNorm backward -> dz3 (g); t = W3^T dz3 ------------------------------------------------------
       bar_lds();
-      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk3);
+      const unsigned mb1 = pf_m1, mb2 = pf_m2;
       {
         Act& xh = t[0];
-        if (!(fa.dbg & 32)) { load_dout<false>(gout, a, rc, kq); t_load(xh, a.xhat + rc * LAT, kq); }
-        else { t_zero(gout); t_zero(xh); }
+        if (DBG & 32) { t_zero(gout); t_zero(xh); }
+        else {
+          xh = g[0];
+          if (!has_dout) t_zero(gout);
+          if (a.agg_dout) {                           // `sum` aggregation backward: the receiver's d(agg) row (cache-resident gather)
+            const unsigned r = (unsigned)a.agg_seg[rc];
+            const char* ar = reinterpret_cast<const char*>(a.agg_dout) + (r * ((unsigned)a.ld_agg * 4u) + 16u * kq);
+            HGN_FOR_B(fb) gout.v[fb] += *reinterpret_cast<const f32x4*>(ar + 64 * fb);
+          }
+        }
         HGN_FOR_B(fb) {                               // LayerNorm-affine gradient partials of this wave's rows
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
             float pb = valid ? gout.v[fb][w] : 0.f;
-            float pg = row16_sum(pb * xh.v[fb][w]);
+            const float pg = row16_sum(pb * xh.v[fb][w]);
             pb = row16_sum(pb);
             if (n == 0) { lnw[16 * fb + w] = pg; lnw[128 + 16 * fb + w] = pb; }
           }
@@ -193,45 +269,52 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
         const float r = valid ? a.rstd[rc] : 0.f;     // rows past the end contribute nothing to any weight gradient
         HGN_FOR_B(fb) g[0].v[fb] = r * (g[0].v[fb] - m1 - xh.v[fb] * m2);
       }
+      if (!(DBG & 16)) stage_half6<NP>(wst, pk3);       // (after the LayerNorm partials went to LDS, see above)
       split3(g[0], xs[0]);
       t_zero(t[0]);
       bar_all();
-      if (!(fa.dbg & 1)) write_gops<NP>(gbase, xs[0]);
+      if (!(DBG & 1)) write_gops<NP>(gbase, xs[0]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) lnacc[k] += lnl[wave * 256 + lane + 64 * k];      // this wave's own partials of this tile
-      if (!(fa.dbg & 4)) mfma_half6<0, 1, NP>(t, xs, wst);
+      if (!(DBG & 4)) mfma_half6_sb<0, NP>(t[0], xs[0], wst);
       bar_lds();
-      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk3 + HALF_BF16);
+      if (!(DBG & 16)) stage_half6<NP>(wst, pk3 + HALF_BF16);
       bar_all();
-      if (!(fa.dbg & 4)) mfma_half6<1, 1, NP>(t, xs, wst);
+      if (!(DBG & 4)) mfma_half6_sb<1, NP>(t[0], xs[0], wst);
       relu_mask_bits(t[0], mb2);                      // dz2
       // ---- layer 2: g = W2^T dz2 -------------------------------------------------------------------------------------
       bar_lds();
-      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk2);
+      if (!(DBG & 16)) stage_half6<NP>(wst, pk2);
       split3(t[0], xs[0]);
       t_zero(g[0]);
       bar_all();
-      if (!(fa.dbg & 1)) write_gops<NP>(gbase, xs[0]);
-      if (!(fa.dbg & 4)) mfma_half6<0, 1, NP>(g, xs, wst);
+      if (!(DBG & 1)) write_gops<NP>(gbase, xs[0]);
+      if (!(DBG & 4)) mfma_half6_sb<0, NP>(g[0], xs[0], wst);
       bar_lds();
-      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk2 + HALF_BF16);
+      if (!(DBG & 16)) stage_half6<NP>(wst, pk2 + HALF_BF16);
       bar_all();
-      if (!(fa.dbg & 4)) mfma_half6<1, 1, NP>(g, xs, wst);
+      if (!(DBG & 4)) mfma_half6_sb<1, NP>(g[0], xs[0], wst);
       relu_mask_bits(g[0], mb1);                      // dz1
-      if (a.dz1 && valid) t_store(g[0], a.dz1 + row * LAT, kq);
+      if (valid) t_store32(g[0], a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
       // ---- layer 1: de = d_out_eff + dz1 W1e -------------------------------------------------------------------------
       bar_lds();
-      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk1);
+      if (!(DBG & 16)) stage_half6<NP>(wst, pk1);
       split3(g[0], xs[0]);
       t[0] = gout;                                    // the skip connection is the accumulator's start value
-      bar_all();
-      if (!(fa.dbg & 1)) write_gops<NP>(gbase, xs[0]);
-      if (!(fa.dbg & 4)) mfma_half6<0, 1, NP>(t, xs, wst);
+      // g and gout are dead: the next tile's rows start their way now and stay in flight across the next barrier (counted
+      // wait: only the weight DMA issued before them has to have landed) and the first product half; the wait for the second
+      // weight half then completes them (vector memory retires in order).  Past the last tile the clamped rows are unused.
+      if (DBG & 32) bar_all();
+      else {
+        prefetch(tile + 1);
+        if (has_dout) bar_keep<18>(); else bar_keep<10>();
+      }
+      if (!(DBG & 4)) mfma_half6_sb<0, NP>(t[0], xs[0], wst);
       bar_lds();
-      if (!(fa.dbg & 16)) stage_half6<NP>(wst, pk1 + HALF_BF16);
+      if (!(DBG & 16)) stage_half6<NP>(wst, pk1 + HALF_BF16);
       bar_all();
-      if (!(fa.dbg & 4)) mfma_half6<1, 1, NP>(t, xs, wst);
-      if (valid) t_store(t[0], d.dx + row * d.ld, kq);
+      if (!(DBG & 4)) mfma_half6_sb<1, NP>(t[0], xs[0], wst);
+      if (valid) t_store32(t[0], d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) lnl[wave * 256 + lane + 64 * k] = lnacc[k];
@@ -239,79 +322,79 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     const float sum = (lnl[tid] + lnl[256 + tid]) + (lnl[512 + tid] + lnl[768 + tid]);
     a.ln_ws[(long)blockIdx.x * 256 + tid] = sum;
   } else {
-    // ================================= weight gradients =================================
+    // ================================= weight gradients of layers 3 and 2 =================================
     const int ww = wave - 4, tw = tid - 256;
     const int blkp = tw >> 7, kgp = (tw >> 5) & 3, qd = tw & 31;      // producer role: 8 rows x 4 features of the A operand
     const int m = lane & 15, kg = lane >> 4;
     const bf16x8* gp = reinterpret_cast<const bf16x8*>(smem + opaque((unsigned)(HALF_BF16 * 2 + (kg * 128 + 32 * ww + m) * 16)));
     const bf16x8* ap = reinterpret_cast<const bf16x8*>(smem + opaque((unsigned)(HALF_BF16 * 2 + OPS64 * 16 + (kg * 128 + m) * 16)));
     bf16x8* apub = reinterpret_cast<bf16x8*>(smem + opaque((unsigned)(HALF_BF16 * 2 + OPS64 * 16 + ((blkp * 4 + kgp) * 128 + 4 * qd) * 16)));
-    f32x4 acc[3][2][8];
-    float cs[3][2];
+    f32x4 acc[2][2][8];
+    float cs[2][2];
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < 2; ++l)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         cs[l][mb] = 0.f;
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) acc[l][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    // A operand of layer l for the whole 64-row tile: this lane loads 4 features of 8 consecutive rows, splits them once and
-    // publishes 4 x 3 operand vectors.  Loaded and consumed inside the window in which the chain waits for its weight DMA, so
-    // the 32 row registers are dead again while the accumulators work.
-    auto publish = [&](int l, long tile) {
+    // A operand (z2 for layer 3, z1 for layer 2) of a whole 64-row tile: this lane loads 4 features of 8 consecutive rows one
+    // phase ahead, splits them once and publishes 4 x 3 operand vectors.
+    f32x4 x[8];
+    auto fetch = [&](int l, long tile) {
       const long r0 = tile * TILE_ROWS + blkp * 32 + kgp * 8;
-      const float* A = fa.A[l] + 4 * qd;
-      const long ld = fa.ldA[l];
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-      bf16x4* pub = reinterpret_cast<bf16x4*>(apub);
+      const char* A = reinterpret_cast<const char*>(fa.A[l]);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {                   // rows 4h .. 4h+3 of the group = one half (8 bytes) of each operand vector
-        f32x4 x[4];
+      for (int j = 0; j < 8; ++j) {
+        const unsigned r = (unsigned)min(r0 + j, M - 1);
+        x[j] = *reinterpret_cast<const f32x4*>(A + (r * (LAT * 4u) + 16u * qd));
+      }
+    };
+    auto publish = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const long r = min(r0 + 4 * h + j, M - 1);
-          x[j] = *reinterpret_cast<const f32x4*>(A + r * ld);
-        }
+      for (int f = 0; f < 4; ++f) {
+        float v[8];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          bf16x4 sp[3];
+        for (int j = 0; j < 8; ++j) v[j] = x[j][f];
+        bf16x8 sp[3];
+        split3v8(v, sp);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float v = x[j][f];
-            const __bf16 hi = (__bf16)v;
-            const float r1 = v - (float)hi;
-            const __bf16 mi = (__bf16)r1;
-            sp[0][j] = hi; sp[1][j] = mi; sp[2][j] = (__bf16)(r1 - (float)mi);
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < (NP == 1 ? 1 : 3); ++s2) pub[(s2 * 8 * 128 + f) * 2 + h] = sp[s2];
-        }
+        for (int s2 = 0; s2 < (NP == 1 ? 1 : 3); ++s2) apub[s2 * 8 * 128 + f] = sp[s2];
       }
     };
     // Interleaving with the chain (same four barriers per layer; the matrix pipe alternates between the two kinds of wave):
     //   chain:  VALU (next dz, split) | write G(l), product half 0 | wait for weight half 1 | product half 1
-    //   wgrad:  dW(l+1) block 1       | publish A(l)               | dW(l) block 0          | -
-    // G(l) / A(l) are written between the 2nd and 3rd barrier and last read before the 2nd barrier of the NEXT layer.
-    bool pending = false;                             // block 1 of the previous layer still to be multiplied
+    //   wgrad:  dW(l+1) rows 32-63    | publish A(l), fetch next A | dW(l) rows 0-31        | -
+    const bool pub = !(DBG & 2), mm = !(DBG & 8);
+    if (t_beg < t_end && pub) fetch(0, t_beg);
     for (long tile = t_beg; tile < t_end; ++tile) {
-#pragma unroll
-      for (int l = 0; l < 3; ++l) {                   // layer 3 (A = z2), layer 2 (A = z1), layer 1 (A = e)
-        bar_lds();
-        if (pending && !(fa.dbg & 8)) wgrad_block<NP>(acc[(l + 2) % 3], cs[(l + 2) % 3], gp, ap, 1);
-        bar_lds();
-        if (!(fa.dbg & 2)) publish(l, tile);
-        bar_lds();
-        if (!(fa.dbg & 8)) wgrad_block<NP>(acc[l], cs[l], gp, ap, 0);
-        bar_lds();
-        pending = true;
-      }
+      // chain layer 3 / dW3 (A = z2)
+      bar_lds();
+      bar_lds();
+      if (pub) { publish(); fetch(1, tile); }
+      bar_lds();
+      if (mm) wgrad_block<NP>(acc[0], cs[0], gp, ap, 0);
+      bar_lds();
+      // chain layer 2 / dW2 (A = z1)
+      bar_lds();
+      if (mm) wgrad_block<NP>(acc[0], cs[0], gp, ap, 1);
+      bar_lds();
+      if (pub) { publish(); if (tile + 1 < t_end) fetch(0, tile + 1); }
+      bar_lds();
+      if (mm) wgrad_block<NP>(acc[1], cs[1], gp, ap, 0);
+      bar_lds();
+      // chain layer 1: no weight gradient here (dW1e = dz1^T e goes through the streaming kernel: dz1 is in memory anyway)
+      bar_lds();
+      if (mm) wgrad_block<NP>(acc[1], cs[1], gp, ap, 1);
+      bar_lds();
+      bar_lds();
+      bar_lds();
     }
-    if (pending && !(fa.dbg & 8)) wgrad_block<NP>(acc[2], cs[2], gp, ap, 1);
     bar_lds();                                        // (E)
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
-      float* slab = fa.slabs + ((long)blockIdx.x * 3 + l) * FSLAB;
+    for (int l = 0; l < 2; ++l) {
+      float* slab = fa.slabs + ((long)blockIdx.x * 2 + l) * FSLAB;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -348,14 +431,17 @@ static long fused_grid(int64_t M) {
 
 extern "C" int hgn_edge_bwd_fused_workspace_bytes(int64_t M, size_t* bytes) {
   if (!bytes || M < 0) return hgn_fail(HGN_E_INVALID, "hgn_edge_bwd_fused_workspace_bytes: bad argument");
-  *bytes = (size_t)fused_grid(M) * 3 * FSLAB * sizeof(float) + 256;
+  *bytes = (size_t)fused_grid(M) * 2 * FSLAB * sizeof(float) + 256;
   return HGN_OK;
 }
 
 extern "C" int hgn_edge_bwd_fused_eligible(const hgn_mlp_bwd_t* a) {
   static const bool off = getenv("HGN_NO_FUSED_BWD") != nullptr || getenv("HGN_FP32_MFMA") != nullptr;
   if (off || !a || !hgn_mlp_bwd6_eligible(a)) return 0;
-  if (a->n_dx != 1 || !a->dx[0].residual || a->dx[0].K != 128 || a->seg_dz1) return 0;
+  if (a->n_dx != 1 || !a->dx[0].residual || a->dx[0].K != 128 || a->seg_dz1 || !a->dz1) return 0;
+  if (a->agg_dout && (a->n_agg_ops != 1 || a->agg_ops[0] != HGN_OP_SUM)) return 0;      // several aggregates (pna): the two-launch path
+  const int64_t ldmax = a->ld_dout > a->dx[0].ld ? a->ld_dout : a->dx[0].ld;
+  if (a->M * (ldmax > 128 ? ldmax : 128) * 4 >= ((int64_t)1 << 32)) return 0;      // 32-bit row offsets inside the kernel
   return 1;
 }
 
@@ -379,34 +465,40 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
         return hgn_fail(HGN_E_INVALID, "hgn_edge_bwd_fused: max/min need the saved arg index");
     }
   }
-  if (!w->z2 || !w->z1 || !w->x || (w->ldx & 3) || !aligned16(w->z2) || !aligned16(w->z1) || !aligned16(w->x) || !w->dW3 ||
-      !w->dW2 || !w->dW1 || w->ldw1 < 128)
-    return hgn_fail(HGN_E_INVALID, "hgn_edge_bwd_fused: bad weight-gradient operands");
+  if (!w->z2 || !w->z1 || !aligned16(w->z2) || !aligned16(w->z1) || !w->dW3 || !w->dW2 || !a->dz1)
+    return hgn_fail(HGN_E_INVALID, "hgn_edge_bwd_fused: bad weight-gradient operands (dz1 must be written: dW1 is the caller's launch)");
   const long G = fused_grid(a->M);
   FusedArgs fa;
   fa.b = *a;
   fa.A[0] = w->z2; fa.ldA[0] = 128;
   fa.A[1] = w->z1; fa.ldA[1] = 128;
-  fa.A[2] = w->x; fa.ldA[2] = w->ldx;
   fa.slabs = (float*)workspace;
   fa.tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   static const int dbg = getenv("HGN_FUSED_DBG") ? atoi(getenv("HGN_FUSED_DBG")) : 0;
   fa.dbg = dbg;
   ProfScope ps(14, (double)a->M, stream);
-  if (matmul_products() == 1) hipLaunchKernelGGL(edge_bwd_fused_kernel<1>, dim3((unsigned)G), dim3(FT), 0, stream, fa);
-  else hipLaunchKernelGGL(edge_bwd_fused_kernel<6>, dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  if (matmul_products() == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  else switch (dbg) {                                   // diagnostic instantiations: one ablation each
+    case 2: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 2>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+    case 4: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 4>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+    case 8: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 8>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+    case 12: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 12>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+    case 16: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 16>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+    case 32: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 32>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+    case 63: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 63>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+    default: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  }
   if (hgn_check_launch("hgn_edge_bwd_fused") != HGN_OK) return HGN_E_LAUNCH;
   // fixed-order sums of the per-workgroup partials: three weight gradients + biases, and the LayerNorm-affine gradients
-  SlabReduceTask rt[3];
-  float* dW[3] = {w->dW3, w->dW2, w->dW1};
-  long ldw[3] = {128, 128, (long)w->ldw1};
-  float* db[3] = {w->db3, w->db2, w->db1};
-  for (int l = 0; l < 3; ++l) {
+  SlabReduceTask rt[2];
+  float* dW[2] = {w->dW3, w->dW2};
+  float* db[2] = {w->db3, w->db2};
+  for (int l = 0; l < 2; ++l) {
     rt[l].type = 0; rt[l].K = 128; rt[l].n_out = 128; rt[l].acc = w->accumulate ? 1 : 0; rt[l].n_chunks = (int)G;
-    rt[l].dW = dW[l]; rt[l].ldw = ldw[l]; rt[l].db = db[l]; rt[l].slab = fa.slabs + (long)l * FSLAB;
-    rt[l].chunk_stride = 3L * FSLAB;
+    rt[l].dW = dW[l]; rt[l].ldw = 128; rt[l].db = db[l]; rt[l].slab = fa.slabs + (long)l * FSLAB;
+    rt[l].chunk_stride = 2L * FSLAB;
   }
-  if (launch_slab_reduce(rt, 3, stream) != HGN_OK) return HGN_E_LAUNCH;
+  if (launch_slab_reduce(rt, 2, stream) != HGN_OK) return HGN_E_LAUNCH;
   // LayerNorm partial slabs: ln_ws holds hgn_mlp_bwd_ln_workspace_bytes(M) bytes = (tiles + parts) slabs; G <= tiles
   if (launch_ln_reduce(a->ln_ws, G, a->ln_ws + G * 256, a->d_gamma, a->d_beta, a->ln_accumulate, stream) != HGN_OK) return HGN_E_LAUNCH;
   return hgn_check_launch("hgn_edge_bwd_fused (reductions)");

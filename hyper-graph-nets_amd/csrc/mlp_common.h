@@ -97,18 +97,8 @@ __device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict
   }
 }
 
-// d_out_eff of the lane's row: d_out (optional) + the aggregation backward scattered back through the CSR row of the edge.
-template <bool ACC>
-__device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {
-  // ACC: add d_out_eff to g (residual path; 128-wide, aligned);  otherwise g = d_out_eff
-  if (ACC) {
-    if (a.d_out) t_add(g, a.d_out + rc * a.ld_dout, kq);
-  } else if (a.d_out) {
-    const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
-    if (vec_out) t_load(g, a.d_out + rc * a.ld_dout, kq); else t_load_masked(g, a.d_out + rc * a.ld_dout, kq, a.out_w);
-  } else {
-    t_zero(g);
-  }
+// Aggregation backward of the lane's row added to g: sum_slot d(op_slot)(agg_dout[seg[row]][slot * 128 ...]) (graphnet.py:50-70).
+__device__ __forceinline__ void add_agg_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {
   if (a.agg_dout) {
     const long r = a.agg_seg[rc];
     const int cnt = a.agg_rowptr[r + 1] - a.agg_rowptr[r];
@@ -129,6 +119,21 @@ __device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long r
       }
     }
   }
+}
+
+// d_out_eff of the lane's row: d_out (optional) + the aggregation backward scattered back through the CSR row of the edge.
+template <bool ACC>
+__device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {
+  // ACC: add d_out_eff to g (residual path; 128-wide, aligned);  otherwise g = d_out_eff
+  if (ACC) {
+    if (a.d_out) t_add(g, a.d_out + rc * a.ld_dout, kq);
+  } else if (a.d_out) {
+    const bool vec_out = (a.out_w == LAT) && ((a.ld_dout & 3) == 0);
+    if (vec_out) t_load(g, a.d_out + rc * a.ld_dout, kq); else t_load_masked(g, a.d_out + rc * a.ld_dout, kq, a.out_w);
+  } else {
+    t_zero(g);
+  }
+  add_agg_dout(g, a, rc, kq);
 }
 
 }  // namespace hgn

@@ -64,8 +64,8 @@ class WTask(C.Structure):
 
 
 class WFuse(C.Structure):
-    _fields_ = [('z2', c_f32p), ('z1', c_f32p), ('x', c_f32p), ('ldx', C.c_int64), ('dW3', c_f32p), ('db3', c_f32p),
-                ('dW2', c_f32p), ('db2', c_f32p), ('dW1', c_f32p), ('ldw1', C.c_int64), ('db1', c_f32p), ('accumulate', C.c_int32)]
+    _fields_ = [('z2', c_f32p), ('z1', c_f32p), ('dW3', c_f32p), ('db3', c_f32p), ('dW2', c_f32p), ('db2', c_f32p),
+                ('accumulate', C.c_int32)]
 
 
 class Pack(C.Structure):

@@ -572,17 +572,19 @@ class EdgeBlockFn(torch.autograd.Function):
             b.seg_dz1 = dP.data_ptr() + 4 * LAT; b.ld_seg_dz1 = 2 * LAT; b.seg_ids = topo.rcv.data_ptr()
         if fused:
             wf = _lib.WFuse()
-            wf.z2 = z2.data_ptr(); wf.z1 = z1.data_ptr(); wf.x = e.data_ptr(); wf.ldx = _ld(e)
+            wf.z2 = z2.data_ptr(); wf.z1 = z1.data_ptr()
             wf.dW3 = dw3.data_ptr(); wf.db3 = db3.data_ptr(); wf.dW2 = dw2.data_ptr(); wf.db2 = db2.data_ptr()
-            wf.dW1 = dw1.data_ptr() + 4 * 2 * LAT; wf.ldw1 = 3 * LAT; wf.db1 = db1.data_ptr()
-            if accs[0] != accs[2] or accs[0] != accs[4]:
+            if accs[2] != accs[4]:
                 raise _lib.HgnError('edge block: mixed accumulate / overwrite gradient targets')
-            wf.accumulate = accs[0]
+            wf.accumulate = accs[2]
             b.dz3 = None; b.dz2 = None
             nb = C.c_size_t(0)
             _lib.check(L.hgn_edge_bwd_fused_workspace_bytes(E, C.byref(nb)), 'hgn_edge_bwd_fused_workspace_bytes')
             ws = _workspace(dev, nb.value, 'fused')
             _lib.check(L.hgn_edge_bwd_fused(C.byref(b), C.byref(wf), ws.data_ptr(), ws.numel(), st), 'hgn_edge_bwd_fused')
+            # dW1's edge block: dz1 is in memory anyway (the sender / receiver sums read it), one streaming task
+            _run_wgrad([_wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
+                               db1.data_ptr(), accs[0])], E, dev, edge_level=True, keep=[e, dz1])
         elif E > 0:
             _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
         elif not accs[6]:

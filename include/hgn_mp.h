@@ -207,21 +207,19 @@ int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* args /*host*/);   /* 1 if hgn_mlp
 int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* packed_blocks_t /*host array, transposed form*/,
                     int n_blocks, float* dx, int64_t ld_dx, void* stream);
 
-/* Edge-block backward with the weight gradients in the SAME pass (csrc/fused_bwd.hip): autograd of
+/* Edge-block backward with the weight gradients of the two inner layers in the SAME pass (csrc/fused_bwd.hip): autograd of
  * GraphNet._update_edge_features (graphnet.py:22-32) for one edge set -- everything hgn_mlp_bwd computes for an edge block
  * (dz1, de = dx[0], LayerNorm-affine gradients, the folded aggregation backward) PLUS
- *   dW3 (+)= dz3^T z2, db3 (+)= colsum dz3;  dW2 (+)= dz2^T z1, db2 (+)= colsum dz2;  dW1[:, cols of x] (+)= dz1^T x, db1 (+)= colsum dz1
- * without dz3 / dz2 ever being written to memory (`a->dz3`, `a->dz2` are ignored; `a->dz1` is still written when non-null:
- * the sender / receiver sums of the split first layer read it).  One persistent 8-wave workgroup per CU; per-workgroup
- * partials are added in fixed order (deterministic).  Eligible when hgn_mlp_bwd6_eligible(a) holds, a->n_dx == 1 with a
- * 128-wide residual source, and a->seg_dz1 is null.  workspace: hgn_edge_bwd_fused_workspace_bytes(M) bytes, 16-byte
- * aligned; a->ln_ws: hgn_mlp_bwd_ln_workspace_bytes(M) bytes as for hgn_mlp_bwd. */
+ *   dW3 (+)= dz3^T z2, db3 (+)= colsum dz3;  dW2 (+)= dz2^T z1, db2 (+)= colsum dz2
+ * without dz3 / dz2 ever being written to memory (`a->dz3`, `a->dz2` are ignored).  `a->dz1` must be given: it is read by the
+ * sender / receiver sums of the split first layer and by the caller's hgn_mlp_wgrad task for dW1 (= dz1^T x).  One persistent
+ * 8-wave workgroup per CU; per-workgroup partials are added in fixed order (deterministic).  Eligible when
+ * hgn_mlp_bwd6_eligible(a) holds, a->n_dx == 1 with a 128-wide residual source, and a->seg_dz1 is null.  workspace:
+ * hgn_edge_bwd_fused_workspace_bytes(M) bytes, 16-byte aligned; a->ln_ws: hgn_mlp_bwd_ln_workspace_bytes(M) bytes. */
 typedef struct {
   const float* z2; const float* z1;   /* [M,128] saved post-ReLU activations of the forward (leading dimension 128)   */
-  const float* x; int64_t ldx;        /* [M,128] the residual source of a->dx[0] (edge latents e)                        */
   float* dW3; float* db3;             /* [128][128], [128]                                                              */
   float* dW2; float* db2;
-  float* dW1; int64_t ldw1; float* db1;   /* &dW1[0][col0 of x], leading dimension of dW1; db1 nullable               */
   int32_t accumulate;                 /* 0: results overwrite, 1: results are added (flat gradient buffer)             */
 } hgn_wfuse_t;
 int hgn_edge_bwd_fused_workspace_bytes(int64_t M, size_t* bytes /*host*/);

@@ -1098,7 +1098,8 @@ def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
         finally:
             ops.prof_enable(False)
             ops.set_fused_edge_backward(False)
-        assert ('edge_bwd_fused' in k) == fused and ('mlp_bwd_edge' in k) == (not fused), sorted(k)
+        took_fused = fused and agg == 'sum'                  # several aggregates per edge set (pna) / arg-routing: two launches
+        assert ('edge_bwd_fused' in k) == took_fused and ('mlp_bwd_edge' in k) == (not took_fused), sorted(k)
     (out_f, loss_f, g_f, ig_f), (out_u, loss_u, g_u, ig_u) = res[True], res[False]
     assert torch.equal(out_f, out_u)
     for kname in g_u:
