@@ -199,7 +199,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     const bool has_dout = a.d_out != nullptr;
     Act g[1], t[1], gout;
     // next tile's d(e') and x-hat rows are loaded into gout / g while this tile's last product runs (both are dead by then)
-    unsigned pf_m1 = 0, pf_m2 = 0;
+    unsigned pf_m1 = 0, pf_m2 = 0, pf_seg = 0;
     bf16x8 xs[1][3][4];
     int n = lane & 15, kq = lane >> 4;
     // LayerNorm-affine gradient partials: the 16-row sums of a tile go through 1 KB of LDS per wave (written BEFORE the layer's
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     float* lnw = nullptr;
     const unsigned ld_dout4 = (unsigned)a.ld_dout * 4u;
     unsigned char* gbase = nullptr;
-    auto prefetch = [&](long tile) {                  // 8 (+ 8 with d_out) row loads and 2 sign-word loads
+    auto prefetch = [&](long tile) {                  // 8 (+ 8 with d_out) row loads, 2 sign-word loads (+ 1 receiver id)
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       const unsigned rc = (unsigned)(row < M ? row : M - 1);
       t_load32(g[0], a.xhat, rc * (LAT * 4u) + 16u * kq);
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       const unsigned* bits = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.relu_bits) + (rc * 32u + 4u * kq));
       pf_m1 = bits[0];
       pf_m2 = bits[4];
+      pf_seg = a.agg_dout ? (unsigned)a.agg_seg[rc] : 0u;      // receiver of the row: its d(agg) row is gathered at the tile's start
     };
     if (t_beg < t_end && !(DBG & 32)) prefetch(t_beg);
     for (long tile = t_beg; tile < t_end; ++tile) {
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
           xh = g[0];
           if (!has_dout) t_zero(gout);
           if (a.agg_dout) {                           // `sum` aggregation backward: the receiver's d(agg) row (cache-resident gather)
-            const unsigned r = (unsigned)a.agg_seg[rc];
+            const unsigned r = pf_seg;
             const char* ar = reinterpret_cast<const char*>(a.agg_dout) + (r * ((unsigned)a.ld_agg * 4u) + 16u * kq);
             HGN_FOR_B(fb) gout.v[fb] += *reinterpret_cast<const f32x4*>(ar + 64 * fb);
           }
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       if (DBG & 32) bar_all();
       else {
         prefetch(tile + 1);
-        if (has_dout) bar_keep<18>(); else bar_keep<10>();
+        if (a.agg_dout) { if (has_dout) bar_keep<19>(); else bar_keep<11>(); }
+        else { if (has_dout) bar_keep<18>(); else bar_keep<10>(); }
       }
       if (!(DBG & 4)) mfma_half6_sb<0, NP>(t[0], xs[0], wst);
       bar_lds();
