@@ -85,17 +85,23 @@ __device__ __forceinline__ void write_gops(unsigned char* __restrict__ gbase /*l
       }
 }
 
-// dW_layer += G^T A over the 32 rows of block `blk` of the tile; wave ww owns dW rows [32 ww, 32 ww + 32)
+// dW_layer += G^T A over the 32 rows of block `blk` of the tile; wave ww owns dW rows [32 ww, 32 ww + 32).
+// The A vectors of feature block nb + 1 are read while block nb multiplies (double-buffered; the sched_barriers keep the compiler
+// from sinking the reads to their use, where every block would start with an exposed LDS round trip).
 template <int NP>
 __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], const bf16x8* __restrict__ gp /*lane base: G image*/,
                                             const bf16x8* __restrict__ ap /*lane base: A image*/, int blk) {
+  constexpr int NS = NP == 1 ? 1 : 3;
   bf16x8 gs[2][3];
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int s = 0; s < (NP == 1 ? 1 : 3); ++s) gs[mb][s] = gp[(s * 8 + blk * 4) * 128 + 16 * mb];
+    for (int s = 0; s < NS; ++s) gs[mb][s] = gp[(s * 8 + blk * 4) * 128 + 16 * mb];
+  bf16x8 as[2][3];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {               // bias gradient: the three split terms add up to the fp32 value exactly
+  for (int s = 0; s < NS; ++s) as[0][s] = ap[(s * 8 + blk * 4) * 128];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {                 // bias gradient: the three split terms add up to the fp32 value exactly
     float t = 0.f;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -107,23 +113,26 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], 
   }
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
-    bf16x8 as[3];
+    if (nb + 1 < 8) {
 #pragma unroll
-    for (int s = 0; s < (NP == 1 ? 1 : 3); ++s) as[s] = ap[(s * 8 + blk * 4) * 128 + 16 * nb];
+      for (int s = 0; s < NS; ++s) as[(nb + 1) & 1][s] = ap[(s * 8 + blk * 4) * 128 + 16 * (nb + 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 (&a)[3] = as[nb & 1];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       f32x4 c = acc[mb][nb];
       if (NP != 1) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][2], as[0], c, 0, 0, 0);      // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], as[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][2], a[0], c, 0, 0, 0);      // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], a[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], a[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], a[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], a[1], c, 0, 0, 0);
       }
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], as[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], a[0], c, 0, 0, 0);
       acc[mb][nb] = c;
     }
-    __builtin_amdgcn_sched_barrier(0);           // keep the operand vectors of later blocks out of the register file
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -132,28 +141,34 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], 
 template <int HALFI, int NP>
 __device__ __forceinline__ void mfma_half6_sb(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
   const int lane = threadIdx.x & 63;
+  const __bf16* lp = lds + lane * 8;
+  bf16x8 fr[2][3];
 #pragma unroll
-  for (int cl = 0; cl < 2; ++cl) {
-    const int c = 2 * HALFI + cl;
+  for (int s = 0; s < (NP == 1 ? 1 : 3); ++s) fr[0][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + 0) * 8 + 0) * TILE_BF16);
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-      const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
-      f32x4 t = acc.v[ob];
-      if (NP == 1) {
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[0][c], t, 0, 0, 0);
-      } else {
-        const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
-        const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(lds + ((2 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, xs[0][c], t, 0, 0, 0);      // smallest terms first
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[2][c], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[1][c], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mi, xs[0][c], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[1][c], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[0][c], t, 0, 0, 0);
-      }
-      acc.v[ob] = t;
-      if (ob == 3 || ob == 7) __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < 16; ++i) {                   // i = 8 * cl + ob
+    const int cl = i >> 3, ob = i & 7, c = 2 * HALFI + cl;
+    if (i + 1 < 16) {
+      const int cl1 = (i + 1) >> 3, ob1 = (i + 1) & 7;
+#pragma unroll
+      for (int s = 0; s < (NP == 1 ? 1 : 3); ++s)
+        fr[(i + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + cl1) * 8 + ob1) * TILE_BF16);
     }
+    __builtin_amdgcn_sched_barrier(0);             // issued here, ahead of this block's products
+    const bf16x8 (&a)[3] = fr[i & 1];              // a[0] hi, a[1] mid, a[2] lo
+    f32x4 t = acc.v[ob];
+    if (NP == 1) {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][c], t, 0, 0, 0);
+    } else {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[0][c], t, 0, 0, 0);      // smallest terms first
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[2][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[1][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[0][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[1][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][c], t, 0, 0, 0);
+    }
+    acc.v[ob] = t;
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -296,7 +311,8 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       bar_all();
       if (!(DBG & 4)) mfma_half6_sb<1, NP>(g[0], xs[0], wst);
       relu_mask_bits(g[0], mb1);                      // dz1
-      if (valid) t_store32(g[0], a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
+      // (whole 64-row tiles are stored: rows past M land in the padding the caller provides)
+      t_store32(g[0], a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
       // ---- layer 1: de = d_out_eff + dz1 W1e -------------------------------------------------------------------------
       bar_lds();
       if (!(DBG & 16)) stage_half6<NP>(wst, pk1);

@@ -525,7 +525,7 @@ class EdgeBlockFn(torch.autograd.Function):
         dev = (d_out if d_out is not None else d_agg).device
         dz3 = torch.empty(E, LAT, device=dev)
         dz2 = torch.empty(E, LAT, device=dev)
-        dz1 = torch.empty(E, LAT, device=dev)
+        dz1 = torch.empty((E + 63) // 64 * 64, LAT, device=dev)[:E]      # whole 64-row tiles: hgn_edge_bwd_fused stores the padding rows too
         de = torch.empty(E, LAT, device=dev)
         b = _lib.MlpBwd()
         b.M = E

@@ -211,7 +211,8 @@ int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* p
  * GraphNet._update_edge_features (graphnet.py:22-32) for one edge set -- everything hgn_mlp_bwd computes for an edge block
  * (dz1, de = dx[0], LayerNorm-affine gradients, the folded aggregation backward) PLUS
  *   dW3 (+)= dz3^T z2, db3 (+)= colsum dz3;  dW2 (+)= dz2^T z1, db2 (+)= colsum dz2
- * without dz3 / dz2 ever being written to memory (`a->dz3`, `a->dz2` are ignored).  `a->dz1` must be given: it is read by the
+ * without dz3 / dz2 ever being written to memory (`a->dz3`, `a->dz2` are ignored).  `a->dz1` must be given AND hold
+ * ceil(M / 64) * 64 rows (the kernel stores whole 64-row tiles; rows >= M are padding): it is read by the
  * sender / receiver sums of the split first layer and by the caller's hgn_mlp_wgrad task for dW1 (= dz1^T x).  One persistent
  * 8-wave workgroup per CU; per-workgroup partials are added in fixed order (deterministic).  Eligible when
  * hgn_mlp_bwd6_eligible(a) holds, a->n_dx == 1 with a 128-wide residual source, and a->seg_dz1 is null.  workspace:
