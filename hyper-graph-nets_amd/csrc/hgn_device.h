@@ -261,6 +261,20 @@ __device__ __forceinline__ float row_sum(const Act& a) {
   return t;
 }
 
+// row_sum of the squares, with the squares rounded on their own (no fused multiply-add): the same bits as row_sum of a tile
+// that holds a * a, without that tile
+__device__ __forceinline__ float row_sum_sq(const Act& a) {
+  float s0 = 0.f, s1 = 0.f;
+  HGN_FOR_B(fb) {
+    s0 += __fmul_rn(a.v[fb][0], a.v[fb][0]) + __fmul_rn(a.v[fb][1], a.v[fb][1]);
+    s1 += __fmul_rn(a.v[fb][2], a.v[fb][2]) + __fmul_rn(a.v[fb][3], a.v[fb][3]);
+  }
+  float t = s0 + s1;
+  t += __shfl_xor(t, 16);
+  t += __shfl_xor(t, 32);
+  return t;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // One 128-wide contraction block = two staged halves.  `between()` is called once, after the first half's DMA has been
 // issued and before the wait, so the caller's own global loads fly together with it.

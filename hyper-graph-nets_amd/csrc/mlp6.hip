@@ -56,9 +56,24 @@ __global__ void pack_bf16x3_kernel(const PackArgs a) {
 template <int NS, int NP>
 __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+  __shared__ int seg_ids_lds[NS][SEG_PRE_INTS];     // see SegPre
   static_assert(HALF_BF16 * 2 >= SEG_LDS_FLOATS * 4, "the weight stage doubles as the segment-sum tile");
   const int kq = (threadIdx.x & 63) >> 4;
   const Rows<NS> R(a.M);
+  HGN_STAMP();                                      // kernel entered
+  // Every INDEX the kernel gathers through is loaded here, ahead of everything: the dependent row loads below then cost one
+  // memory round trip instead of two (measured on 1.19 M edge rows: the first block's loads took 12.6 of the workgroup's 75 us
+  // when each `add` source was index load -> wait -> row loads -> wait -> add, one after the other).
+  int add_row[NS][HGN_MAX_ADD];
+#pragma unroll
+  for (int u = 0; u < NS; ++u)
+#pragma unroll
+    for (int i = 0; i < HGN_MAX_ADD; ++i) add_row[u][i] = i < a.n_add ? a.add[i].idx[R.rc[u]] : 0;
+  SegPre seg_pre[NS];
+  if (a.seg_out) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) seg_pre[u].load(a.seg_ids, R.tile_row0 + u * TILE_ROWS, a.M);
+  }
 
   Act acc[NS], b[NS];
   bool first = true;
@@ -74,10 +89,20 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
           const long srow = s.idx ? (long)s.idx[R.rc[u]] : R.rc[u];
           const float* xr = s.x + srow * s.ld + k0;
           // narrow / unaligned sources (encoder inputs): zero-extended to the 128-wide block whose pack is zero padded
-          if (vec) { if (kw == 128) t_load(b[u], xr, kq); else t_load_w(b[u], xr, kq, kw); } else t_load_masked(b[u], xr, kq, kw);
-          if (first) {
-            t_load(acc[u], a.b1, kq);
-            for (int i = 0; i < a.n_add; ++i) t_add(acc[u], a.add[i].P + (long)a.add[i].idx[R.rc[u]] * a.add[i].ld, kq);
+          if (HGN_ABL & 8) t_zero(b[u]);
+          else if (vec) { if (kw == 128) t_load(b[u], xr, kq); else t_load_w(b[u], xr, kq, kw); } else t_load_masked(b[u], xr, kq, kw);
+          if (first) {                              // acc = b1 + P0[row] + P1[row]: all loads issued before the first add
+            if (a.n_add == 0) t_load(acc[u], a.b1, kq);
+            else {
+              static_assert(HGN_MAX_ADD == 2, "two gathered pre-projections at most");
+              Act p1;
+              t_load(acc[u], a.add[0].P + (long)add_row[u][0] * a.add[0].ld, kq);
+              if (a.n_add > 1) t_load(p1, a.add[1].P + (long)add_row[u][1] * a.add[1].ld, kq);
+              __builtin_amdgcn_sched_barrier(0);    // (the row loads above are in flight before the bias loads and the adds)
+              HGN_FOR_B(fb) acc[u].v[fb] = *reinterpret_cast<const f32x4*>(a.b1 + 16 * fb + 4 * kq) + acc[u].v[fb];
+              if (a.n_add > 1) HGN_FOR_B(fb) acc[u].v[fb] += p1.v[fb];
+            }
+            if (a.seg_out) seg_pre[u].stash(seg_ids_lds[u]);
           }
         }
         first = false;
@@ -87,8 +112,8 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     relu6(acc[u]);
-    if (a.z1 && R.valid[u]) t_store(acc[u], a.z1 + R.row[u] * LAT, kq);
-    if (a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + kq] = relu_bits_of(acc[u]);
+    if (!(HGN_ABL & 4) && a.z1 && R.valid[u]) t_store(acc[u], a.z1 + R.row[u] * LAT, kq);
+    if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + kq] = relu_bits_of(acc[u]);
   }
   gemm6<NS, NP>(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
 #pragma unroll
@@ -97,25 +122,27 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     relu6(b[u]);
-    if (a.z2 && R.valid[u]) t_store(b[u], a.z2 + R.row[u] * LAT, kq);
-    if (a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + 4 + kq] = relu_bits_of(b[u]);
+    if (!(HGN_ABL & 4) && a.z2 && R.valid[u]) t_store(b[u], a.z2 + R.row[u] * LAT, kq);
+    if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + 4 + kq] = relu_bits_of(b[u]);
   }
   gemm6<NS, NP>(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) t_load(acc[u], a.b3, kq);
+  }, [&](Act (&free_b)[NS]) {                       // the residual rows arrive while the last block multiplies
+    if (a.res) {
+#pragma unroll
+      for (int u = 0; u < NS; ++u) t_load(free_b[u], a.res + R.rc[u] * a.ld_res, kq);
+    }
   });
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     if (a.ln_g) {
       const float mean = row_sum(acc[u]) * (1.f / LAT);
-      HGN_FOR_B(fb) {
-        acc[u].v[fb] -= mean;
-        b[u].v[fb] = acc[u].v[fb] * acc[u].v[fb];
-      }
-      const float var = row_sum(b[u]) * (1.f / LAT);
+      HGN_FOR_B(fb) acc[u].v[fb] -= mean;
+      const float var = row_sum_sq(acc[u]) * (1.f / LAT);
       const float rstd = 1.f / sqrtf(var + 1e-5f);
       HGN_FOR_B(fb) acc[u].v[fb] *= rstd;
-      if (a.xhat && R.valid[u]) t_store(acc[u], a.xhat + R.row[u] * LAT, kq);
+      if (!(HGN_ABL & 4) && a.xhat && R.valid[u]) t_store(acc[u], a.xhat + R.row[u] * LAT, kq);
       if (a.rstd && R.valid[u] && kq == 0) a.rstd[R.row[u]] = rstd;
       HGN_FOR_B(fb) {
         const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
@@ -123,17 +150,18 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
         acc[u].v[fb] = acc[u].v[fb] * gm + bt;
       }
     }
-    if (R.valid[u]) {
-      if (a.res) t_add(acc[u], a.res + R.row[u] * a.ld_res, kq);
-      t_store(acc[u], a.out + R.row[u] * a.ld_out, kq);
-    }
+    if (a.res) HGN_FOR_B(fb) acc[u].v[fb] += b[u].v[fb];
+    if (R.valid[u]) t_store(acc[u], a.out + R.row[u] * a.ld_out, kq);
   }
-  if (a.seg_out) {
+  HGN_STAMP();                                      // epilogue stores issued
+  if (a.seg_out) {                                  // (waits for none of the stores above: see SegPre)
 #pragma unroll
     for (int u = 0; u < NS; ++u)
       if (R.tile_row0 + u * TILE_ROWS < a.M)          // uniform over the workgroup
-        tile_segment_sum(acc[u], reinterpret_cast<float*>(lds), a.seg_ids, a.seg_out, a.ld_seg_out, R.tile_row0 + u * TILE_ROWS, a.M);
+        tile_segment_sum(acc[u], reinterpret_cast<float*>(lds), a.seg_ids, a.seg_out, a.ld_seg_out, R.tile_row0 + u * TILE_ROWS, a.M,
+                         seg_ids_lds[u]);
   }
+  HGN_STAMP();                                      // segment sums done
 }
 
 // single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
@@ -184,9 +212,9 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       Act& xh = t[u];
-      load_dout<false>(g[u], a, R.rc[u], kq);
+      if (HGN_ABL & 8) t_zero(g[u]); else load_dout<false>(g[u], a, R.rc[u], kq);
       if (PARK && R.valid[u]) t_store(g[u], park + R.row[u] * park_ld, kq);
-      t_load(xh, a.xhat + R.rc[u] * LAT, kq);
+      if (HGN_ABL & 8) t_zero(xh); else t_load(xh, a.xhat + R.rc[u] * LAT, kq);
       HGN_FOR_B(fb) {                               // LayerNorm-affine gradient partials of this wave's rows
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -213,14 +241,14 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
       const float m2 = qs * (1.f / LAT);
       const float r = a.rstd[R.rc[u]];
       HGN_FOR_B(fb) g[u].v[fb] = r * (g[u].v[fb] - m1 - xh.v[fb] * m2);
-      if (a.dz3 && R.valid[u]) t_store(g[u], a.dz3 + R.row[u] * LAT, kq);
+      if (!(HGN_ABL & 4) && a.dz3 && R.valid[u]) t_store(g[u], a.dz3 + R.row[u] * LAT, kq);
       t_zero(t[u]);
     }
   });
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     relu_mask_bits(t[u], mb2[u]);
-    if (a.dz2 && R.valid[u]) t_store(t[u], a.dz2 + R.row[u] * LAT, kq);
+    if (!(HGN_ABL & 4) && a.dz2 && R.valid[u]) t_store(t[u], a.dz2 + R.row[u] * LAT, kq);
   }
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
   gemm6<NS, NP>(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] {
@@ -230,7 +258,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     relu_mask_bits(g[u], mb1[u]);
-    if (a.dz1 && R.valid[u]) t_store(g[u], a.dz1 + R.row[u] * LAT, kq);
+    if (!(HGN_ABL & 4) && a.dz1 && R.valid[u]) t_store(g[u], a.dz1 + R.row[u] * LAT, kq);
   }
   // receiver sums of dz1 while the tile is still in registers (the stage buffer is free between two blocks; the next block's
   // opening barrier orders the reads below before its weight DMA)
@@ -281,6 +309,17 @@ __global__ __launch_bounds__(WG, 3) void linear6_bwd_kernel(const Lin6Args a) {
 
 using namespace hgn;
 
+#if HGN_ABL & 16
+extern "C" int hgn_debug_mlp6_stamps(unsigned long long* host256, int* n) {
+  (void)hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(host256, HIP_SYMBOL(hgn::g_hgn_stamps), 256 * 8) != hipSuccess) return HGN_E_LAUNCH;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(hgn::g_hgn_stamp_n), 4) != hipSuccess) return HGN_E_LAUNCH;
+  int zero = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(hgn::g_hgn_stamp_n), &zero, 4);
+  return HGN_OK;
+}
+#endif
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int hgn_pack_bf16x3(const hgn_pack_t* blocks, int n, void* stream) {
@@ -313,6 +352,8 @@ namespace hgn {
 // per row, but measured no faster in the product (edge forward 1.18 vs 1.21 ms, backward 1.37 vs 1.34 ms at 1.19 M rows) and
 // worse on small launches (half as many workgroups), so the 64-row kernels stay the default.
 static bool tile128() { static const bool v = getenv("HGN_TILE128") != nullptr; return v; }
+// diagnostic: extra dynamic LDS per workgroup, to see the kernels at 2 or 1 workgroups per CU (HGN_DIAG_LDS_PAD=bytes)
+static unsigned lds_pad() { static const unsigned v = getenv("HGN_DIAG_LDS_PAD") ? (unsigned)atoi(getenv("HGN_DIAG_LDS_PAD")) : 0u; return v; }
 
 int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   if (tile128() && matmul_products() == 6 && a->M > TILE_ROWS) {
@@ -321,7 +362,7 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   } else {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
     if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6>), dim3((unsigned)tiles), dim3(WG), lds_pad(), (hipStream_t)stream, *a);
   }
   return hgn_check_launch("hgn_mlp_fwd (split-bf16)");
 }
@@ -368,7 +409,7 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
       for (int i = 0; i < a->n_dx; ++i) park = park || a->dx[i].residual;
     if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else if (park) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, true>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, false>), dim3((unsigned)tiles), dim3(WG), lds_pad(), (hipStream_t)stream, *a);
     *n_slabs = tiles;
   }
   return hgn_check_launch("hgn_mlp_bwd (split-bf16)");

@@ -4,6 +4,25 @@
 #include "hgn_device.h"
 #include "mlp_common.h"
 
+// Diagnostic builds only (tools/build_ablations.sh): compile-time ablation mask of the split-bf16 edge kernels.
+//   1 no weight DMA   2 no MFMA   4 no stores of saved activations / intermediate gradients   8 no row loads
+//  16 time stamps (s_memrealtime, 10 ns) of one mid-launch workgroup's wave 0 through the forward kernel (tools/fwdstamps.py)
+#ifndef HGN_ABL
+#define HGN_ABL 0
+#endif
+#if HGN_ABL & 16
+namespace hgn {
+static __device__ unsigned long long g_hgn_stamps[256];      // (one copy per translation unit: only csrc/mlp6.hip reads its own)
+static __device__ int g_hgn_stamp_n;
+}
+#define HGN_STAMP()                                                                      \
+  do {                                                                                   \
+    if (blockIdx.x == 9000 && threadIdx.x == 0 && g_hgn_stamp_n < 256) g_hgn_stamps[g_hgn_stamp_n++] = wall_clock64(); \
+  } while (0)
+#else
+#define HGN_STAMP() do {} while (0)
+#endif
+
 namespace hgn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -75,21 +94,38 @@ __device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS
 
 // acc[u][ob] += Wblock * b[u] for one packed 128 x 128 block.  `between()` runs after the first half's DMA has been issued and
 // before the wait (the caller's own global loads fly with it); `b` is split after the wait, so `between` may load it.
+// `post_split(b)` runs once `b` has been split into the bf16 operands: its registers are free from there to the end of the block,
+// e.g. as the landing zone of a load the caller needs right after the block (two product halves and a DMA wait ahead of its use).
+template <int NS, int NP, class F, class G>
+__device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
+                                      F&& between, G&& post_split) {
+  bf16x8 xs[NS][3][4];
+  HGN_STAMP();                                    // 0: block entered
+  wg_barrier_lds();
+  HGN_STAMP();                                    // 1: stage free
+  if (!(HGN_ABL & 1)) stage_half6<NP>(lds, pk);
+  between();
+  HGN_STAMP();                                    // 2: DMA + caller's loads issued
+  __syncthreads();
+  HGN_STAMP();                                    // 3: landed
+#pragma unroll
+  for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
+  post_split(b);
+  HGN_STAMP();                                    // 4: split
+  if (!(HGN_ABL & 2)) mfma_half6<0, NS, NP>(acc, xs, lds);
+  HGN_STAMP();                                    // 5: products of half 0 issued
+  wg_barrier_lds();
+  HGN_STAMP();                                    // 6: every wave done with half 0
+  if (!(HGN_ABL & 1)) stage_half6<NP>(lds, pk + HALF_BF16);
+  __syncthreads();
+  HGN_STAMP();                                    // 7: half 1 landed
+  if (!(HGN_ABL & 2)) mfma_half6<1, NS, NP>(acc, xs, lds);
+  HGN_STAMP();                                    // 8: products of half 1 issued
+}
 template <int NS, int NP, class F>
 __device__ __forceinline__ void gemm6(Act (&acc)[NS], const Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
                                       F&& between) {
-  bf16x8 xs[NS][3][4];
-  wg_barrier_lds();
-  stage_half6<NP>(lds, pk);
-  between();
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
-  mfma_half6<0, NS, NP>(acc, xs, lds);
-  wg_barrier_lds();
-  stage_half6<NP>(lds, pk + HALF_BF16);
-  __syncthreads();
-  mfma_half6<1, NS, NP>(acc, xs, lds);
+  gemm6<NS, NP>(acc, const_cast<Act (&)[NS]>(b), lds, pk, between, [](Act (&)[NS]) {});
 }
 
 __device__ __forceinline__ void relu6(Act& a) {

@@ -35,23 +35,45 @@ __device__ __forceinline__ void relu_mask_bits(Act& g, unsigned m) {
 // in half 0 over through LDS, so every segment is written once per tile.  `ldsf`: SEG_LDS_FLOATS floats, free for use; the
 // caller must put a workgroup barrier between this call and the next write to `ldsf`.
 constexpr int SEG_LDS_FLOATS = 64 * 132 + 64 + 128;
+// `pre_ids` (optional): the segment ids this call needs, already in LDS (SegPre, filled near kernel entry): [0, 64) the id of
+// row tile_row0 + i (-1 past the end), [64] / [65] the ids of the rows before / after the tile (-1: none).  Vector memory retires
+// in order, so a load issued HERE is also a wait for every store the caller has in flight (its output rows); with `pre_ids`
+// the function waits for no global memory at all and its barriers are LDS-only.  (The ids are parked in LDS rather than in
+// registers: a register that lives from kernel entry to here gets spilled, and the reload is a vector-memory load again.)
+constexpr int SEG_PRE_INTS = TILE_ROWS + 2;
+struct SegPre {
+  int id, prev, next;
+  __device__ __forceinline__ void load(const int32_t* __restrict__ seg_ids, long tile_row0, long M) {
+    const long r = tile_row0 + threadIdx.x;
+    id = (threadIdx.x < TILE_ROWS && r < M) ? seg_ids[r] : -1;
+    prev = tile_row0 > 0 ? seg_ids[tile_row0 - 1] : -1;
+    const long e = min(tile_row0 + TILE_ROWS, M);
+    next = e < M ? seg_ids[e] : -1;
+  }
+  __device__ __forceinline__ void stash(int* __restrict__ lds_ids) const {      // visible after the caller's next workgroup barrier
+    if (threadIdx.x < TILE_ROWS) lds_ids[threadIdx.x] = id;
+    if (threadIdx.x == 0) { lds_ids[TILE_ROWS] = prev; lds_ids[TILE_ROWS + 1] = next; }
+  }
+};
 __device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict__ ldsf, const int32_t* __restrict__ seg_ids,
-                                                 float* __restrict__ out, long ld, long tile_row0, long M) {
+                                                 float* __restrict__ out, long ld, long tile_row0, long M,
+                                                 const int* __restrict__ pre_ids = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
-  int* ids = reinterpret_cast<int*>(ldsf + 64 * 132);
+  const int* ids = pre_ids ? pre_ids : reinterpret_cast<const int*>(ldsf + 64 * 132);
   float* hp = ldsf + 64 * 132 + 64;
-  __syncthreads();                                          // every wave is done with the weight stage
+  if (pre_ids) wg_barrier_lds(); else __syncthreads();      // every wave is done with the weight stage
   float* wr = ldsf + (wave * WAVE_ROWS + n) * 132 + 4 * kq;
   HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(wr + 16 * fb) = v.v[fb];
   const int rows = (int)min((long)TILE_ROWS, M - tile_row0);
-  if (threadIdx.x < 64) ids[threadIdx.x] = threadIdx.x < rows ? seg_ids[tile_row0 + threadIdx.x] : -1;
-  __syncthreads();
+  if (!pre_ids && threadIdx.x < 64)
+    reinterpret_cast<int*>(ldsf + 64 * 132)[threadIdx.x] = threadIdx.x < rows ? seg_ids[tile_row0 + threadIdx.x] : -1;
+  if (pre_ids) wg_barrier_lds(); else __syncthreads();
   const int half = threadIdx.x >> 7, c = threadIdx.x & 127;
   const int r0 = 32 * half, r1 = min(rows, r0 + 32);
   const bool active = r0 < rows;
-  const bool tile_cont_prev = tile_row0 > 0 && seg_ids[tile_row0 - 1] == ids[0];
-  const bool tile_cont_next = tile_row0 + rows < M && seg_ids[tile_row0 + rows] == ids[rows - 1];
+  const bool tile_cont_prev = tile_row0 > 0 && (pre_ids ? pre_ids[TILE_ROWS] : seg_ids[tile_row0 - 1]) == ids[0];
+  const bool tile_cont_next = tile_row0 + rows < M && (pre_ids ? pre_ids[TILE_ROWS + 1] : seg_ids[tile_row0 + rows]) == ids[rows - 1];
   int cur = -1;
   float s = 0.f;
   bool first = true;                                        // still inside the segment my range began with
@@ -87,7 +109,7 @@ __device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict
       }
     }
   }
-  __syncthreads();
+  if (pre_ids) wg_barrier_lds(); else __syncthreads();
   if (!half && active) {
     const bool joined = rows > 32 && ids[32] == cur;        // half 1 began inside my last segment
     const float total = s + (joined ? hp[c] : 0.f);

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhgn_mp.so')
+# HGN_LIB: diagnostic builds of the same C-ABI (tools/build_ablations.sh); never set in production
+LIB_PATH = os.environ.get('HGN_LIB') or os.path.join(_HERE, 'libhgn_mp.so')
 
 HGN_MAX_SRC = 8
 HGN_MAX_ADD = 2
