@@ -55,25 +55,19 @@ struct SegPre {
     if (threadIdx.x == 0) { lds_ids[TILE_ROWS] = prev; lds_ids[TILE_ROWS + 1] = next; }
   }
 };
-__device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict__ ldsf, const int32_t* __restrict__ seg_ids,
-                                                 float* __restrict__ out, long ld, long tile_row0, long M,
-                                                 const int* __restrict__ pre_ids = nullptr) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 15, kq = lane >> 4;
-  const int* ids = pre_ids ? pre_ids : reinterpret_cast<const int*>(ldsf + 64 * 132);
+// The column walk of tile_segment_sum: the 64 x 128 tile is in `ldsf` (row stride 132 floats), the ids in `ids`, and a workgroup
+// barrier lies between those writes and this call.  Threads 0..255 walk (thread = (half, column)); EVERY thread of the workgroup
+// must call (one barrier inside; `lds_only`: the barrier does not wait for the caller's global stores).
+__device__ __forceinline__ void tile_segment_walk(float* __restrict__ ldsf, const int* __restrict__ ids, int prev_id, int next_id,
+                                                  float* __restrict__ out, long ld, long tile_row0, long M, bool lds_only) {
   float* hp = ldsf + 64 * 132 + 64;
-  if (pre_ids) wg_barrier_lds(); else __syncthreads();      // every wave is done with the weight stage
-  float* wr = ldsf + (wave * WAVE_ROWS + n) * 132 + 4 * kq;
-  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(wr + 16 * fb) = v.v[fb];
   const int rows = (int)min((long)TILE_ROWS, M - tile_row0);
-  if (!pre_ids && threadIdx.x < 64)
-    reinterpret_cast<int*>(ldsf + 64 * 132)[threadIdx.x] = threadIdx.x < rows ? seg_ids[tile_row0 + threadIdx.x] : -1;
-  if (pre_ids) wg_barrier_lds(); else __syncthreads();
-  const int half = threadIdx.x >> 7, c = threadIdx.x & 127;
+  const bool walker = threadIdx.x < 256;
+  const int half = (threadIdx.x >> 7) & 1, c = threadIdx.x & 127;
   const int r0 = 32 * half, r1 = min(rows, r0 + 32);
-  const bool active = r0 < rows;
-  const bool tile_cont_prev = tile_row0 > 0 && (pre_ids ? pre_ids[TILE_ROWS] : seg_ids[tile_row0 - 1]) == ids[0];
-  const bool tile_cont_next = tile_row0 + rows < M && (pre_ids ? pre_ids[TILE_ROWS + 1] : seg_ids[tile_row0 + rows]) == ids[rows - 1];
+  const bool active = walker && r0 < rows;
+  const bool tile_cont_prev = tile_row0 > 0 && prev_id == ids[0];
+  const bool tile_cont_next = tile_row0 + rows < M && next_id == ids[rows - 1];
   int cur = -1;
   float s = 0.f;
   bool first = true;                                        // still inside the segment my range began with
@@ -109,7 +103,7 @@ __device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict
       }
     }
   }
-  if (pre_ids) wg_barrier_lds(); else __syncthreads();
+  if (lds_only) wg_barrier_lds(); else __syncthreads();
   if (!half && active) {
     const bool joined = rows > 32 && ids[32] == cur;        // half 1 began inside my last segment
     const float total = s + (joined ? hp[c] : 0.f);
@@ -117,6 +111,24 @@ __device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict
     float* dst = out + (long)cur * ld + c;
     if ((first && cont_prev) || (to_end && tile_cont_next)) unsafeAtomicAdd(dst, total); else *dst = total;
   }
+}
+
+__device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict__ ldsf, const int32_t* __restrict__ seg_ids,
+                                                 float* __restrict__ out, long ld, long tile_row0, long M,
+                                                 const int* __restrict__ pre_ids = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int* ids = pre_ids ? pre_ids : reinterpret_cast<const int*>(ldsf + 64 * 132);
+  if (pre_ids) wg_barrier_lds(); else __syncthreads();      // every wave is done with the weight stage
+  float* wr = ldsf + (wave * WAVE_ROWS + n) * 132 + 4 * kq;
+  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(wr + 16 * fb) = v.v[fb];
+  const int rows = (int)min((long)TILE_ROWS, M - tile_row0);
+  if (!pre_ids && threadIdx.x < 64)
+    reinterpret_cast<int*>(ldsf + 64 * 132)[threadIdx.x] = threadIdx.x < rows ? seg_ids[tile_row0 + threadIdx.x] : -1;
+  if (pre_ids) wg_barrier_lds(); else __syncthreads();
+  const int prev_id = tile_row0 > 0 ? (pre_ids ? pre_ids[TILE_ROWS] : seg_ids[tile_row0 - 1]) : -1;
+  const int next_id = tile_row0 + rows < M ? (pre_ids ? pre_ids[TILE_ROWS + 1] : seg_ids[tile_row0 + rows]) : -1;
+  tile_segment_walk(ldsf, ids, prev_id, next_id, out, ld, tile_row0, M, pre_ids != nullptr);
 }
 
 // Aggregation backward of the lane's row added to g: sum_slot d(op_slot)(agg_dout[seg[row]][slot * 128 ...]) (graphnet.py:50-70).

@@ -93,6 +93,8 @@ _SIGS = {
     'hgn_set_matmul_products': (C.c_int, [C.c_int]),
     'hgn_get_matmul_products': (C.c_int, []),
     'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
+    'hgn_mlp_fwd_ws_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
+    'hgn_set_ws_fwd': (C.c_int, [C.c_int]),
     'hgn_linear_fwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
     'hgn_mlp_bwd6_eligible': (C.c_int, [C.POINTER(MlpBwd)]),

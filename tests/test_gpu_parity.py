@@ -1159,3 +1159,37 @@ def test_deferred_node_level_weight_gradients_match_immediate_launches():
     for (kname, p), off in zip(tr.model.named_parameters(), tr.fp.offsets):
         if float(g_o[kname].abs().max()) > 0:
             assert H.rel_err(grads[True][off:off + p.numel()].view(p.shape), g_o[kname]) <= TOL_GRAD, kname
+
+
+@pytest.mark.parametrize('nx,ny,agg', [(7, 5, 'sum'), (40, 40, 'sum'), (23, 17, 'pna')])
+def test_weight_stationary_edge_forward_equals_staged_forward(nx, ny, agg):
+    """csrc/ws_fwd.hip (opt-in: weights of the three edge-MLP layers resident in registers, activations through LDS) against the
+    staged-weights kernel it can replace, through the same autograd function: outputs, aggregates and every gradient (the
+    backward reads the activations / sign words the forward saved) to fp32 rounding -- the first layer adds its bias and gathered
+    pre-projections after the products instead of before, so not bit for bit -- and against the fp64 oracle at the usual
+    tolerances.  Sizes: fewer tiles than workgroups, more, and a ragged last tile; pna: no in-kernel segment sums."""
+    import hgn_amd
+    from hgn_amd import ops
+    graph = synth.grid_graph(seed=4, nx=nx, ny=ny)
+    shapes = O.param_shapes('none', agg, 2, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=13)
+    N = nx * ny
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(4))
+    mask = torch.ones(N, dtype=torch.bool); mask[:2] = False
+    model = H.hip_model('none', agg, 2, ['mesh_edges'], sd)
+    res = {}
+    for ws in (True, False):
+        ops.set_ws_edge_forward(ws)
+        try:
+            res[ws] = H.hip_run(model, graph, target, mask)
+        finally:
+            ops.set_ws_edge_forward(False)
+    (out_w, loss_w, g_w, ig_w), (out_s, loss_s, g_s, ig_s) = res[True], res[False]
+    assert H.rel_err(out_w, out_s) <= 2e-6
+    for kname in g_s:
+        if float(g_s[kname].abs().max()) > 0:
+            assert H.rel_err(g_w[kname], g_s[kname]) <= 5e-5, kname     # (a ReLU sign can flip where z ~ 1e-8: both are valid)
+    out_o, _, g_o, _ = H.oracle_run(sd, graph, 'none', agg, target, mask) if agg == 'sum' and N <= 400 else (None, None, None, None)
+    if out_o is not None:
+        assert H.rel_err(out_w, out_o) <= TOL_OUT
+        assert max(H.rel_err(g_w[kname], g_o[kname]) for kname in g_o if float(g_o[kname].abs().max()) > 0) <= TOL_GRAD
