@@ -53,13 +53,26 @@ __global__ void pack_bf16x3_kernel(const PackArgs a) {
 // forward (output 128 wide): same contract as mlp_fwd_kernel.  NS = 2: 128-row workgroup tiles, 2 waves / SIMD -- half the
 // weight DMA, LDS operand reads and barriers per row (0.635 -> 0.554 ms for 594 048 edge rows in tools/micro/bf16x6_mlp.hip).
 // ----------------------------------------------------------------------------------------------------------
-template <int NS, int NP>
-__global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
-  __shared__ int seg_ids_lds[NS][SEG_PRE_INTS];     // see SegPre
+// NWV = 12 ("big": one 12-wave workgroup per CU on a 192-row tile instead of three 4-wave workgroups on 64 rows each): the three
+// groups share ONE weight stage, which can then hold a whole 96 KB block -- a third of the L2 -> LDS traffic, one DMA wait and
+// two barriers per block instead of two and four (gemm6_big).  Same per-row arithmetic, bit for bit.
+template <int NS, int NP, int NWV = WG / 64>
+__global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
+  constexpr bool BIG = NWV != WG / 64;
+  constexpr int GROUPS = BIG ? NWV / 4 : NS;          // 64-row sub-tiles of the workgroup's tile
+  static_assert(!BIG || (NS == 1 && NWV % 4 == 0), "big workgroups: one 16-row sub-tile per wave, whole 64-row groups");
+  constexpr int LDS_BF16 = BIG ? (BLOCK_BF16 > GROUPS * SEG_LDS_FLOATS * 2 ? BLOCK_BF16 : GROUPS * SEG_LDS_FLOATS * 2) : HALF_BF16;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_BF16];
+  __shared__ int seg_ids_lds[GROUPS][SEG_PRE_INTS];   // see SegPre
   static_assert(HALF_BF16 * 2 >= SEG_LDS_FLOATS * 4, "the weight stage doubles as the segment-sum tile");
   const int kq = (threadIdx.x & 63) >> 4;
-  const Rows<NS> R(a.M);
+  const Rows<NS, NWV> R(a.M);
+  const int grp = BIG ? (int)(threadIdx.x >> 8) : 0, ltid = BIG ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
+  auto block = [&](Act (&acc_)[NS], Act (&b_)[NS], const __bf16* pk_, auto&& between_, auto&& post_) {
+    if constexpr (BIG) gemm6_big<NS, NP, NWV>(acc_, b_, lds, pk_, between_, post_);
+    else gemm6<NS, NP>(acc_, b_, lds, pk_, between_, post_);
+  };
+  auto nothing = [](Act (&)[NS]) {};
   HGN_STAMP();                                      // kernel entered
   // Every INDEX the kernel gathers through is loaded here, ahead of everything: the dependent row loads below then cost one
   // memory round trip instead of two (measured on 1.19 M edge rows: the first block's loads took 12.6 of the workgroup's 75 us
@@ -71,8 +84,11 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
     for (int i = 0; i < HGN_MAX_ADD; ++i) add_row[u][i] = i < a.n_add ? a.add[i].idx[R.rc[u]] : 0;
   SegPre seg_pre[NS];
   if (a.seg_out) {
+    if constexpr (BIG) seg_pre[0].load(a.seg_ids, R.tile_row0 + grp * TILE_ROWS, a.M, ltid);
+    else {
 #pragma unroll
-    for (int u = 0; u < NS; ++u) seg_pre[u].load(a.seg_ids, R.tile_row0 + u * TILE_ROWS, a.M);
+      for (int u = 0; u < NS; ++u) seg_pre[u].load(a.seg_ids, R.tile_row0 + u * TILE_ROWS, a.M);
+    }
   }
 
   Act acc[NS], b[NS];
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
     const bool vec = ((s.ld & 3) == 0) && ((s.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
     for (int k0 = 0; k0 < s.K; k0 += 128) {
       const int kw = min(128, s.K - k0);
-      gemm6<NS, NP>(acc, b, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
+      block(acc, b, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
           const long srow = s.idx ? (long)s.idx[R.rc[u]] : R.rc[u];
@@ -102,11 +118,11 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
               HGN_FOR_B(fb) acc[u].v[fb] = *reinterpret_cast<const f32x4*>(a.b1 + 16 * fb + 4 * kq) + acc[u].v[fb];
               if (a.n_add > 1) HGN_FOR_B(fb) acc[u].v[fb] += p1.v[fb];
             }
-            if (a.seg_out) seg_pre[u].stash(seg_ids_lds[u]);
+            if (a.seg_out) { if constexpr (BIG) seg_pre[0].stash(seg_ids_lds[grp], ltid); else seg_pre[u].stash(seg_ids_lds[u]); }
           }
         }
         first = false;
-      });
+      }, nothing);
     }
   }
 #pragma unroll
@@ -115,17 +131,17 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
     if (!(HGN_ABL & 4) && a.z1 && R.valid[u]) t_store(acc[u], a.z1 + R.row[u] * LAT, kq);
     if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + kq] = relu_bits_of(acc[u]);
   }
-  gemm6<NS, NP>(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
+  block(b, acc, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) t_load(b[u], a.b2, kq);
-  });
+  }, nothing);
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     relu6(b[u]);
     if (!(HGN_ABL & 4) && a.z2 && R.valid[u]) t_store(b[u], a.z2 + R.row[u] * LAT, kq);
     if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + 4 + kq] = relu_bits_of(b[u]);
   }
-  gemm6<NS, NP>(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
+  block(acc, b, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) t_load(acc[u], a.b3, kq);
   }, [&](Act (&free_b)[NS]) {                       // the residual rows arrive while the last block multiplies
@@ -155,11 +171,16 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_fwd_kernel(const hgn
   }
   HGN_STAMP();                                      // epilogue stores issued
   if (a.seg_out) {                                  // (waits for none of the stores above: see SegPre)
+    if constexpr (BIG) {                              // every 4-wave group walks its own 64-row sub-tile, side by side
+      tile_segment_sum(acc[0], reinterpret_cast<float*>(lds) + grp * SEG_LDS_FLOATS, a.seg_ids, a.seg_out, a.ld_seg_out,
+                       R.tile_row0 + grp * TILE_ROWS, a.M, seg_ids_lds[grp], ltid);
+    } else {
 #pragma unroll
-    for (int u = 0; u < NS; ++u)
-      if (R.tile_row0 + u * TILE_ROWS < a.M)          // uniform over the workgroup
-        tile_segment_sum(acc[u], reinterpret_cast<float*>(lds), a.seg_ids, a.seg_out, a.ld_seg_out, R.tile_row0 + u * TILE_ROWS, a.M,
-                         seg_ids_lds[u]);
+      for (int u = 0; u < NS; ++u)
+        if (R.tile_row0 + u * TILE_ROWS < a.M)          // uniform over the workgroup
+          tile_segment_sum(acc[u], reinterpret_cast<float*>(lds), a.seg_ids, a.seg_out, a.ld_seg_out, R.tile_row0 + u * TILE_ROWS, a.M,
+                           seg_ids_lds[u]);
+    }
   }
   HGN_STAMP();                                      // segment sums done
 }
@@ -207,12 +228,15 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
   unsigned mb1[NS], mb2[NS];
 #pragma unroll
   for (int u = 0; u < NS; ++u) { mb1[u] = a.relu_bits[R.rc[u] * 8 + kq]; mb2[u] = a.relu_bits[R.rc[u] * 8 + 4 + kq]; }
+  int pre_seg[NS];                                  // receiver of the row (aggregation backward): loaded with the sign words
+#pragma unroll
+  for (int u = 0; u < NS; ++u) pre_seg[u] = a.agg_dout ? a.agg_seg[R.rc[u]] : -1;
   // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
   gemm6<NS, NP>(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       Act& xh = t[u];
-      if (HGN_ABL & 8) t_zero(g[u]); else load_dout<false>(g[u], a, R.rc[u], kq);
+      if (HGN_ABL & 8) t_zero(g[u]); else load_dout<false>(g[u], a, R.rc[u], kq, pre_seg[u]);
       if (PARK && R.valid[u]) t_store(g[u], park + R.row[u] * park_ld, kq);
       if (HGN_ABL & 8) t_zero(xh); else t_load(xh, a.xhat + R.rc[u] * LAT, kq);
       HGN_FOR_B(fb) {                               // LayerNorm-affine gradient partials of this wave's rows
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
 #pragma unroll
       for (int u = 0; u < NS; ++u)
         if (R.valid[u]) {
-          if (d.residual) { if (PARK) t_add(t[u], park + R.row[u] * park_ld, kq); else load_dout<true>(t[u], a, R.rc[u], kq); }
+          if (d.residual) { if (PARK) t_add(t[u], park + R.row[u] * park_ld, kq); else load_dout<true>(t[u], a, R.rc[u], kq, pre_seg[u]); }
           t_store(t[u], d.dx + R.row[u] * d.ld + k0, kq);
         }
     }
@@ -355,7 +379,25 @@ static bool tile128() { static const bool v = getenv("HGN_TILE128") != nullptr; 
 // diagnostic: extra dynamic LDS per workgroup, to see the kernels at 2 or 1 workgroups per CU (HGN_DIAG_LDS_PAD=bytes)
 static unsigned lds_pad() { static const unsigned v = getenv("HGN_DIAG_LDS_PAD") ? (unsigned)atoi(getenv("HGN_DIAG_LDS_PAD")) : 0u; return v; }
 
+// 12-wave workgroups on 192-row tiles (mlp6_fwd_kernel<1, NP, 12>; HGN_BIG_TILES=1 or hgn_set_big_tiles(1)), for launches of at
+// least big_min_rows() rows.  Diagnostic, like HGN_TILE128: a third of the weight DMA, half the barriers and DMA waits per block,
+// bit-identical results -- and the same time (edge forward 1.241 vs 1.231 ms at 1.19 M rows, profiles/r02_edge_kernel_ablation.log).
+static int g_big_tiles = getenv("HGN_BIG_TILES") ? 1 : 0;
+static long big_min_rows() {             // below 2 tiles per CU a 192-row grid leaves CUs idle (HGN_BIG_MIN_ROWS overrides: tests)
+  static const long v = getenv("HGN_BIG_MIN_ROWS") ? atol(getenv("HGN_BIG_MIN_ROWS")) : 192L * 256 * 2;
+  return v;
+}
+}  // namespace hgn
+extern "C" int hgn_set_big_tiles(int on) { hgn::g_big_tiles = on ? 1 : 0; return HGN_OK; }
+namespace hgn {
+
 int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
+  if (g_big_tiles && !tile128() && a->M >= big_min_rows()) {
+    const long tiles = (a->M + 191) / 192;
+    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
+    return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
+  }
   if (tile128() && matmul_products() == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
     hipLaunchKernelGGL((mlp6_fwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);

@@ -6,6 +6,7 @@
 
 // Diagnostic builds only (tools/build_ablations.sh): compile-time ablation mask of the split-bf16 edge kernels.
 //   1 no weight DMA   2 no MFMA   4 no stores of saved activations / intermediate gradients   8 no row loads
+//  32 (experiment, not an ablation) raised wave priority around the product sweeps
 //  16 time stamps (s_memrealtime, 10 ns) of one mid-launch workgroup's wave 0 through the forward kernel (tools/fwdstamps.py)
 #ifndef HGN_ABL
 #define HGN_ABL 0
@@ -17,7 +18,10 @@ static __device__ int g_hgn_stamp_n;
 }
 #define HGN_STAMP()                                                                      \
   do {                                                                                   \
-    if (blockIdx.x == 9000 && threadIdx.x == 0 && g_hgn_stamp_n < 256) g_hgn_stamps[g_hgn_stamp_n++] = wall_clock64(); \
+    if (blockIdx.x == 5000 && threadIdx.x == 0 && g_hgn_stamp_n < 120) {                 \
+      g_hgn_stamps[128 + g_hgn_stamp_n] = clock64();      /* shader cycles: with the 100 MHz stamps, the in-kernel clock */ \
+      g_hgn_stamps[g_hgn_stamp_n++] = wall_clock64();                                    \
+    }                                                                                    \
   } while (0)
 #else
 #define HGN_STAMP() do {} while (0)
@@ -58,6 +62,21 @@ __device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf
   for (unsigned i = wave; i < (NP == 1 ? HALF_TILES / 3 : HALF_TILES); i += WG / 64)          // one operand tile (1 KiB) per wave instruction
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
                                      (__attribute__((address_space(3))) void*)(lds + i * TILE_BF16), 16, 0, 0);
+}
+
+// Whole packed block (both halves: 96 KB, contiguous in memory and in LDS) by a workgroup of NWV waves
+template <int NP, int NWV>
+__device__ __forceinline__ void stage_block6(__bf16* __restrict__ lds, const __bf16* __restrict__ gsrc) {
+  unsigned lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  const unsigned wave = threadIdx.x >> 6;
+  constexpr unsigned PER_HALF = NP == 1 ? HALF_TILES / 3 : HALF_TILES;
+#pragma unroll
+  for (unsigned h = 0; h < 2; ++h)
+#pragma unroll
+    for (unsigned i = wave; i < PER_HALF; i += NWV)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (h * HALF_TILES + i) * TILE_BF16 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(lds + (h * HALF_TILES + i) * TILE_BF16), 16, 0, 0);
 }
 
 // A wave owns NS sub-tiles of 16 rows; every operand fragment read from LDS is multiplied with all of them.
@@ -112,20 +131,48 @@ __device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __re
   for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
   post_split(b);
   HGN_STAMP();                                    // 4: split
+  if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(2);
   if (!(HGN_ABL & 2)) mfma_half6<0, NS, NP>(acc, xs, lds);
+  if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(0);
   HGN_STAMP();                                    // 5: products of half 0 issued
   wg_barrier_lds();
   HGN_STAMP();                                    // 6: every wave done with half 0
   if (!(HGN_ABL & 1)) stage_half6<NP>(lds, pk + HALF_BF16);
   __syncthreads();
   HGN_STAMP();                                    // 7: half 1 landed
+  if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(2);
   if (!(HGN_ABL & 2)) mfma_half6<1, NS, NP>(acc, xs, lds);
+  if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(0);
   HGN_STAMP();                                    // 8: products of half 1 issued
 }
 template <int NS, int NP, class F>
 __device__ __forceinline__ void gemm6(Act (&acc)[NS], const Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
                                       F&& between) {
   gemm6<NS, NP>(acc, const_cast<Act (&)[NS]>(b), lds, pk, between, [](Act (&)[NS]) {});
+}
+
+// The same block for a BIG workgroup (NWV waves, one per CU) that can afford a 96 KB stage: both halves are fetched at once, so
+// a block costs one DMA wait and two barriers instead of two and four, and the weights are fetched once per 16 NWV rows.
+template <int NS, int NP, int NWV, class F, class G>
+__device__ __forceinline__ void gemm6_big(Act (&acc)[NS], Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
+                                          F&& between, G&& post_split) {
+  bf16x8 xs[NS][3][4];
+  wg_barrier_lds();
+  if (!(HGN_ABL & 1)) stage_block6<NP, NWV>(lds, pk);
+  between();
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
+  post_split(b);
+  if (!(HGN_ABL & 2)) mfma_half6<0, NS, NP>(acc, xs, lds);
+  __builtin_amdgcn_sched_barrier(0);              // (no fragment of the second half in registers before the first is done)
+  {
+    // (an address register of its own for the upper half: DS immediates reach 64 KB, the stage is 96 KB)
+    unsigned up = HALF_BF16 * 2;
+    asm volatile("" : "+v"(up));
+    const __bf16* lds1 = reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(lds) + up);
+    if (!(HGN_ABL & 2)) mfma_half6<1, NS, NP>(acc, xs, lds1);
+  }
 }
 
 __device__ __forceinline__ void relu6(Act& a) {
@@ -136,15 +183,16 @@ __device__ __forceinline__ void relu6(Act& a) {
 
 // Rows of a workgroup: NS sub-tiles of 64 consecutive rows, sub-tile u of wave w = rows 64u + 16w .. +15 of the tile (each
 // sub-tile is a contiguous 64-row block, which the in-kernel segment sums rely on).
-template <int NS>
+template <int NS, int NWV = WG / 64>
 struct Rows {
   long row[NS], rc[NS]; bool valid[NS]; long tile_row0;
   __device__ __forceinline__ Rows(long M) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    tile_row0 = xcd_tile() * (TILE_ROWS * NS);
+    constexpr int SUB = WAVE_ROWS * NWV;               // rows of one sub-tile (64 for the 4-wave workgroups)
+    tile_row0 = xcd_tile() * (SUB * NS);
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      row[u] = tile_row0 + u * TILE_ROWS + wave * WAVE_ROWS + (lane & 15);
+      row[u] = tile_row0 + u * SUB + wave * WAVE_ROWS + (lane & 15);
       valid[u] = row[u] < M;
       rc[u] = valid[u] ? row[u] : M - 1;
     }

@@ -43,31 +43,35 @@ constexpr int SEG_LDS_FLOATS = 64 * 132 + 64 + 128;
 constexpr int SEG_PRE_INTS = TILE_ROWS + 2;
 struct SegPre {
   int id, prev, next;
-  __device__ __forceinline__ void load(const int32_t* __restrict__ seg_ids, long tile_row0, long M) {
-    const long r = tile_row0 + threadIdx.x;
-    id = (threadIdx.x < TILE_ROWS && r < M) ? seg_ids[r] : -1;
-    prev = tile_row0 > 0 ? seg_ids[tile_row0 - 1] : -1;
+  __device__ __forceinline__ void load(const int32_t* __restrict__ seg_ids, long tile_row0, long M, int ltid = -1) {
+    if (ltid < 0) ltid = threadIdx.x;
+    const long r = tile_row0 + ltid;
+    id = (ltid < TILE_ROWS && r < M) ? seg_ids[r] : -1;
+    prev = (tile_row0 > 0 && tile_row0 <= M) ? seg_ids[tile_row0 - 1] : -1;
     const long e = min(tile_row0 + TILE_ROWS, M);
     next = e < M ? seg_ids[e] : -1;
   }
-  __device__ __forceinline__ void stash(int* __restrict__ lds_ids) const {      // visible after the caller's next workgroup barrier
-    if (threadIdx.x < TILE_ROWS) lds_ids[threadIdx.x] = id;
-    if (threadIdx.x == 0) { lds_ids[TILE_ROWS] = prev; lds_ids[TILE_ROWS + 1] = next; }
+  __device__ __forceinline__ void stash(int* __restrict__ lds_ids, int ltid = -1) const {      // visible after the caller's next workgroup barrier
+    if (ltid < 0) ltid = threadIdx.x;
+    if (ltid < TILE_ROWS) lds_ids[ltid] = id;
+    if (ltid == 0) { lds_ids[TILE_ROWS] = prev; lds_ids[TILE_ROWS + 1] = next; }
   }
 };
 // The column walk of tile_segment_sum: the 64 x 128 tile is in `ldsf` (row stride 132 floats), the ids in `ids`, and a workgroup
 // barrier lies between those writes and this call.  Threads 0..255 walk (thread = (half, column)); EVERY thread of the workgroup
 // must call (one barrier inside; `lds_only`: the barrier does not wait for the caller's global stores).
+// `ltid`: the thread's index among the (at least 256) threads that share THIS tile -- threadIdx.x, or the index inside a 256-thread
+// group when several groups of one workgroup walk a tile each (every group on its own `ldsf` / `ids`; the barrier is the workgroup's).
 __device__ __forceinline__ void tile_segment_walk(float* __restrict__ ldsf, const int* __restrict__ ids, int prev_id, int next_id,
-                                                  float* __restrict__ out, long ld, long tile_row0, long M, bool lds_only) {
+                                                  float* __restrict__ out, long ld, long tile_row0, long M, bool lds_only, int ltid) {
   float* hp = ldsf + 64 * 132 + 64;
-  const int rows = (int)min((long)TILE_ROWS, M - tile_row0);
-  const bool walker = threadIdx.x < 256;
-  const int half = (threadIdx.x >> 7) & 1, c = threadIdx.x & 127;
+  const int rows = (int)max(0L, min((long)TILE_ROWS, M - tile_row0));
+  const bool walker = ltid < 256;
+  const int half = (ltid >> 7) & 1, c = ltid & 127;
   const int r0 = 32 * half, r1 = min(rows, r0 + 32);
   const bool active = walker && r0 < rows;
-  const bool tile_cont_prev = tile_row0 > 0 && prev_id == ids[0];
-  const bool tile_cont_next = tile_row0 + rows < M && next_id == ids[rows - 1];
+  const bool tile_cont_prev = rows > 0 && tile_row0 > 0 && prev_id == ids[0];
+  const bool tile_cont_next = rows > 0 && tile_row0 + rows < M && next_id == ids[rows - 1];
   int cur = -1;
   float s = 0.f;
   bool first = true;                                        // still inside the segment my range began with
@@ -115,28 +119,36 @@ __device__ __forceinline__ void tile_segment_walk(float* __restrict__ ldsf, cons
 
 __device__ __forceinline__ void tile_segment_sum(const Act& v, float* __restrict__ ldsf, const int32_t* __restrict__ seg_ids,
                                                  float* __restrict__ out, long ld, long tile_row0, long M,
-                                                 const int* __restrict__ pre_ids = nullptr) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                 const int* __restrict__ pre_ids = nullptr, int ltid = -1) {
+  if (ltid < 0) ltid = threadIdx.x;
+  const int lane = ltid & 63, wave = ltid >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const int* ids = pre_ids ? pre_ids : reinterpret_cast<const int*>(ldsf + 64 * 132);
   if (pre_ids) wg_barrier_lds(); else __syncthreads();      // every wave is done with the weight stage
   float* wr = ldsf + (wave * WAVE_ROWS + n) * 132 + 4 * kq;
   HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(wr + 16 * fb) = v.v[fb];
   const int rows = (int)min((long)TILE_ROWS, M - tile_row0);
-  if (!pre_ids && threadIdx.x < 64)
-    reinterpret_cast<int*>(ldsf + 64 * 132)[threadIdx.x] = threadIdx.x < rows ? seg_ids[tile_row0 + threadIdx.x] : -1;
+  if (!pre_ids && ltid < 64)
+    reinterpret_cast<int*>(ldsf + 64 * 132)[ltid] = ltid < rows ? seg_ids[tile_row0 + ltid] : -1;
   if (pre_ids) wg_barrier_lds(); else __syncthreads();
   const int prev_id = tile_row0 > 0 ? (pre_ids ? pre_ids[TILE_ROWS] : seg_ids[tile_row0 - 1]) : -1;
   const int next_id = tile_row0 + rows < M ? (pre_ids ? pre_ids[TILE_ROWS + 1] : seg_ids[tile_row0 + rows]) : -1;
-  tile_segment_walk(ldsf, ids, prev_id, next_id, out, ld, tile_row0, M, pre_ids != nullptr);
+  tile_segment_walk(ldsf, ids, prev_id, next_id, out, ld, tile_row0, M, pre_ids != nullptr, ltid);
 }
 
 // Aggregation backward of the lane's row added to g: sum_slot d(op_slot)(agg_dout[seg[row]][slot * 128 ...]) (graphnet.py:50-70).
-__device__ __forceinline__ void add_agg_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {
+// `pre_seg`: a.agg_seg[rc] loaded by the caller ahead of time (kernel entry), or -1: the dependent row loads below then cost one
+// memory round trip, not two.  The segment length is only read when a `mean` slot needs it.
+__device__ __forceinline__ void add_agg_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq, int pre_seg = -1) {
   if (a.agg_dout) {
-    const long r = a.agg_seg[rc];
-    const int cnt = a.agg_rowptr[r + 1] - a.agg_rowptr[r];
-    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    const long r = pre_seg >= 0 ? (long)pre_seg : (long)a.agg_seg[rc];
+    bool has_mean = false;
+    for (int slot = 0; slot < a.n_agg_ops; ++slot) has_mean = has_mean || a.agg_ops[slot] == HGN_OP_MEAN;
+    float inv = 0.f;
+    if (has_mean) {
+      const int cnt = a.agg_rowptr[r + 1] - a.agg_rowptr[r];
+      inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    }
     for (int slot = 0; slot < a.n_agg_ops; ++slot) {
       const float* ar = a.agg_dout + r * a.ld_agg + slot * LAT;
       const int op = a.agg_ops[slot];
@@ -157,7 +169,7 @@ __device__ __forceinline__ void add_agg_dout(Act& g, const hgn_mlp_bwd_t& a, lon
 
 // d_out_eff of the lane's row: d_out (optional) + the aggregation backward scattered back through the CSR row of the edge.
 template <bool ACC>
-__device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq) {
+__device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long rc, int kq, int pre_seg = -1) {
   // ACC: add d_out_eff to g (residual path; 128-wide, aligned);  otherwise g = d_out_eff
   if (ACC) {
     if (a.d_out) t_add(g, a.d_out + rc * a.ld_dout, kq);
@@ -167,7 +179,7 @@ __device__ __forceinline__ void load_dout(Act& g, const hgn_mlp_bwd_t& a, long r
   } else {
     t_zero(g);
   }
-  add_agg_dout(g, a, rc, kq);
+  add_agg_dout(g, a, rc, kq, pre_seg);
 }
 
 }  // namespace hgn

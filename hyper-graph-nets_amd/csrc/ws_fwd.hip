@@ -342,7 +342,7 @@ __global__ __launch_bounds__(WS_T, 2) void ws_fwd_kernel(const hgn_mlp_fwd_t a, 
     }
     if (a.seg_out) {
       wg_barrier_lds();                                      // B6: the e' tile and its ids are in LDS
-      tile_segment_walk(segf, seg_ids_lds, seg_ids_lds[TILE_ROWS], seg_ids_lds[TILE_ROWS + 1], a.seg_out, a.ld_seg_out, row0, M, true);
+      tile_segment_walk(segf, seg_ids_lds, seg_ids_lds[TILE_ROWS], seg_ids_lds[TILE_ROWS + 1], a.seg_out, a.ld_seg_out, row0, M, true, tid);
     }
     // (the next tile writes image 0 only after B4, which every wave passes behind its last read of it; the segment tile after
     //  the next tile's B1..B5; the ids are double-buffered)

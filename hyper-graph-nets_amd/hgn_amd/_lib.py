@@ -95,6 +95,7 @@ _SIGS = {
     'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
     'hgn_mlp_fwd_ws_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
     'hgn_set_ws_fwd': (C.c_int, [C.c_int]),
+    'hgn_set_big_tiles': (C.c_int, [C.c_int]),
     'hgn_linear_fwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
     'hgn_mlp_bwd6_eligible': (C.c_int, [C.POINTER(MlpBwd)]),

@@ -300,14 +300,14 @@ torch.save([t.detach().cpu() for t in [y, agg, hn, h.grad, e.grad] + [p.grad for
 
 def test_kernel_variants_behind_environment_switches(tmp_path):
     """The diagnostic kernel variants kept in the library (HGN_TILE128: two sub-tiles per wave; HGN_WGRAD_RESPLIT: the previous
-    weight-gradient kernel) compute the same function as the defaults: one child process per setting (the switches are read
+    weight-gradient kernel; HGN_BIG_TILES: 12-wave workgroups on 192-row tiles) compute the same function as the defaults: one child process per setting (the switches are read
     once per process), edge block + node MLP forward / backward compared with the default build of the same inputs."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, 'hyper-graph-nets_amd')
     outs = {}
-    for name, env in (('default', {}), ('tile128', {'HGN_TILE128': '1'}), ('resplit', {'HGN_WGRAD_RESPLIT': '1'})):
+    for name, env in (('default', {}), ('tile128', {'HGN_TILE128': '1'}), ('resplit', {'HGN_WGRAD_RESPLIT': '1'}), ('big', {'HGN_BIG_TILES': '1', 'HGN_BIG_MIN_ROWS': '1'})):
         out = str(tmp_path / (name + '.pt'))
         code = _VARIANT_SNIPPET.format(root=root, pkg=pkg, out=out)
         r = subprocess.run([sys.executable, '-c', code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
@@ -319,6 +319,8 @@ def test_kernel_variants_behind_environment_switches(tmp_path):
         assert torch.equal(a, b)                               # same arithmetic per row, only the tiling differs
     for a, b in zip(outs['default'], outs['resplit']):
         assert H.rel_err(a, b) <= 1e-6
+    for a, b in zip(outs['default'], outs['big']):         # 12-wave workgroups on 192-row tiles (forward): the same bits
+        assert torch.equal(a, b)
 
 
 # ---------------------------------------------------------------------------------------------------------------
