@@ -7,6 +7,7 @@
 // Diagnostic builds only (tools/build_ablations.sh): compile-time ablation mask of the split-bf16 edge kernels.
 //   1 no weight DMA   2 no MFMA   4 no stores of saved activations / intermediate gradients   8 no row loads
 //  32 (experiment, not an ablation) raised wave priority around the product sweeps
+//  64 (experiment) operand fragments read one output block ahead of the products (mfma_half6_pipe)
 //  16 time stamps (s_memrealtime, 10 ns) of one mid-launch workgroup's wave 0 through the forward kernel (tools/fwdstamps.py)
 #ifndef HGN_ABL
 #define HGN_ABL 0
@@ -111,6 +112,47 @@ __device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS
   }
 }
 
+// The same sweep for one sub-tile with the fragments of output block i + 1 read while block i multiplies (scheduling barriers keep
+// the reads where they are written).  Experiment (HGN_ABL & 64), see DESIGN.md section 5.8.
+template <int HALF, int NP>
+__device__ __forceinline__ void mfma_half6_pipe(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+  const __bf16* lp = lds + lane * 8;
+  constexpr int NSP = NP == 1 ? 1 : 3;
+  bf16x8 fr[2][3];
+#pragma unroll
+  for (int s = 0; s < NSP; ++s) fr[0][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + 0) * 8 + 0) * TILE_BF16);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                   // i = 8 * cl + ob
+    const int cl = i >> 3, ob = i & 7, c = 2 * HALF + cl;
+    if (i + 1 < 16) {
+      const int cl1 = (i + 1) >> 3, ob1 = (i + 1) & 7;
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) fr[(i + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + cl1) * 8 + ob1) * TILE_BF16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 (&a)[3] = fr[i & 1];              // a[0] hi, a[1] mid, a[2] lo
+    f32x4 t = acc.v[ob];
+    if (NP == 1) {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][c], t, 0, 0, 0);
+    } else {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[0][c], t, 0, 0, 0);      // smallest terms first
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[2][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[1][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[0][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[1][c], t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][c], t, 0, 0, 0);
+    }
+    acc.v[ob] = t;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int HALF, int NS, int NP>
+__device__ __forceinline__ void mfma_half6_sel(Act (&acc)[NS], const bf16x8 (&xs)[NS][3][4], const __bf16* __restrict__ lds) {
+  if constexpr (NS == 1 && (HGN_ABL & 64) != 0) mfma_half6_pipe<HALF, NP>(acc[0], xs[0], lds);
+  else mfma_half6<HALF, NS, NP>(acc, xs, lds);
+}
+
 // acc[u][ob] += Wblock * b[u] for one packed 128 x 128 block.  `between()` runs after the first half's DMA has been issued and
 // before the wait (the caller's own global loads fly with it); `b` is split after the wait, so `between` may load it.
 // `post_split(b)` runs once `b` has been split into the bf16 operands: its registers are free from there to the end of the block,
@@ -132,7 +174,7 @@ __device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __re
   post_split(b);
   HGN_STAMP();                                    // 4: split
   if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(2);
-  if (!(HGN_ABL & 2)) mfma_half6<0, NS, NP>(acc, xs, lds);
+  if (!(HGN_ABL & 2)) mfma_half6_sel<0, NS, NP>(acc, xs, lds);
   if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(0);
   HGN_STAMP();                                    // 5: products of half 0 issued
   wg_barrier_lds();
@@ -141,7 +183,7 @@ __device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __re
   __syncthreads();
   HGN_STAMP();                                    // 7: half 1 landed
   if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(2);
-  if (!(HGN_ABL & 2)) mfma_half6<1, NS, NP>(acc, xs, lds);
+  if (!(HGN_ABL & 2)) mfma_half6_sel<1, NS, NP>(acc, xs, lds);
   if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(0);
   HGN_STAMP();                                    // 8: products of half 1 issued
 }

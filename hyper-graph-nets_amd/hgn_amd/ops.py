@@ -22,8 +22,9 @@ _GATE_LOG = None              # tests only: when a list, every training forward 
 _WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
 # edge blocks: data gradients and weight gradients in one pass (hgn_edge_bwd_fused).  Opt-in (HGN_FUSED_BWD=1 or
 # set_fused_edge_backward(True)): it moves 2.5 KB per edge and layer less than the two launches it replaces, but with one
-# persistent 8-wave workgroup per CU its load / DMA latencies are exposed -- measured 2.58 ms against 1.29 + 0.73 ms at 1.19 M rows
-# (DESIGN.md section 5.6), so the two-launch path stays the default.
+# persistent 8-wave workgroup per CU its load / DMA latencies are exposed -- measured 1.64 + 0.27 + 0.14 ms (kernel, dW1e task,
+# receiver sums) against 1.37 + 0.78 ms at 1.19 M rows, the whole step equal: the two-launch path stays
+# the default.
 _FUSED_EDGE_BWD = bool(__import__('os').environ.get('HGN_FUSED_BWD'))
 
 
@@ -36,7 +37,7 @@ def set_fused_edge_backward(on: bool) -> None:
 def set_ws_edge_forward(on: bool) -> None:
     """True: eligible edge-block forwards run the weight-stationary kernel (csrc/ws_fwd.hip: the three layers' weights in registers,
     activations through LDS, no weight traffic per tile); False (default): the staged-weights kernel.  Opt-in (or HGN_WS_FWD=1):
-    measured 1.43 ms against 1.29 ms at 1.19 M rows (DESIGN.md section 5.8)."""
+    measured 1.43 ms against 1.29 ms at 1.19 M rows (DESIGN.md section 5.9)."""
     _lib.check(_lib.lib().hgn_set_ws_fwd(1 if on else 0), 'hgn_set_ws_fwd')
 
 
