@@ -150,6 +150,7 @@ __global__ __launch_bounds__(WS_T, 2) void ws_fwd_kernel(const hgn_mlp_fwd_t a, 
   // Global rows are addressed as UNIFORM base + 32-bit byte offset (eligibility bounds every array to 4 GiB): one register per
   // address instead of a 64-bit pointer per array and row.
   auto ld4 = [](const float* base, unsigned off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off); };
+  auto ld4w = [](const float* base, size_t off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off); };      // (gathered rows: the node arrays' size is not known here)
   auto st4 = [](float* base, unsigned off, const f32x4& v) { *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + off) = v; };
   const unsigned lde4 = (unsigned)a.src[0].ld * 4u, ldo4 = (unsigned)a.ld_out * 4u, ldr4 = (unsigned)a.ld_res * 4u;
   const unsigned ldp0 = (unsigned)a.add[0].ld * 4u, ldp1 = (unsigned)a.add[1].ld * 4u;
@@ -207,8 +208,8 @@ __global__ __launch_bounds__(WS_T, 2) void ws_fwd_kernel(const hgn_mlp_fwd_t a, 
     auto gather = [&](int h) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        if (a.n_add > 0) pg[r] = ld4(a.add[0].P, (unsigned)gid[16 * (2 * h + r) + n] * ldp0 + ucol4);
-        if (a.n_add > 1) ph[r] = ld4(a.add[1].P, (unsigned)gid[TILE_ROWS + 16 * (2 * h + r) + n] * ldp1 + ucol4);
+        if (a.n_add > 0) pg[r] = ld4w(a.add[0].P, (size_t)(unsigned)gid[16 * (2 * h + r) + n] * ldp0 + ucol4);
+        if (a.n_add > 1) ph[r] = ld4w(a.add[1].P, (size_t)(unsigned)gid[TILE_ROWS + 16 * (2 * h + r) + n] * ldp1 + ucol4);
       }
     };
     gather(0);
