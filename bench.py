@@ -394,18 +394,21 @@ def main():
             #   edge backward: read d(e') + x-hat (2 x 512), sign words 32, rstd 4, write dz3 + dz2 + dz1 + de (4 x 512);
             #                  d(agg) rows (N x 512) gathered, receiver sums of dz1 (N x 512) written
             #   weight grads : two operand rows (2 x 512) per task and row
-            #   fused backward (opt-in): read d(e') + x-hat + z2 + z1 + e (5 x 512), sign words, rstd, write dz1 + de (2 x 512)
+            #   fused backward (default where eligible): read d(e') + x-hat + z2 + z1 (4 x 512), sign words, rstd, write dz1 + de
+            #                  (2 x 512); d(agg) rows (N x 512) gathered.  It does the work of the edge backward AND of the dW3 / dW2
+            #                  weight-gradient tasks (2 x 1024 per row more in the two-launch path): `replaces_bytes_per_launch`
             algo = {'mlp_fwd_edge': (5 * 512 + 36, 1536 * N_nodes), 'mlp_bwd_edge': (6 * 512 + 36, 1024 * N_nodes),
-                    'wgrad': (1024, 0), 'wgrad_node': (1024, 0), 'edge_bwd_fused': (7 * 512 + 36, 512 * N_nodes)}
+                    'wgrad': (1024, 0), 'wgrad_node': (1024, 0), 'edge_bwd_fused': (6 * 512 + 36, 512 * N_nodes)}
             # bytes the arithmetic NEEDS: without the dz3 / dz2 / dz1 hand-off to the weight-gradient launch
-            necessary = {'mlp_bwd_edge': (3 * 512 + 36, 1024 * N_nodes)}
+            necessary = {'mlp_bwd_edge': (3 * 512 + 36, 1024 * N_nodes), 'edge_bwd_fused': (5 * 512 + 36, 512 * N_nodes)}
+            replaces = {'edge_bwd_fused': (6 * 512 + 36 + 2 * 1024, 1024 * N_nodes)}      # hgn_mlp_bwd + the dW3 / dW2 tasks of hgn_mlp_wgrad
             cand = {n: v for n, v in k.items() if n in algo and (n in fwd_only or not overlapped)}
             name, v = max(cand.items(), key=lambda kv: kv[1]['ms'])
             t_launch = v['ms'] / v['count'] * 1e-3
             rows = v['units'] / v['count']
             bytes_launch = algo[name][0] * rows + algo[name][1]
             ach = bytes_launch / t_launch / 1e9
-            per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1, 'edge_bwd_fused': 6}[name] * 2 * 128 * 128
+            per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1, 'edge_bwd_fused': 5}[name] * 2 * 128 * 128
             tf = per_row * rows / t_launch / 1e12
             fp32_only = bool(os.environ.get('HGN_FP32_MFMA'))
             traffic, traffic_note = None, None
@@ -436,9 +439,14 @@ def main():
                                                'products': 'fp32 MFMA' if fp32_only else
                                                'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate'},
                                'selection': 'largest accumulated time' + (' among forward kernels (side stream on)' if overlapped else '')}
+            if name in replaces:      # one launch doing the work of several: the bytes THOSE would move, over this kernel's time
+                rb = replaces[name][0] * rows + replaces[name][1]
+                res['roofline']['replaces_bytes_per_launch'] = rb
+                res['roofline']['frac_vs_replaced_launches'] = rb / t_launch / 1e9 / PEAK_HBM_GBS
+                res['roofline']['replaces'] = 'hgn_mlp_bwd (edge) + the dW3 / dW2 tasks of hgn_mlp_wgrad: their algorithmic bytes'
             # whole-step matrix utilisation: algorithmic flops of every MFMA launch of the step / step time
-            step_flops = sum(v2['units'] / psteps * ({'wgrad': 1, 'wgrad_node': 1, 'linear_fwd': 2, 'linear_bwd': 2}.get(n2, 3)) * 2 * 128 * 128
-                             for n2, v2 in k.items() if n2.startswith(('mlp', 'wgrad', 'linear')))
+            step_flops = sum(v2['units'] / psteps * ({'wgrad': 1, 'wgrad_node': 1, 'linear_fwd': 2, 'linear_bwd': 2, 'edge_bwd_fused': 5}.get(n2, 3)) * 2 * 128 * 128
+                             for n2, v2 in k.items() if n2.startswith(('mlp', 'wgrad', 'linear', 'edge_bwd')))
             res['roofline_step'] = {'bound': 'mfma', 'achieved': step_flops / (ms_per_step * 1e-3) / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS,
                                     'unit': 'TFLOP/s', 'frac': step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                     'note': 'lower bound: node MLPs with more than one 128-wide source do more than 3 products'}

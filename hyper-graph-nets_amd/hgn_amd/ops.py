@@ -20,18 +20,20 @@ _GATE_LOG = None              # tests only: when a list, every training forward 
 
 
 _WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
-# edge blocks: data gradients and weight gradients in one pass (hgn_edge_bwd_fused).  Opt-in (HGN_FUSED_BWD=1 or
-# set_fused_edge_backward(True)): it moves 2.5 KB per edge and layer less than the two launches it replaces, but with one
-# persistent 8-wave workgroup per CU its load / DMA latencies are exposed -- measured 1.64 + 0.27 + 0.14 ms (kernel, dW1e task,
-# receiver sums) against 1.37 + 0.78 ms at 1.19 M rows, the whole step equal: the two-launch path stays
-# the default.
-_FUSED_EDGE_BWD = bool(__import__('os').environ.get('HGN_FUSED_BWD'))
+# edge blocks: data gradients and weight gradients in one pass (hgn_edge_bwd_fused) wherever the arguments are eligible (one `sum`
+# aggregate or none, no side stream): it moves 2.5 KB per edge and layer less than the two launches it replaces; kernel for
+# kernel it is at parity (1.64 + 0.27 + 0.14 ms for the kernel, the dW1e task and the receiver sums against 1.37 + 0.78 ms at
+# 1.19 M rows), the whole training step is 2.6 % faster with it (67.9 vs 69.7 ms, profiles/r02_other_configs.json; DESIGN.md
+# section 5.6).  HGN_NO_FUSED_BWD=1 or set_fused_edge_backward(False): always hgn_mlp_bwd + hgn_mlp_wgrad.
+_FUSED_EDGE_BWD_DEFAULT = not bool(__import__('os').environ.get('HGN_NO_FUSED_BWD'))
+_FUSED_EDGE_BWD = _FUSED_EDGE_BWD_DEFAULT
 
 
-def set_fused_edge_backward(on: bool) -> None:
-    """True: edge-block backward through hgn_edge_bwd_fused; False (default): hgn_mlp_bwd + hgn_mlp_wgrad."""
+def set_fused_edge_backward(on) -> None:
+    """True: eligible edge-block backwards go through hgn_edge_bwd_fused (the default); False: hgn_mlp_bwd + hgn_mlp_wgrad;
+    None: back to the process default."""
     global _FUSED_EDGE_BWD
-    _FUSED_EDGE_BWD = bool(on)
+    _FUSED_EDGE_BWD = _FUSED_EDGE_BWD_DEFAULT if on is None else bool(on)
 
 
 def set_ws_edge_forward(on: bool) -> None:

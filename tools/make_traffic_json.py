@@ -30,7 +30,7 @@ for bench_name, kern, launches_per_step, big in (('mlp_fwd_edge', 'mlp6_fwd_kern
     keys = [k for k in fetch if kern in k[0]]
     if not keys:
         continue
-    k = max(keys, key=lambda kk: (kk[1], fetch[kk][1]))       # the edge launches have the largest grid
+    k = max(keys, key=lambda kk: (fetch[kk][1], kk[1]))       # the processor's edge launches: the most frequent (kernel, grid), then the largest
     f_kib, n = fetch[k]
     w_kib = write.get(k, (0.0, 0))[0]
     r = node_rows if bench_name == 'seg_fwd' else rows
@@ -38,6 +38,7 @@ for bench_name, kern, launches_per_step, big in (('mlp_fwd_edge', 'mlp6_fwd_kern
                        'FETCH_SIZE_KiB': f_kib, 'WRITE_SIZE_KiB': w_kib,
                        'traffic_bytes_per_launch': (2 * f_kib + w_kib) * 1024,
                        'read_bytes_per_edge_row': 2 * f_kib * 1024 / rows, 'write_bytes_per_edge_row': w_kib * 1024 / rows}
-    per_step += (2 * f_kib + w_kib) * 1024 / rows
+    if not (bench_name == 'mlp_bwd_edge' and any('edge_bwd_fused_kernel' in kk[0] for kk in fetch)):      # (then only the encoder's backward)
+        per_step += (2 * f_kib + w_kib) * 1024 / rows
 out['edge_level_bytes_per_edge_and_layer'] = per_step
 print(json.dumps(out, indent=1))

@@ -16,10 +16,10 @@ for cfg in "pna --agg pna" "hyper --arch hyper --agg pna --layers 5 --clusters 1
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 "$@" > $O/bench_$n.json 2> $O/bench_$n.err || echo "config $n failed"
   python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true
 done
-HGN_FUSED_BWD=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 > $O/bench_fused_bwd.json 2> $O/bench_fused_bwd.err
+HGN_NO_FUSED_BWD=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 > $O/bench_two_launch_bwd.json 2> $O/bench_two_launch_bwd.err
 HGN_WS_FWD=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 > $O/bench_ws_fwd.json 2> $O/bench_ws_fwd.err
 HGN_BIG_TILES=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 > $O/bench_big_tiles.json 2> $O/bench_big_tiles.err
-for n in fused_bwd ws_fwd big_tiles; do python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true; done
+for n in two_launch_bwd ws_fwd big_tiles; do python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true; done
 timeout -k 10 600 python bench.py --gpus 2 --backend gloo --no-cold --no-secondary --steps 10 --warmup 3 --batch 64 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2_gloo.err; echo "gpus2 rc=$?"
 rm -rf $O/trace/*/*.db $O/pmc_f/*/*.db $O/pmc_w/*/*.db 2>/dev/null
 python -c "import json;d=json.load(open('$O/bench_default.json'));print('default', d['ms_per_step'], d['value'], json.dumps(d['roofline']), json.dumps(d.get('cpu_baseline')), json.dumps(d.get('cold_step')), json.dumps(d.get('secondary')))"
