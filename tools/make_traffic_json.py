@@ -24,21 +24,27 @@ out = {'commit': sys.argv[5] if len(sys.argv) > 5 else None, 'kernel_source_sha'
        'counters': 'FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64 bytes) + WRITE_SIZE, KiB, mean over the launches of '
                    'that (kernel, grid) in `bench.py --steps 2 --warmup 1`'}
 per_step = 0.0
-for bench_name, kern, launches_per_step, big in (('mlp_fwd_edge', 'mlp6_fwd_kernel', 15, True), ('mlp_bwd_edge', 'mlp6_bwd_kernel', 15, True),
-                                                 ('wgrad', 'wgrad6s_kernel', 15, True), ('edge_bwd_fused', 'edge_bwd_fused_kernel', 15, True),
-                                                 ('seg_fwd', 'seg_fwd128_kernel', 15, True)):
+fused_present = any('edge_bwd_fused_kernel' in kk[0] for kk in fetch)
+for bench_name, kern in (('mlp_fwd_edge', 'mlp6_fwd_kernel'), ('mlp_bwd_edge', 'mlp6_bwd_kernel'), ('wgrad', 'wgrad6s_kernel'),
+                         ('edge_bwd_fused', 'edge_bwd_fused_kernel'), ('seg_fwd', 'seg_fwd128_kernel')):
+    if bench_name == 'mlp_bwd_edge' and fused_present:
+        continue                                              # only the encoder's backward is left on that kernel at the edge grid
     keys = [k for k in fetch if kern in k[0]]
     if not keys:
         continue
     k = max(keys, key=lambda kk: (fetch[kk][1], kk[1]))       # the processor's edge launches: the most frequent (kernel, grid), then the largest
     f_kib, n = fetch[k]
     w_kib = write.get(k, (0.0, 0))[0]
-    r = node_rows if bench_name == 'seg_fwd' else rows
     out[bench_name] = {'kernel': k[0], 'grid_threads': k[1], 'launches_averaged': n, 'rows_per_launch': rows,
                        'FETCH_SIZE_KiB': f_kib, 'WRITE_SIZE_KiB': w_kib,
                        'traffic_bytes_per_launch': (2 * f_kib + w_kib) * 1024,
                        'read_bytes_per_edge_row': 2 * f_kib * 1024 / rows, 'write_bytes_per_edge_row': w_kib * 1024 / rows}
-    if not (bench_name == 'mlp_bwd_edge' and any('edge_bwd_fused_kernel' in kk[0] for kk in fetch)):      # (then only the encoder's backward)
-        per_step += (2 * f_kib + w_kib) * 1024 / rows
+# launches per processor layer and step (profiles/r02_kernel_split.csv): one each; with the fused backward the sender AND the
+# receiver sums of dz1 are stand-alone launches (the two-launch backward forms the receiver sums itself)
+for bench_name in ('mlp_fwd_edge', 'mlp_bwd_edge', 'wgrad', 'edge_bwd_fused', 'seg_fwd'):
+    if bench_name in out:
+        e = out[bench_name]
+        e['launches_per_layer'] = 2 if (bench_name == 'seg_fwd' and fused_present) else 1
+        per_step += e['launches_per_layer'] * e['traffic_bytes_per_launch'] / rows
 out['edge_level_bytes_per_edge_and_layer'] = per_step
 print(json.dumps(out, indent=1))
