@@ -61,7 +61,7 @@ def parse():
                          'independent of host-side launch jitter; per-kernel events are then taken in a short eager pass on the '
                          'same buffers right after the timed region (events cannot be timed inside a replayed graph).')
     ap.add_argument('--graph', action='store_true', help='(default at N=1; kept for compatibility)')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'fp16'],
                     help="'bf16': one bf16 MFMA per product instead of the six fp32-accurate split products (reduced precision: NOT the "
                          "headline metric, outside the 1e-5 parity tolerance; BASELINE.json configs[4] asks for such an edge MLP)")
     ap.add_argument('--side-stream', action='store_true',
@@ -364,7 +364,7 @@ def main():
         res = {'metric': 'processed edges/sec (fwd+bwd) on flag_simple mesh', 'value': value, 'unit': 'edges/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32' if args.precision == 'fp32' else 'bf16 (reduced precision run, not the headline metric)', 'data': 'synthetic',
+               'dtype': 'f32' if args.precision == 'fp32' else args.precision + ' (reduced precision run, not the headline metric)', 'data': 'synthetic',
                'config': {'workload': f'flag_simple-shape MeshGraphNets baseline: architecture {args.arch}, '
                                       f'{args.layers} MP layers, latent 128, aggregation {args.agg}, 1xMI355X config; '
                                       f'{args.nx}x{args.ny} triangulated grid per graph ({per} nodes, {E_graph} directed '

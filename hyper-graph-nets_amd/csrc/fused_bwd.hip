@@ -495,7 +495,7 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   static const int dbg = getenv("HGN_FUSED_DBG") ? atoi(getenv("HGN_FUSED_DBG")) : 0;
   fa.dbg = dbg;
   ProfScope ps(14, (double)a->M, stream);
-  if (matmul_products() == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  if (bwd_products() == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
   else switch (dbg) {                                   // diagnostic instantiations: one ablation each
     case 2: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 2>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
     case 4: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 4>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;

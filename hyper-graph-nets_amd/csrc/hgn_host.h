@@ -7,7 +7,8 @@ namespace hgn {
 
 int hgn_fail(int code, const char* msg);          // records msg (thread-local) and returns code
 int hgn_check_launch(const char* what);
-int matmul_products();                            // 6 (fp32-accurate split products) or 1 (single bf16 product): hgn_set_matmul_products
+int bwd_products();                               // products of the backward / weight-gradient kernels: 6, or 1 (bf16) in both reduced modes
+int matmul_products();                            // 6 (fp32-accurate split products), 1 (single bf16 product) or 2 (single fp16 product, forward only): hgn_set_matmul_products
 extern thread_local int g_prof_tag;           // hipGetLastError() -> HGN_OK / HGN_E_LAUNCH
 
 // Fixed-order reductions shared between translation units (wgrad.hip / mlp.hip own the kernels).

@@ -11,6 +11,7 @@ static thread_local char g_err[512] = "";
 thread_local int g_prof_tag = 0;
 static int g_products = 6;
 int matmul_products() { return g_products; }
+int bwd_products() { return g_products == 6 ? 6 : 1; }
 
 int hgn_fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -64,7 +65,8 @@ extern "C" int hgn_prof_enable(int on) {
   return HGN_OK;
 }
 extern "C" int hgn_set_matmul_products(int n) {
-  if (n != 1 && n != 6) return hgn_fail(HGN_E_INVALID, "hgn_set_matmul_products: 6 (fp32-accurate) or 1 (single bf16 product)");
+  if (n != 1 && n != 2 && n != 6)
+    return hgn_fail(HGN_E_INVALID, "hgn_set_matmul_products: 6 (fp32-accurate), 1 (single bf16 product) or 2 (single fp16 product in the forward)");
   g_products = n;
   return HGN_OK;
 }

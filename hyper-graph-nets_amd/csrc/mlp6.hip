@@ -28,7 +28,7 @@ __global__ void pack_bf16x3_kernel(const PackArgs a) {
   const hgn_pack_t d = a.d[blockIdx.y];
   const float* __restrict__ W = d.W;
   const long ldw = d.ldw;
-  const int n_out = d.n_out, n_in = d.n_in, transposed = d.transposed;
+  const int n_out = d.n_out, n_in = d.n_in, transposed = d.transposed & 1, f16 = d.transposed & 2;
   __bf16* __restrict__ out = reinterpret_cast<__bf16*>(d.out);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one (half, cl, ob, lane, j)
   if (i >= 2 * 2 * 8 * 64 * 8) return;
@@ -44,6 +44,13 @@ __global__ void pack_bf16x3_kernel(const PackArgs a) {
   const float r2 = r1 - (float)mi;
   const __bf16 lo = (__bf16)r2;
   __bf16* base = out + (long)half * HALF_BF16 + ((cl * 8 + ob) * 64 + l) * 8 + j;
+  if (f16) {                       // reduced-precision forward (one fp16 product): the leading third holds fp16 bit patterns
+    const _Float16 hf = (_Float16)w;
+    base[0 * 2 * 8 * TILE_BF16] = __builtin_bit_cast(__bf16, hf);
+    base[1 * 2 * 8 * TILE_BF16] = (__bf16)0.f;
+    base[2 * 2 * 8 * TILE_BF16] = (__bf16)0.f;
+    return;
+  }
   base[0 * 2 * 8 * TILE_BF16] = h;
   base[1 * 2 * 8 * TILE_BF16] = mi;
   base[2 * 2 * 8 * TILE_BF16] = lo;
@@ -395,6 +402,7 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   if (g_big_tiles && !tile128() && a->M >= big_min_rows()) {
     const long tiles = (a->M + 191) / 192;
     if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
+    else if (matmul_products() == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
   }
@@ -404,6 +412,7 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   } else {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
     if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else if (matmul_products() == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6>), dim3((unsigned)tiles), dim3(WG), lds_pad(), (hipStream_t)stream, *a);
   }
   return hgn_check_launch("hgn_mlp_fwd (split-bf16)");
@@ -423,6 +432,7 @@ extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const voi
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(7, (double)M, (hipStream_t)stream);
   if (matmul_products() == 1) hipLaunchKernelGGL(linear6_fwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  else if (matmul_products() == 2) hipLaunchKernelGGL(linear6_fwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear6_fwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_fwd6");
 }
@@ -440,7 +450,7 @@ extern "C" int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* a) {
 namespace hgn {
 // *n_slabs = number of 256-float LayerNorm-gradient partials written to a->ln_ws (one per workgroup)
 int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
-  if (tile128() && matmul_products() == 6 && a->M > TILE_ROWS) {
+  if (tile128() && bwd_products() == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
     hipLaunchKernelGGL((mlp6_bwd_kernel<2, 6, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     *n_slabs = tiles;
@@ -449,7 +459,7 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
     bool park = false;                      // several aggregation ops feeding a residual source gradient (pna edge blocks)
     if (a->agg_dout && a->n_agg_ops > 1)
       for (int i = 0; i < a->n_dx; ++i) park = park || a->dx[i].residual;
-    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    if (bwd_products() == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else if (park) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, true>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, false>), dim3((unsigned)tiles), dim3(WG), lds_pad(), (hipStream_t)stream, *a);
     *n_slabs = tiles;
@@ -470,7 +480,7 @@ extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const voi
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(8, (double)M, (hipStream_t)stream);
-  if (matmul_products() == 1) hipLaunchKernelGGL(linear6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  if (bwd_products() == 1) hipLaunchKernelGGL(linear6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear6_bwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_bwd6");
 }

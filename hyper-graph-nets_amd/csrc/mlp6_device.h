@@ -53,14 +53,37 @@ __device__ __forceinline__ void split3(const Act& x, bf16x8 (&s)[3][4]) {
     }
 }
 
-// NP = 1 (single bf16 product): only the leading split of the weights is staged (the first third of the half's tiles)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// operand split of a product mode: 6 -> three bf16 terms; 1 -> the leading bf16 term; 2 -> fp16 (bit patterns in the bf16 slots)
+template <int NP>
+__device__ __forceinline__ void split_np(const Act& x, bf16x8 (&s)[3][4]) {
+  if constexpr (NP == 2) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[0][c][j] = __builtin_bit_cast(__bf16, (_Float16)x.v[2 * c + (j >> 2)][j & 3]);
+  } else {
+    split3(x, s);
+  }
+}
+// one reduced-precision product: bf16 (NP = 1) or fp16 (NP = 2) operands, fp32 accumulation
+template <int NP>
+__device__ __forceinline__ f32x4 mfma_one(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (NP == 2)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// NP = 1 (single bf16 product) / NP = 2 (single fp16 product: the leading third of the pack holds fp16 bit patterns, hgn_pack_bf16x3
+// with transposed | 2): only the leading split of the weights is staged (the first third of the half's tiles)
 template <int NP>
 __device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf16* __restrict__ gsrc) {
   unsigned lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const unsigned wave = threadIdx.x >> 6;
 #pragma unroll
-  for (unsigned i = wave; i < (NP == 1 ? HALF_TILES / 3 : HALF_TILES); i += WG / 64)          // one operand tile (1 KiB) per wave instruction
+  for (unsigned i = wave; i < (NP != 6 ? HALF_TILES / 3 : HALF_TILES); i += WG / 64)          // one operand tile (1 KiB) per wave instruction
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
                                      (__attribute__((address_space(3))) void*)(lds + i * TILE_BF16), 16, 0, 0);
 }
@@ -71,7 +94,7 @@ __device__ __forceinline__ void stage_block6(__bf16* __restrict__ lds, const __b
   unsigned lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const unsigned wave = threadIdx.x >> 6;
-  constexpr unsigned PER_HALF = NP == 1 ? HALF_TILES / 3 : HALF_TILES;
+  constexpr unsigned PER_HALF = NP != 6 ? HALF_TILES / 3 : HALF_TILES;
 #pragma unroll
   for (unsigned h = 0; h < 2; ++h)
 #pragma unroll
@@ -90,9 +113,9 @@ __device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
       const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
-      if (NP == 1) {
+      if (NP != 6) {
 #pragma unroll
-        for (int u = 0; u < NS; ++u) acc[u].v[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, xs[u][0][c], acc[u].v[ob], 0, 0, 0);
+        for (int u = 0; u < NS; ++u) acc[u].v[ob] = mfma_one<NP>(a_hi, xs[u][0][c], acc[u].v[ob]);
         continue;
       }
       const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
@@ -118,7 +141,7 @@ template <int HALF, int NP>
 __device__ __forceinline__ void mfma_half6_pipe(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
   const int lane = threadIdx.x & 63;
   const __bf16* lp = lds + lane * 8;
-  constexpr int NSP = NP == 1 ? 1 : 3;
+  constexpr int NSP = NP != 6 ? 1 : 3;
   bf16x8 fr[2][3];
 #pragma unroll
   for (int s = 0; s < NSP; ++s) fr[0][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + 0) * 8 + 0) * TILE_BF16);
@@ -133,8 +156,8 @@ __device__ __forceinline__ void mfma_half6_pipe(Act& acc, const bf16x8 (&xs)[3][
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8 (&a)[3] = fr[i & 1];              // a[0] hi, a[1] mid, a[2] lo
     f32x4 t = acc.v[ob];
-    if (NP == 1) {
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][c], t, 0, 0, 0);
+    if (NP != 6) {
+      t = mfma_one<NP>(a[0], xs[0][c], t);
     } else {
       t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[0][c], t, 0, 0, 0);      // smallest terms first
       t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[2][c], t, 0, 0, 0);
@@ -170,7 +193,7 @@ __device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __re
   __syncthreads();
   HGN_STAMP();                                    // 3: landed
 #pragma unroll
-  for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
+  for (int u = 0; u < NS; ++u) split_np<NP>(b[u], xs[u]);
   post_split(b);
   HGN_STAMP();                                    // 4: split
   if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(2);
@@ -204,7 +227,7 @@ __device__ __forceinline__ void gemm6_big(Act (&acc)[NS], Act (&b)[NS], __bf16* 
   between();
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < NS; ++u) split3(b[u], xs[u]);
+  for (int u = 0; u < NS; ++u) split_np<NP>(b[u], xs[u]);
   post_split(b);
   if (!(HGN_ABL & 2)) mfma_half6<0, NS, NP>(acc, xs, lds);
   __builtin_amdgcn_sched_barrier(0);              // (no fragment of the second half in registers before the first is done)

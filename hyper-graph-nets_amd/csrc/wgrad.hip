@@ -620,7 +620,7 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
       wa.rows_per_chunk = rows_per(nch0, 2 * DT);
       static const bool resplit = getenv("HGN_WGRAD_RESPLIT") != nullptr;     // the previous kernel, kept for comparison
       if (resplit) hipLaunchKernelGGL(wgrad6_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
-      else if (matmul_products() == 1) hipLaunchKernelGGL(wgrad6s_kernel<1>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+      else if (bwd_products() == 1) hipLaunchKernelGGL(wgrad6s_kernel<1>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
       else hipLaunchKernelGGL(wgrad6s_kernel<6>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
     }
   }

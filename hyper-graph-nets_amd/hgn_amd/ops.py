@@ -43,18 +43,25 @@ def set_ws_edge_forward(on: bool) -> None:
     _lib.check(_lib.lib().hgn_set_ws_fwd(1 if on else 0), 'hgn_set_ws_fwd')
 
 
+_PRODUCTS = {'fp32': 6, 'bf16': 1, 'fp16': 2}
+
+
 def set_matmul_precision(mode: str) -> None:
     """'fp32' (default): every 128x128 product as six split-bf16 MFMAs, fp32 accurate -- the mode all parity claims refer to.
-    'bf16': ONE bf16 MFMA per product (operands rounded to bf16, fp32 accumulation; ~4e-3 relative error per product), the
-    reduced-precision edge/node MLP of BASELINE.json configs[4].  Opt-in, process wide (include/hgn_mp.h:
-    hgn_set_matmul_products)."""
-    if mode not in ('fp32', 'bf16'):
-        raise ValueError("matmul precision must be 'fp32' or 'bf16'")
-    _lib.check(_lib.lib().hgn_set_matmul_products(6 if mode == 'fp32' else 1), 'hgn_set_matmul_products')
+    'bf16': ONE bf16 MFMA per product (operands rounded to bf16, fp32 accumulation; ~4e-3 relative error per product).
+    'fp16': the forward products as ONE fp16 MFMA (11 significant bits: ~5e-4 per product; activations behind a LayerNorm and
+    weights are far inside fp16's range), the backward / weight-gradient products as one bf16 MFMA (fp32 range: gradients need no
+    loss scaling) -- the "fp16 MFMA edge-MLP" of BASELINE.json configs[4].  Opt-in, process wide (include/hgn_mp.h:
+    hgn_set_matmul_products); packed weight images are rebuilt on the next use."""
+    if mode not in _PRODUCTS:
+        raise ValueError("matmul precision must be 'fp32', 'bf16' or 'fp16'")
+    _lib.check(_lib.lib().hgn_set_matmul_products(_PRODUCTS[mode]), 'hgn_set_matmul_products')
+    invalidate_packs()
 
 
 def get_matmul_precision() -> str:
-    return 'fp32' if _lib.lib().hgn_get_matmul_products() == 6 else 'bf16'
+    n = _lib.lib().hgn_get_matmul_products()
+    return {6: 'fp32', 1: 'bf16', 2: 'fp16'}[n]
 
 
 def set_wgrad_stream(stream):
@@ -143,7 +150,8 @@ def packs_of(w: MLPWeights, transposed: bool = False):
     buf = st[1] if st is not None and st[1].numel() == (nb1 + 2) * _lib.PACK_BLOCK_BYTES else \
         torch.empty((nb1 + 2) * _lib.PACK_BLOCK_BYTES, dtype=torch.uint8, device=w.w1.device)
     arr = (_lib.Pack * (nb1 + 2))()
-    t = 1 if transposed else 0
+    # forward-form images of the fp16 mode carry fp16 bit patterns in their leading third (hgn_pack_t.transposed | 2)
+    t = 1 if transposed else (2 if _lib.lib().hgn_get_matmul_products() == 2 else 0)
     for b in range(nb1):
         d = arr[b]
         d.W = w.w1.data_ptr() + 4 * LAT * b; d.ldw = w.w1.shape[1]; d.n_out = LAT

@@ -149,15 +149,19 @@ int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
 typedef struct {
   const float* W; int64_t ldw;     /* block origin (&W[o0][i0]) and leading dimension                       */
   int32_t n_out; int32_t n_in;     /* valid extents of the block (<= 128 each; the rest is zero padded)     */
-  int32_t transposed;              /* 0: contraction over i (forward products), 1: over o (data gradients)  */
+  int32_t transposed;              /* 0: contraction over i (forward products), 1: over o (data gradients);
+                                    * 2: forward form with fp16 bit patterns in the leading third (products mode 2)    */
   void* out;                       /* HGN_PACK_BLOCK_BYTES, 16-byte aligned                                 */
 } hgn_pack_t;
 int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* stream);   /* one launch for up to HGN_MAX_PACK blocks */
 /* Precision of the split-bf16 kernels, process wide.  6 (default): the six products above, fp32 accurate -- the mode every
  * parity claim of this library refers to.  1: ONE bf16 MFMA per product (both operands rounded to bf16, fp32 accumulation,
- * relative error ~4e-3 per product; a third of the weight traffic, a sixth of the MFMAs) -- the reduced-precision edge/node
- * MLP of BASELINE.json configs[4]; opt-in, never a default, outside the 1e-5 parity tolerance. */
-int hgn_set_matmul_products(int n /* 6 or 1 */);
+ * relative error ~4e-3 per product; a third of the weight traffic, a sixth of the MFMAs).  2: the FORWARD products as ONE fp16
+ * MFMA (v_mfma_f32_16x16x32_f16: 11 significant bits, ~5e-4 per product; the forward-form packs must then be built with
+ * hgn_pack_t.transposed = 2), the backward / weight-gradient products as one bf16 MFMA (fp32 exponent range: no loss scaling)
+ * -- the "fp16 MFMA edge-MLP" of BASELINE.json configs[4].  1 and 2 are opt-in, never a default, outside the 1e-5 parity
+ * tolerance. */
+int hgn_set_matmul_products(int n /* 6, 1 or 2 */);
 int hgn_get_matmul_products(void);
 int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd will take the split-bf16 kernel */
 /* 1 if the arguments have the edge-block shape of the weight-stationary forward (csrc/ws_fwd.hip: one 128-wide ungathered source,

@@ -1078,6 +1078,22 @@ def test_config4_shape_cylinder_hyper_L25_balance_vs_oracle(steps):
     rb = H.report(tid, 'output (reduced precision: one bf16 product)', out_b, out_o)
     assert rb['norm'] <= (2e-2 if steps == 1 else 5e-2), rb
     assert H.rel_err(loss_b, loss_o) <= 5e-2
+    # fp16 forward products (what configs[4] names), bf16 backward products: 11 significant bits per forward operand instead
+    # of 8 -> the outputs are ~8x closer to the fp64 result than in the bf16 mode (bound: a quarter of the bf16 bound, and
+    # better than the bf16 run of the same inputs); gradients flow through bf16 products and keep the bf16 tolerance.
+    hgn_amd.set_matmul_precision('fp16')
+    try:
+        assert hgn_amd.get_matmul_precision() == 'fp16'
+        out_h, loss_h, grads_h, _ = H.hip_run(model, graph, target, mask)
+    finally:
+        hgn_amd.set_matmul_precision('fp32')
+    rh = H.report(tid, 'output (reduced precision: fp16 forward products)', out_h, out_o)
+    assert rh['norm'] <= (5e-3 if steps == 1 else 1.25e-2), rh
+    assert rh['norm'] < rb['norm'], (rh, rb)
+    assert H.rel_err(loss_h, loss_o) <= 2e-2
+    wh, _ = H.worst_grad(grads_h, grads_o)
+    H._REPORT.append({'test': tid, 'what': 'param grads (worst tensor), fp16 forward / bf16 backward', 'norm': wh})
+    assert wh < 1.0, wh                                     # (bf16 products in the backward: measured in the report, no bound claimed)
     out_again, _, _, _ = H.hip_run(model, graph, target, mask)
     assert torch.equal(out_again, out)                     # switching back restores the fp32-accurate results bit for bit
 
