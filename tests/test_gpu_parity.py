@@ -1098,12 +1098,13 @@ def test_config4_shape_cylinder_hyper_L25_balance_vs_oracle(steps):
     assert torch.equal(out_again, out)                     # switching back restores the fp32-accurate results bit for bit
 
 
-@pytest.mark.parametrize('agg,nx,ny', [('sum', 7, 5), ('sum', 40, 40), ('pna', 23, 17), ('max', 9, 9)])
+@pytest.mark.parametrize('agg,nx,ny', [('sum', 7, 5), ('sum', 40, 40), ('sum', 120, 100), ('pna', 23, 17), ('max', 9, 9)])
 def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
     """hgn_edge_bwd_fused (data gradients + weight gradients of an edge block in one persistent kernel, dz3 / dz2 never written)
     against the two-launch path it replaces (hgn_mlp_bwd + hgn_mlp_wgrad) on the same inputs: same products, other summation
     order over rows -> 2e-6, and the fused path against the fp64 oracle at the usual tolerances.
-    Sizes: fewer tiles than workgroups, the 146-tile benchmark graph, a ragged last tile."""
+    Sizes: fewer tiles than workgroups, the 146-tile benchmark graph, 1 100 tiles (several per persistent workgroup: the
+    loop-carried prefetch), a ragged last tile."""
     import hgn_amd
     from hgn_amd import ops
     graph = synth.grid_graph(seed=3, nx=nx, ny=ny)
@@ -1186,7 +1187,7 @@ def test_deferred_node_level_weight_gradients_match_immediate_launches():
             assert H.rel_err(grads[True][off:off + p.numel()].view(p.shape), g_o[kname]) <= TOL_GRAD, kname
 
 
-@pytest.mark.parametrize('nx,ny,agg', [(7, 5, 'sum'), (40, 40, 'sum'), (23, 17, 'pna')])
+@pytest.mark.parametrize('nx,ny,agg', [(7, 5, 'sum'), (40, 40, 'sum'), (120, 100, 'sum'), (23, 17, 'pna')])
 def test_weight_stationary_edge_forward_equals_staged_forward(nx, ny, agg):
     """csrc/ws_fwd.hip (opt-in: weights of the three edge-MLP layers resident in registers, activations through LDS) against the
     staged-weights kernel it can replace, through the same autograd function: outputs, aggregates and every gradient (the
