@@ -1214,7 +1214,9 @@ def test_weight_stationary_edge_forward_equals_staged_forward(nx, ny, agg):
     assert H.rel_err(out_w, out_s) <= 2e-6
     for kname in g_s:
         if float(g_s[kname].abs().max()) > 0:
-            assert H.rel_err(g_w[kname], g_s[kname]) <= 5e-5, kname     # (a ReLU sign can flip where z ~ 1e-8: both are valid)
+            # (a ReLU sign flips where |z| is at rounding level -- both results are valid -- and a flipped unit changes its
+            #  row's gradient by O(1): a handful of rows in 72 000 move a weight gradient by up to 1e-4 of its norm)
+            assert H.rel_err(g_w[kname], g_s[kname]) <= 2e-4, kname
     out_o, _, g_o, _ = H.oracle_run(sd, graph, 'none', agg, target, mask) if agg == 'sum' and N <= 400 else (None, None, None, None)
     if out_o is not None:
         assert H.rel_err(out_w, out_o) <= TOL_OUT
