@@ -581,8 +581,8 @@ class EdgeBlockFn(torch.autograd.Function):
         # backward kernel itself when the segments are short (include/hgn_mp.h: seg_dz1)
         dP = torch.empty(N, 2 * LAT, device=dev)
         # One pass for data gradients AND weight gradients (include/hgn_mp.h: hgn_edge_bwd_fused): dz3 / dz2 never reach memory.
-        fused = (_FUSED_EDGE_BWD and pk_t is not None and E > 0 and _WGRAD_STREAM is None
-                 and bool(L.hgn_edge_bwd_fused_eligible(C.byref(b))))
+        fused = (_FUSED_EDGE_BWD and pk_t is not None and E > 0 and _WGRAD_STREAM is None and accs[2] == accs[4]
+                 and bool(L.hgn_edge_bwd_fused_eligible(C.byref(b))))      # (dW3 / dW2 share one accumulate flag in hgn_wfuse_t)
         fuse_seg = (not fused and pk_t is not None and E > 0 and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
                     and L.hgn_mlp_bwd6_eligible(C.byref(b)))
         if fuse_seg:
@@ -592,8 +592,6 @@ class EdgeBlockFn(torch.autograd.Function):
             wf = _lib.WFuse()
             wf.z2 = z2.data_ptr(); wf.z1 = z1.data_ptr()
             wf.dW3 = dw3.data_ptr(); wf.db3 = db3.data_ptr(); wf.dW2 = dw2.data_ptr(); wf.db2 = db2.data_ptr()
-            if accs[2] != accs[4]:
-                raise _lib.HgnError('edge block: mixed accumulate / overwrite gradient targets')
             wf.accumulate = accs[2]
             b.dz3 = None; b.dz2 = None
             nb = C.c_size_t(0)
