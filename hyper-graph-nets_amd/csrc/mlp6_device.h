@@ -8,6 +8,7 @@
 //   1 no weight DMA   2 no MFMA   4 no stores of saved activations / intermediate gradients   8 no row loads
 //  32 (experiment, not an ablation) raised wave priority around the product sweeps
 //  64 (experiment) operand fragments read one output block ahead of the products (mfma_half6_pipe)
+// 256 (comparison) the compiler-scheduled product sweep (mfma_half6) instead of the pair-ahead one (mfma_half6_pipe2, the default)
 //  16 time stamps (s_memrealtime, 10 ns) of one mid-launch workgroup's wave 0 through the forward kernel (tools/fwdstamps.py)
 #ifndef HGN_ABL
 #define HGN_ABL 0
@@ -81,7 +82,7 @@ template <int NP>
 __device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf16* __restrict__ gsrc) {
   unsigned lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
-  const unsigned wave = threadIdx.x >> 6;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar tile offsets, LDS bases straight into M0
 #pragma unroll
   for (unsigned i = wave; i < (NP != 6 ? HALF_TILES / 3 : HALF_TILES); i += WG / 64)          // one operand tile (1 KiB) per wave instruction
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
@@ -93,7 +94,7 @@ template <int NP, int NWV>
 __device__ __forceinline__ void stage_block6(__bf16* __restrict__ lds, const __bf16* __restrict__ gsrc) {
   unsigned lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
-  const unsigned wave = threadIdx.x >> 6;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr unsigned PER_HALF = NP != 6 ? HALF_TILES / 3 : HALF_TILES;
 #pragma unroll
   for (unsigned h = 0; h < 2; ++h)
@@ -170,9 +171,58 @@ __device__ __forceinline__ void mfma_half6_pipe(Act& acc, const bf16x8 (&xs)[3][
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+// Two output blocks at a time (two independent accumulation chains, as the compiler pairs them anyway) with the SIX operand
+// fragments of the next pair read from LDS before the current pair's twelve products are issued: a whole pair (192 matrix-pipe
+// cycles) of distance between a `ds_read_b128` and its use, where the unconstrained schedule reads just in time and starts
+// every pair with an exposed LDS round trip.  24 more registers during the sweep, which is not where the kernels peak.
+template <int HALF, int NP>
+__device__ __forceinline__ void mfma_half6_pipe2(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+  const __bf16* lp = lds + lane * 8;
+  constexpr int NSP = NP != 6 ? 1 : 3;
+  bf16x8 fr[2][2][3];
+  auto load_pair = [&](int g, bf16x8 (&f)[2][3]) {
+    const int cl = g >> 2, ob0 = 2 * (g & 3);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) f[k][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + cl) * 8 + ob0 + k) * TILE_BF16);
+  };
+  load_pair(0, fr[0]);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int cl = g >> 2, ob0 = 2 * (g & 3), c = 2 * HALF + cl;
+    if (g + 1 < 8) load_pair(g + 1, fr[(g + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 (&a)[2][3] = fr[g & 1];           // a[k][0] hi, [1] mid, [2] lo of output block ob0 + k
+    f32x4 t0 = acc.v[ob0], t1 = acc.v[ob0 + 1];
+    if (NP != 6) {
+      t0 = mfma_one<NP>(a[0][0], xs[0][c], t0);
+      t1 = mfma_one<NP>(a[1][0], xs[0][c], t1);
+    } else {
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][2], xs[0][c], t0, 0, 0, 0);      // smallest terms first
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][2], xs[0][c], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], xs[2][c], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], xs[2][c], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], xs[1][c], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], xs[1][c], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], xs[0][c], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], xs[0][c], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], xs[1][c], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], xs[1][c], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], xs[0][c], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], xs[0][c], t1, 0, 0, 0);
+    }
+    acc.v[ob0] = t0; acc.v[ob0 + 1] = t1;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 template <int HALF, int NS, int NP>
 __device__ __forceinline__ void mfma_half6_sel(Act (&acc)[NS], const bf16x8 (&xs)[NS][3][4], const __bf16* __restrict__ lds) {
+  // one sub-tile per wave: the pair-ahead sweep (forward -0.7 %, backward -1.6 % at 1.19 M rows against the compiler's own
+  // schedule of mfma_half6; same products in the same order per accumulator: identical bits)
   if constexpr (NS == 1 && (HGN_ABL & 64) != 0) mfma_half6_pipe<HALF, NP>(acc[0], xs[0], lds);
+  else if constexpr (NS == 1 && (HGN_ABL & 256) == 0) mfma_half6_pipe2<HALF, NP>(acc[0], xs[0], lds);
   else mfma_half6<HALF, NS, NP>(acc, xs, lds);
 }
 

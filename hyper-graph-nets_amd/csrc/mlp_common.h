@@ -64,27 +64,30 @@ struct SegPre {
 // group when several groups of one workgroup walk a tile each (every group on its own `ldsf` / `ids`; the barrier is the workgroup's).
 __device__ __forceinline__ void tile_segment_walk(float* __restrict__ ldsf, const int* __restrict__ ids, int prev_id, int next_id,
                                                   float* __restrict__ out, long ld, long tile_row0, long M, bool lds_only, int ltid) {
+  // Everything that steers the walk is the same for the 64 threads of a wave (they walk the same rows of different columns):
+  // the ids go through readfirstlane, so the segment tests compile to SCALAR branches instead of exec-mask sequences (the
+  // walk was a hundred `s_and_saveexec` regions per tile before).
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   float* hp = ldsf + 64 * 132 + 64;
   const int rows = (int)max(0L, min((long)TILE_ROWS, M - tile_row0));
-  const bool walker = ltid < 256;
-  const int half = (ltid >> 7) & 1, c = ltid & 127;
+  const int half = uni((ltid >> 7) & 1), c = ltid & 127;
   const int r0 = 32 * half, r1 = min(rows, r0 + 32);
-  const bool active = walker && r0 < rows;
-  const bool tile_cont_prev = rows > 0 && tile_row0 > 0 && prev_id == ids[0];
-  const bool tile_cont_next = rows > 0 && tile_row0 + rows < M && next_id == ids[rows - 1];
+  const bool active = uni(ltid < 256 ? 1 : 0) && r0 < rows;
+  const bool tile_cont_prev = rows > 0 && tile_row0 > 0 && uni(prev_id) == uni(ids[0]);
+  const bool tile_cont_next = rows > 0 && tile_row0 + rows < M && uni(next_id) == uni(ids[rows > 0 ? rows - 1 : 0]);
   int cur = -1;
   float s = 0.f;
   bool first = true;                                        // still inside the segment my range began with
   bool cont_prev = false;                                   // ... and that segment began before my range
   if (active) {
-    cur = ids[r0];
-    cont_prev = half ? ids[r0 - 1] == cur : tile_cont_prev;
+    cur = uni(ids[r0]);
+    cont_prev = half ? uni(ids[r0 - 1]) == cur : tile_cont_prev;
     for (int rb = r0; rb < r1; rb += 8) {
       float x[8]; int id[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = min(rb + j, r1 - 1);
-        x[j] = ldsf[r * 132 + c]; id[j] = ids[r];
+        x[j] = ldsf[r * 132 + c]; id[j] = uni(ids[r]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -109,9 +112,9 @@ __device__ __forceinline__ void tile_segment_walk(float* __restrict__ ldsf, cons
   }
   if (lds_only) wg_barrier_lds(); else __syncthreads();
   if (!half && active) {
-    const bool joined = rows > 32 && ids[32] == cur;        // half 1 began inside my last segment
+    const bool joined = rows > 32 && uni(ids[32]) == cur;   // half 1 began inside my last segment
     const float total = s + (joined ? hp[c] : 0.f);
-    const bool to_end = joined ? ids[rows - 1] == cur : rows <= 32;     // the segment runs to the end of the tile
+    const bool to_end = joined ? uni(ids[rows - 1]) == cur : rows <= 32;     // the segment runs to the end of the tile
     float* dst = out + (long)cur * ld + c;
     if ((first && cont_prev) || (to_end && tile_cont_next)) unsafeAtomicAdd(dst, total); else *dst = total;
   }
