@@ -214,34 +214,72 @@ def _zero_unaccumulated(bufs, accs):
 # gradient buffer (parallel.FlatParams) are queued per row count and launched 16 at a time; whatever is left goes out when the
 # autograd engine finishes the backward pass (queue_callback), i.e. before `backward()` returns -- also under HIP-graph capture.
 _DEFER_NODE_WGRAD = not bool(__import__('os').environ.get('HGN_NO_DEFERRED_WGRAD'))
-_wq = {}                      # (M, device) -> [tasks, tensors kept alive]
-_wq_callback_armed = False
+_wq = {}                      # (M, device) -> [tasks, tensors kept alive, set of queued dW / db target addresses]
+_wq_graph_task = -1           # id of the autograd engine run whose final callback will flush the queue (-1: none armed)
+
+
+def _graph_task_id() -> int:
+    try:
+        return int(torch._C._current_graph_task_id())
+    except AttributeError:                    # an older torch: treated as "not inside an engine run"
+        return -1
 
 
 def flush_wgrad() -> None:
     """Launch every queued weight-gradient task now."""
-    global _wq_callback_armed
-    _wq_callback_armed = False
-    for (M, dev), (tasks, keep) in list(_wq.items()):
-        if tasks:
-            _run_wgrad_here(tasks, M, dev, False)
+    global _wq_graph_task
+    _wq_graph_task = -1
+    try:
+        for (M, dev), q in list(_wq.items()):
+            if q[0]:
+                _run_wgrad_here(q[0], M, dev, False)
+    finally:
+        _wq.clear()
+
+
+def discard_stale_wgrad() -> int:
+    """Drop queued tasks without launching them and disarm the callback.  Tasks can only be left over when a backward pass
+    raised after queueing them (the engine then drops its callbacks): their operand pointers belong to that failed step and
+    must not be launched into the next step's gradient buffer.  -> number of tasks dropped.  Called at the start of every
+    trainer step (parallel.DataParallelTrainer, graphs.*) and whenever a task is queued from a different engine run."""
+    global _wq_graph_task
+    n = sum(len(q[0]) for q in _wq.values())
     _wq.clear()
+    _wq_graph_task = -1
+    return n
+
+
+def _wtask_targets(t):
+    return [p for p in (t.dW, t.db) if p]
 
 
 def _defer_wgrad(tasks, M, dev, keep):
-    global _wq_callback_armed
-    q = _wq.setdefault((M, dev), [[], []])
-    if len(q[0]) + len(tasks) > _lib.HGN_MAX_WTASK:
-        _run_wgrad_here(q[0], M, dev, False)
-        q[0], q[1] = [], []
+    global _wq_graph_task
+    gid = _graph_task_id()
+    if gid < 0:                              # backward driven by hand, outside an engine run: nothing will call back
+        _run_wgrad_here(tasks, M, dev, False)
+        return
+    if gid != _wq_graph_task:
+        # first task of THIS engine run.  Anything still queued was left by a run that raised: never launch it.
+        discard_stale_wgrad()
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad)
+        _wq_graph_task = gid
+    q = _wq.setdefault((M, dev), [[], [], set()])
+    tg = [p for t in tasks for p in _wtask_targets(t)]
+    # wgrad_reduce_kernel adds one task's result onto its target without atomics, one grid slice per task: two tasks of ONE
+    # launch must never share a dW / db target (the same MLP applied twice at one row count: `repeated` blocks, the cross
+    # model and the mesh-edge model of `multiscale`).  Launch what is queued first; stream order then serialises the two.
+    if len(q[0]) + len(tasks) > _lib.HGN_MAX_WTASK or any(p in q[2] for p in tg) or len(set(tg)) != len(tg):
+        if q[0]:
+            _run_wgrad_here(q[0], M, dev, False)
+        q[0], q[1], q[2] = [], [], set()
+    if len(set(tg)) != len(tg):              # the hand-over itself repeats a target: one launch per task
+        for t in tasks:
+            _run_wgrad_here([t], M, dev, False)
+        return
     q[0] += tasks
     q[1] += list(keep)
-    if not _wq_callback_armed:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad)
-            _wq_callback_armed = True
-        except RuntimeError:                 # not inside an engine run (backward called by hand): nothing to wait for
-            flush_wgrad()
+    q[2].update(tg)
 
 
 def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False, keep=(), defer: bool = False):
@@ -541,8 +579,7 @@ class EdgeBlockFn(torch.autograd.Function):
         if d_out is None and d_agg is None:
             return (None,) * (5 + len(wt))
         dev = (d_out if d_out is not None else d_agg).device
-        dz3 = torch.empty(E, LAT, device=dev)
-        dz2 = torch.empty(E, LAT, device=dev)
+        dz3 = dz2 = None              # [E,128] each, only on the two-launch path (the fused kernel keeps them on chip)
         dz1 = torch.empty((E + 63) // 64 * 64, LAT, device=dev)[:E]      # whole 64-row tiles: hgn_edge_bwd_fused stores the padding rows too
         de = torch.empty(E, LAT, device=dev)
         b = _lib.MlpBwd()
@@ -564,7 +601,7 @@ class EdgeBlockFn(torch.autograd.Function):
         b.ln_g = w.ln_w.data_ptr(); b.xhat = xhat.data_ptr(); b.rstd = rstd.data_ptr()
         b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr(); b.relu_bits = bits.data_ptr()
         b.W3 = w.w3.data_ptr(); b.W2 = w.w2.data_ptr(); b.ldw1 = 3 * LAT
-        b.dz3 = dz3.data_ptr(); b.dz2 = dz2.data_ptr(); b.dz1 = dz1.data_ptr()
+        b.dz1 = dz1.data_ptr()
         b.n_dx = 1
         d = b.dx[0]
         d.W = w.w1.data_ptr() + 4 * 2 * LAT; d.K = LAT; d.dx = de.data_ptr(); d.ld = LAT; d.residual = 1
@@ -593,7 +630,6 @@ class EdgeBlockFn(torch.autograd.Function):
             wf.z2 = z2.data_ptr(); wf.z1 = z1.data_ptr()
             wf.dW3 = dw3.data_ptr(); wf.db3 = db3.data_ptr(); wf.dW2 = dw2.data_ptr(); wf.db2 = db2.data_ptr()
             wf.accumulate = accs[2]
-            b.dz3 = None; b.dz2 = None
             nb = C.c_size_t(0)
             _lib.check(L.hgn_edge_bwd_fused_workspace_bytes(E, C.byref(nb)), 'hgn_edge_bwd_fused_workspace_bytes')
             ws = _workspace(dev, nb.value, 'fused')
@@ -601,11 +637,14 @@ class EdgeBlockFn(torch.autograd.Function):
             # dW1's edge block: dz1 is in memory anyway (the sender / receiver sums read it), one streaming task
             _run_wgrad([_wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
                                db1.data_ptr(), accs[0])], E, dev, edge_level=True, keep=[e, dz1])
-        elif E > 0:
-            _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
-        elif not accs[6]:
-            dg.zero_(); dbt.zero_()
-        if not fused:
+        else:
+            dz3 = torch.empty(E, LAT, device=dev)
+            dz2 = torch.empty(E, LAT, device=dev)
+            b.dz3 = dz3.data_ptr(); b.dz2 = dz2.data_ptr()
+            if E > 0:
+                _lib.check(L.hgn_mlp_bwd(C.byref(b), st), 'hgn_mlp_bwd')
+            elif not accs[6]:
+                dg.zero_(); dbt.zero_()
             tasks = [_wtask(0, z2.data_ptr(), LAT, LAT, None, dz3.data_ptr(), LAT, LAT, dw3.data_ptr(), LAT, db3.data_ptr(), accs[4]),
                      _wtask(0, z1.data_ptr(), LAT, LAT, None, dz2.data_ptr(), LAT, LAT, dw2.data_ptr(), LAT, db2.data_ptr(), accs[2]),
                      _wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,

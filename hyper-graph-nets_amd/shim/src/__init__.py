@@ -1,9 +1,10 @@
 """Path shim: a package named ``src`` that resolves the reference's hot-path module paths to the MI355X implementation.
 
-Put ``hyper-graph-nets_amd/shim`` and ``hyper-graph-nets_amd`` BEFORE the reference checkout on PYTHONPATH and run the
-reference's ``main.py`` unchanged:
+This directory must come BEFORE the reference checkout on ``sys.path``.  ``python main.py`` puts the checkout (the script
+directory) first, ahead of PYTHONPATH, so the reference's unchanged ``main.py`` is started through the launcher, which orders
+the path from inside the interpreter (hgn_amd/run_main.py):
 
-    PYTHONPATH=<repo>/hyper-graph-nets_amd/shim:<repo>/hyper-graph-nets_amd:<reference> python main.py flag
+    cd <reference>; PYTHONPATH=<repo>/hyper-graph-nets_amd python -m hgn_amd.run_main flag
 
 ``import src.migration.meshgraphnet`` (flag.py:8), ``src.migration.normalizer`` (flag.py:9), ``src.util`` (flag.py:11),
 ``src.rmp.get_rmp`` (flag.py:4), ``src.graph_balancer.get_graph_balancer`` (flag.py:47), ``src.model.get_model``

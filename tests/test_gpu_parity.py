@@ -1187,6 +1187,89 @@ def test_deferred_node_level_weight_gradients_match_immediate_launches():
             assert H.rel_err(grads[True][off:off + p.numel()].view(p.shape), g_o[kname]) <= TOL_GRAD, kname
 
 
+@pytest.mark.parametrize('arch', ['repeated', 'multiscale'])
+def test_shared_weight_gradient_targets_through_the_flat_gradient_trainer(arch):
+    """A block that applies ONE MLP twice at one row count (RepeatedGraphNet: node and edge model `repetitions` times,
+    repeatedgraphnet.py:18-22; MultiScaleGraphNet: node_model_cross and the mesh_edges model twice, multiscalegraphnet.py:20-63)
+    hands the deferred queue two accumulating tasks with the same dW / db target.  The reduction adds without atomics, one grid
+    slice per task, so the two must not share a launch: gradients through DataParallelTrainer equal the undeferred launches,
+    are the same on every run, and match the fp64 oracle."""
+    import hgn_amd
+    from hgn_amd import ops, parallel
+    graph = synth.grid_graph(seed=5, nx=16, ny=12, clusters=4 if arch == 'multiscale' else 0)
+    sets = [e.name for e in graph.edge_sets]
+    hyper_w = 8 if arch == 'multiscale' else 0
+    shapes = O.param_shapes(arch, 'sum', 2, sets, 5, {n: 7 for n in sets}, hyper_w, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=2)
+    G = hgn_amd.MultiGraph([x.cuda() for x in graph.node_features],
+                           [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in graph.edge_sets])
+    N = graph.node_features[0].shape[0]
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(1))
+    mask = torch.ones(N, dtype=torch.bool)
+    runs = []
+    for defer in (True, True, False):
+        old = ops._DEFER_NODE_WGRAD
+        ops._DEFER_NODE_WGRAD = defer
+        try:
+            tr = parallel.DataParallelTrainer(H.hip_model(arch, 'sum', 2, sets, sd), lr=0.0)
+            tr.step(G, target.cuda(), mask.cuda())
+            tr.step(G, target.cuda(), mask.cuda())
+        finally:
+            ops._DEFER_NODE_WGRAD = old
+        assert not ops._wq
+        runs.append(tr.fp.grad.clone())
+    assert torch.equal(runs[0], runs[1])
+    assert H.rel_err(runs[0], runs[2]) <= 1e-6
+    _, _, g_o, _ = H.oracle_run(sd, graph, arch, 'sum', target, mask)
+    n_norm = float(mask.sum()) * 3
+    for (kname, p), off in zip(tr.model.named_parameters(), tr.fp.offsets):
+        if float(g_o[kname].abs().max()) > 0:
+            assert H.rel_err(runs[0][off:off + p.numel()].view(p.shape), g_o[kname]) <= TOL_GRAD, kname
+
+
+def test_failed_backward_leaves_no_stale_weight_gradient_tasks():
+    """A backward pass that raises after node-level tasks were queued drops the engine's final callback: the queued tasks (raw
+    pointers into that step's buffers) must never be launched into the next step's gradients, and the next backward must arm
+    its own callback -- its gradients are complete when backward() returns."""
+    import hgn_amd
+    from hgn_amd import ops, parallel
+    graph = synth.grid_graph(seed=9, nx=12, ny=9)
+    sets = ['mesh_edges']
+    shapes = O.param_shapes('none', 'sum', 2, sets, 5, {'mesh_edges': 7}, 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=3)
+    G = hgn_amd.MultiGraph([x.cuda() for x in graph.node_features],
+                           [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in graph.edge_sets])
+    N = graph.node_features[0].shape[0]
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    mask = torch.ones(N, dtype=torch.bool).cuda()
+    tr = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 2, sets, sd), lr=0.0)
+    tr.step(G, target, mask)
+    good = tr.fp.grad.clone()
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+
+    # the encoder runs last in the backward pass: by then the processor's node-level tasks are queued
+    tr.fp.zero_grad()
+    feats = [Boom.apply(x.requires_grad_(True)) for x in G.node_features]
+    out = tr.model(hgn_amd.MultiGraph(feats, G.edge_sets))
+    with pytest.raises(RuntimeError, match='boom'):
+        ((out - target) * mask.unsqueeze(1)).square().sum().backward()
+    assert sum(len(q[0]) for q in ops._wq.values()) > 0          # the failed run left its tasks behind
+    for x in G.node_features:
+        x.requires_grad_(False)
+    tr.step(G, target, mask)
+    assert not ops._wq
+    torch.cuda.synchronize()
+    assert torch.equal(tr.fp.grad, good)
+
+
 @pytest.mark.parametrize('nx,ny,agg', [(7, 5, 'sum'), (40, 40, 'sum'), (120, 100, 'sum'), (23, 17, 'pna')])
 def test_weight_stationary_edge_forward_equals_staged_forward(nx, ny, agg):
     """csrc/ws_fwd.hip (opt-in: weights of the three edge-MLP layers resident in registers, activations through LDS) against the
