@@ -68,6 +68,14 @@ def parse():
                     help='weight-gradient launches on a second stream (co-run with the next data-gradient kernels); paid off while those '
                          'kernels were MFMA bound, measured 1.7 %% slower since they are row-traffic bound')
     ap.add_argument('--no-side-stream', action='store_true', help='(default; kept for compatibility)')
+    ap.add_argument('--workload', default='flag', choices=['flag', 'plate', 'cylinder'],
+                    help="'flag' (headline): flag_simple-shape grids.  'plate': deforming_plate-shape frames (11x11x11 plate grid of 4-vertex "
+                         "cells + an obstacle block) through PlateModel: radius-search world edges, spectral clustering into --clusters hyper "
+                         "nodes, hetero connector (BASELINE.json configs[2] / plateCluster.yaml).  'cylinder': cylinder_flow-shape frames "
+                         "(65x29 grid) through CylinderModel + hyper remote sets + a balance set (configs[4]; run with --precision fp16)")
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong-scaling mode: TOTAL graphs over all ranks (BASELINE.json configs[3]: 8 graphs over 8 GPUs = 1 per rank); '
+                         'default 0 = weak scaling with --batch graphs per GPU')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
 
@@ -86,23 +94,36 @@ def kernel_source_sha() -> str:
 
 
 def secondary_configs(args):
-    """Driver-visible secondary figures: the YAML default aggregation (pna, flag.yaml:32) and the edge-set structure of the
-    deforming_plate HyperGraphNets configuration of BASELINE.json configs[2] / plateCluster.yaml (hetero block, K = 31 hyper
-    nodes, 5 MP layers, pna; mesh + world + three remote edge sets) on the same 40x40 grids -- each a short run of this same
-    script as a CHILD process (never exec: the parent holds the GPU)."""
+    """Driver-visible secondary figures, each a short run of this same script as a CHILD process (never exec: the parent holds the
+    GPU), each on the shape its name says:
+      * the YAML default aggregation (pna, flag.yaml:32) on the headline flag_simple-shape batch;
+      * BASELINE.json configs[2]: deforming_plate-shape frames THROUGH PlateModel (4-vertex cells, radius-search world edges,
+        spectral clustering K = 31, hetero connector, pna, 5 MP layers: plateCluster.yaml);
+      * BASELINE.json configs[4] at one GPU: cylinder_flow-shape frames, hyper block, 25 MP layers, + balance set, fp16 forward
+        products (`--precision fp16`: reduced precision, its own tolerance, tests/test_gpu_parity.py);
+      * the plate configuration's EDGE-SET STRUCTURE on the flag grids (what round 2 reported as "plate config"): kept for
+        continuity under a name that says what it is."""
     out = {}
     base = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '2', '--no-cold', '--no-cpu-baseline', '--no-prof',
             '--no-secondary', '--batch', str(args.batch)]
     for name, extra in (('flag_simple_shape_pna_L15', ['--agg', 'pna']),
-                        ('plate_config_edge_sets_hetero_pna_L5_K31_on_40x40_grids', ['--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31',
-                                                                      '--world-edges', '300'])):
+                        ('deforming_plate_shape_PlateModel_spectral_K31_hetero_pna_L5',
+                         ['--workload', 'plate', '--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31']),
+                        ('cylinder_flow_shape_hyper_pna_L25_balance_fp16_products',
+                         ['--workload', 'cylinder', '--arch', 'hyper', '--agg', 'pna', '--layers', '25', '--clusters', '16',
+                          '--precision', 'fp16']),
+                        ('flag_grid_40x40_with_plate_edge_set_structure_hetero_pna_L5_K31',
+                         ['--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31', '--world-edges', '300'])):
         try:
-            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=420)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]
             if r.returncode == 0 and line:
                 d = json.loads(line[-1])
                 out[name] = {'edges_per_s': d['value'], 'ms_per_step': d['ms_per_step'], 'edges_per_step': d['config']['edges_per_step'],
-                             'steps': d['steps'], 'workload': d['config']['workload']}
+                             'graphs_per_gpu': d['config']['graphs_per_gpu'], 'steps': d['steps'], 'dtype': d['dtype'],
+                             'workload': d['config']['workload']}
+                if 'graph_build' in d['config']:
+                    out[name]['graph_build'] = d['config']['graph_build']
             else:
                 out[name] = {'error': (r.stderr or '')[-300:]}
         except Exception as ex:                             # a secondary figure must never cost the headline line
@@ -133,16 +154,13 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(args, graph1):
-    """The oracle (CPU port of the reference op sequence) on ONE flag_simple-shape graph at full depth, fwd+loss+bwd."""
+def cpu_baseline(args, graph1, state_dict):
+    """The oracle (CPU port of the reference op sequence) on ONE graph of the workload at full depth, fwd+loss+bwd, with the
+    benchmarked model's own parameters."""
     from oracle import mgn_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    sets = [e.name for e in graph1.edge_sets]
-    shapes = O.param_shapes(args.arch, args.agg, args.layers, sets, graph1.node_features[0].shape[1],
-                            {e.name: e.features.shape[1] for e in graph1.edge_sets},
-                            graph1.node_features[1].shape[1] if len(graph1.node_features) > 1 else 0, 3, 128)
-    sd = {k: v.requires_grad_(True) for k, v in O.init_state_dict_like(shapes, 0).items()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in state_dict.items()}
     N = graph1.node_features[0].shape[0]
     target = torch.randn(N, 3, generator=torch.Generator().manual_seed(0))
     mask = torch.ones(N, dtype=torch.bool); mask[:3] = False
@@ -162,7 +180,7 @@ def cpu_baseline(args, graph1):
         log(f'cpu baseline iter {iters}: {time.perf_counter() - t0:.1f} s')
     dt = (time.perf_counter() - t0) / iters
     return {'value': E / dt, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 graph ({N} nodes, {E} edges), L={args.layers}, {args.agg}, fwd+loss+bwd, {iters} iters, '
+            'sample': f'1 graph of the workload ({N} nodes, {E} edges), L={args.layers}, {args.agg}, fwd+loss+bwd, {iters} iters, '
                       f'{dt:.3f} s/iter, torch {torch.__version__} CPU fp32'}
 
 
@@ -203,6 +221,141 @@ def cpu_baseline_features(frames, iters=10):
         FO.hierarchical_connect(g, clusters, nb, ff.intra_edge, ff.inter_edge, ff.hyper_node, True)
     t2 = time.perf_counter()
     return {'cores': cores, 'build_graph ms/frame': (t1 - t0) / iters * 1e3, 'build_graph+connect ms/frame': (t2 - t1) / iters * 1e3}
+
+
+
+def _params(arch, agg, layers, clustering, K):
+    """The `model` section of a reference YAML (configs/plateCluster.yaml:24-60 key set) for the system models."""
+    remote = arch not in ('none',)
+    return {'size': 3, 'aggregation': agg, 'message_passing_steps': layers,
+            'rmp': {'clustering': clustering if remote else 'none', 'connector': arch if remote else 'none', 'num_clusters': K,
+                    'hyper_noise': 'none', 'hyper_node_features': True, 'frequency': 1, 'fully_connect': False,
+                    'intra_cluster_sampling': {'enabled': False, 'alpha': 0.1, 'spotter_threshold': 0}},
+            'graph_balancer': {'algorithm': 'none', 'frequency': 1}}
+
+
+def build_flag(args, gids, dev):
+    import hgn_amd
+    from hgn_amd import synthetic
+    graphs = [synthetic.grid_graph(seed=1000 + g, nx=args.nx, ny=args.ny, clusters=args.clusters, world=args.world_edges)
+              for g in gids[:min(len(gids), 4)]]
+    while len(graphs) < len(gids):                       # reuse topologies, fresh features (host generation is slow)
+        src = graphs[len(graphs) % 4]
+        gen = torch.Generator().manual_seed(2000 + gids[len(graphs)])
+        graphs.append(synthetic.MultiGraph([torch.randn(x.shape, generator=gen) for x in src.node_features],
+                                           [synthetic.EdgeSet(e.name, torch.randn(e.features.shape, generator=gen), e.senders,
+                                                              e.receivers) for e in src.edge_sets]))
+    big = synthetic.batch(graphs)
+    graph = hgn_amd.MultiGraph([x.to(dev) for x in big.node_features],
+                               [hgn_amd.EdgeSet(e.name, e.features.to(dev), e.senders.to(dev), e.receivers.to(dev))
+                                for e in big.edge_sets])
+    N_nodes = graph.node_features[0].shape[0]
+    per = N_nodes // len(gids)
+    target = torch.randn(N_nodes, 3, generator=torch.Generator().manual_seed(gids[0])).to(dev)
+    node_type = torch.zeros(N_nodes, dtype=torch.bool)
+    for i in range(len(gids)):
+        node_type[i * per:i * per + 3] = True            # 3 HANDLE nodes per graph are masked out of the loss
+    E_graph = sum(e.senders.shape[0] for e in graph.edge_sets) // len(gids)
+    extra_sets = (f', {args.clusters} hyper nodes per graph' if args.clusters else '') + \
+        (f', {2 * args.world_edges} synthetic world edges per graph' if args.world_edges else '')
+    wl = (f'flag_simple-shape MeshGraphNets baseline: architecture {args.arch}, {args.layers} MP layers, latent 128, aggregation '
+          f'{args.agg}, 1xMI355X config; {args.nx}x{args.ny} triangulated grid per graph ({per} nodes, {E_graph} directed edges'
+          f'{extra_sets}); full training step fwd+loss+bwd+allreduce+Adam')
+    return {'graph': graph, 'target': target, 'mask': (~node_type).to(dev), 'workload': wl, 'nodes_per_graph': per,
+            'edges_per_graph': E_graph, 'cpu_graph': lambda: synthetic.grid_graph(seed=1000, nx=args.nx, ny=args.ny, clusters=args.clusters,
+                                                                                 world=args.world_edges)}
+
+
+def build_plate(args, gids, dev):
+    """deforming_plate shape through the system model itself: per frame PlateModel.build_graph (4-vertex cells ->
+    two-way mesh edges, world edges by the 0.03 radius search, plate.py:69-200) and expand_graph (obstacle removal, spectral
+    clustering once per trajectory, hetero connector: plate.py:202-216); the frames of this rank are batched into one disjoint
+    union (MeshSimulator.py:159-234 semantics, correct hyper ids).  All frames share one mesh (one trajectory), as in the
+    reference's batches."""
+    import random
+    import numpy as np
+    from hgn_amd import synthetic, system_model, batching
+    K = args.clusters or 31
+    random.seed(0); np.random.seed(0)
+    pm = system_model.PlateModel(_params(args.arch, args.agg, args.layers, 'spectral', K))
+    frames = [synthetic.plate_frame(seed=1000 + g, nx=11, ny=11, nz=11, obstacle=(6, 6, 3)) for g in gids]
+    cells = frames[0]['cells'].to(dev)
+    graphs, targets, masks = [], [], []
+    t_build = t_expand = 0.0
+    t_first_expand = None
+    for i, fr in enumerate(frames):
+        cf = {k: v.to(dev) for k, v in fr.items()}
+        cf['cells'] = cells                               # one mesh per trajectory: the topology cache is hit
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        g = pm.build_graph(cf, True)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        mg = pm.expand_graph(g, i, len(frames), True)     # step 0 clusters (host, scikit-learn), later frames reuse the clusters
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        if i == 0:
+            t_first_expand = t2 - t1
+        else:
+            t_build += t1 - t0; t_expand += t2 - t1
+        graphs.append(mg)
+        targets.append(pm.get_target(cf, True))
+        masks.append(cf['node_type'][:, 0] == 0)
+    big = batching.batch_graphs(graphs)
+    n = max(1, len(frames) - 1)
+    per = frames[0]['world_pos'].shape[0]
+    counts = {e.name: e.senders.shape[0] // len(gids) for e in big.edge_sets}
+    E_graph = sum(e.senders.shape[0] for e in big.edge_sets) // len(gids)
+    wl = (f'deforming_plate-shape HyperGraphNets (BASELINE.json configs[2], plateCluster.yaml): PlateModel frames of an 11x11x11 plate '
+          f'grid of 4-vertex cells + a 6x6x3 obstacle block ({per} nodes), mesh edges from the deform rule, world edges by the 0.03 '
+          f'radius search, spectral clustering K={K}, connector {args.arch}, {args.layers} MP layers, latent 128, aggregation {args.agg}; '
+          f'per graph on average {counts}; full training step fwd+loss+bwd+allreduce+Adam on the batched frames')
+    def cpu_graph():
+        g1 = graphs[0]
+        return synthetic.MultiGraph([x.detach().cpu() for x in g1.node_features],
+                                    [synthetic.EdgeSet(e.name, e.features.detach().cpu(), e.senders.cpu(), e.receivers.cpu()) for e in g1.edge_sets])
+    return {'graph': big, 'target': torch.cat(targets), 'mask': torch.cat(masks), 'workload': wl, 'nodes_per_graph': per,
+            'edges_per_graph': E_graph, 'cpu_graph': cpu_graph, 'model': pm.learned_model,
+            'graph_build': {'build_graph_ms_per_frame': t_build / n * 1e3, 'expand_graph_ms_per_frame': t_expand / n * 1e3,
+                            'first_expand_graph_incl_clustering_ms': t_first_expand * 1e3,
+                            'note': 'outside the timed step (the metric is fwd+bwd): PlateModel.build_graph = cells->edges (cached per mesh) + '
+                                    'radius search + features + normalisers; expand_graph = hetero remote sets on the cached clusters; the '
+                                    'first expand_graph includes obstacle removal and spectral clustering on the host (once per trajectory)'}}
+
+
+def build_cylinder(args, gids, dev):
+    """cylinder_flow shape (BASELINE.json configs[4]): CylinderModel.build_graph frames (65x29 grid: 1885 nodes, 3-dim mesh-edge
+    features, cylinder.py:65-106) + a balance edge set + the hyper connector's remote sets on K strips (the reference cannot run
+    this combination, SURVEY.md section 9-6: the sets are built by synthetic.cylinder_remote_sets)."""
+    import hgn_amd
+    from hgn_amd import synthetic, system_model
+    K = args.clusters or 16
+    cm = system_model.CylinderModel(_params('none', args.agg, 1, 'none', K))
+    graphs = []
+    for g in gids[:min(len(gids), 4)]:
+        fr = synthetic.cylinder_frame(seed=1000 + g, nx=65, ny=29)
+        mg = cm.build_graph({k: v.to(dev) for k, v in fr.items()}, True)
+        me = mg.edge_sets[0]
+        mesh = synthetic.EdgeSet('mesh_edges', me.features.detach().cpu(), me.senders.cpu(), me.receivers.cpu())
+        graphs.append(synthetic.cylinder_remote_sets(mg.node_features[0].detach().cpu(), fr['mesh_pos'], mesh, K, 100, 1000 + g))
+    while len(graphs) < len(gids):
+        src = graphs[len(graphs) % 4]
+        gen = torch.Generator().manual_seed(2000 + gids[len(graphs)])
+        graphs.append(synthetic.MultiGraph([torch.randn(x.shape, generator=gen) for x in src.node_features],
+                                           [synthetic.EdgeSet(e.name, torch.randn(e.features.shape, generator=gen), e.senders,
+                                                              e.receivers) for e in src.edge_sets]))
+    big = synthetic.batch(graphs)
+    graph = hgn_amd.MultiGraph([x.to(dev) for x in big.node_features],
+                               [hgn_amd.EdgeSet(e.name, e.features.to(dev), e.senders.to(dev), e.receivers.to(dev))
+                                for e in big.edge_sets])
+    N_nodes = graph.node_features[0].shape[0]
+    per = N_nodes // len(gids)
+    target = torch.randn(N_nodes, 3, generator=torch.Generator().manual_seed(gids[0])).to(dev)
+    mask = torch.ones(N_nodes, dtype=torch.bool, device=dev)
+    E_graph = sum(e.senders.shape[0] for e in graph.edge_sets) // len(gids)
+    wl = (f'cylinder_flow-shape HyperGraphNets (BASELINE.json configs[4]): CylinderModel frames of a 65x29 triangulated grid ({per} nodes, '
+          f'3-dim mesh-edge features) + balance set (200 directed edges) + hyper connector remote sets on K={K} strips, architecture '
+          f'{args.arch}, {args.layers} MP layers, latent 128, aggregation {args.agg}, products {args.precision} ({E_graph} directed edges per '
+          f'graph over all sets); full training step fwd+loss+bwd+allreduce+Adam')
+    return {'graph': graph, 'target': target, 'mask': mask, 'workload': wl, 'nodes_per_graph': per, 'edges_per_graph': E_graph,
+            'cpu_graph': lambda: graphs[0]}
 
 
 def spawn_ranks(args) -> int:
@@ -246,34 +399,24 @@ def main():
     ops.set_matmul_precision(args.precision)
 
     # ---- this rank's shard of the global batch: graphs {g : g mod world == rank}, each with its own seed ----------
-    B = args.batch
-    gids = parallel.shard_indices(B * world, rank, world)
-    graphs = [synthetic.grid_graph(seed=1000 + g, nx=args.nx, ny=args.ny, clusters=args.clusters, world=args.world_edges)
-              for g in gids[:min(len(gids), 4)]]
-    while len(graphs) < len(gids):                       # reuse topologies, fresh features (host generation is slow)
-        src = graphs[len(graphs) % 4]
-        gen = torch.Generator().manual_seed(2000 + gids[len(graphs)])
-        graphs.append(synthetic.MultiGraph([torch.randn(x.shape, generator=gen) for x in src.node_features],
-                                           [synthetic.EdgeSet(e.name, torch.randn(e.features.shape, generator=gen), e.senders,
-                                                              e.receivers) for e in src.edge_sets]))
-    big = synthetic.batch(graphs)
-    graph = hgn_amd.MultiGraph([x.to(dev) for x in big.node_features],
-                               [hgn_amd.EdgeSet(e.name, e.features.to(dev), e.senders.to(dev), e.receivers.to(dev))
-                                for e in big.edge_sets])
+    strong = args.global_batch > 0
+    total_graphs = args.global_batch if strong else args.batch * world
+    if strong and total_graphs % world:
+        raise SystemExit(f'--global-batch {total_graphs} is not a multiple of the {world} ranks')
+    B = total_graphs // world
+    gids = parallel.shard_indices(total_graphs, rank, world)
+    wk = {'flag': build_flag, 'plate': build_plate, 'cylinder': build_cylinder}[args.workload](args, gids, dev)
+    graph, target, mask = wk['graph'], wk['target'], wk['mask']
     N_nodes = graph.node_features[0].shape[0]
     E_rank = sum(e.senders.shape[0] for e in graph.edge_sets)
-    E_graph = E_rank // len(gids)
-    target = torch.randn(N_nodes, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
-    node_type = torch.zeros(N_nodes, dtype=torch.bool)
-    per = N_nodes // len(gids)
-    for i in range(len(gids)):
-        node_type[i * per:i * per + 3] = True            # 3 HANDLE nodes per graph are masked out of the loss
-    mask = (~node_type).to(dev)
+    E_graph, per = wk['edges_per_graph'], wk['nodes_per_graph']
 
     torch.manual_seed(0)
     sets = [e.name for e in graph.edge_sets]
-    model = hgn_amd.MeshGraphNet(output_size=3, latent_size=128, num_layers=2, message_passing_aggregator=args.agg,
-                                 message_passing_steps=args.layers, architecture=args.arch, edge_sets=sets).to(dev)
+    model = wk.get('model')                              # plate: the system model's own learned_model (built by get_model's class)
+    if model is None:
+        model = hgn_amd.MeshGraphNet(output_size=3, latent_size=128, num_layers=2, message_passing_aggregator=args.agg,
+                                     message_passing_steps=args.layers, architecture=args.arch, edge_sets=sets).to(dev)
     log(f'rank {rank}: batch built: {N_nodes} nodes, {E_rank} edges')
     with torch.no_grad():
         model(graph)                                     # materialise lazy layers, build + cache the CSR topology
@@ -361,15 +504,12 @@ def main():
     value = E_rank * world * args.steps / dt
 
     if rank == 0:
-        res = {'metric': 'processed edges/sec (fwd+bwd) on flag_simple mesh', 'value': value, 'unit': 'edges/s',
+        res = {'metric': 'processed edges/sec (fwd+bwd) on ' + {'flag': 'flag_simple mesh', 'plate': 'deforming_plate-shape graphs', 'cylinder': 'cylinder_flow-shape graphs'}[args.workload], 'value': value, 'unit': 'edges/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
                'dtype': 'f32' if args.precision == 'fp32' else args.precision + ' (reduced precision run, not the headline metric)', 'data': 'synthetic',
-               'config': {'workload': f'flag_simple-shape MeshGraphNets baseline: architecture {args.arch}, '
-                                      f'{args.layers} MP layers, latent 128, aggregation {args.agg}, 1xMI355X config; '
-                                      f'{args.nx}x{args.ny} triangulated grid per graph ({per} nodes, {E_graph} directed '
-                                      f'edges); full training step fwd+loss+bwd+allreduce+Adam',
-                          'graphs_per_gpu': B, 'global_batch': B * world, 'edges_per_step': E_rank * world,
+               'config': {'workload': wk['workload'],
+                          'graphs_per_gpu': B, 'global_batch': total_graphs, 'edges_per_step': E_rank * world,
                           'params': n_params, 'parallelism': f'dp{world}', 'loss': float(loss), 'hip_graph': bool(use_graph),
                           'ranks': dist.get_world_size() if world > 1 else 1,
                           'collective_backend': (dist.get_backend() if world > 1 else None),
@@ -465,13 +605,14 @@ def main():
                 res['roofline_aggregation'] = {'kernel': f'seg_fwd128 ({which})', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
                                                'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
                                                'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3}
+        if 'graph_build' in wk:
+            res['config']['graph_build'] = wk['graph_build']
         if cold is not None:
             res['cold_step'] = cold
         if world == 1 and not args.no_secondary:
             res['secondary'] = secondary_configs(args)
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(args, synthetic.grid_graph(seed=1000, nx=args.nx, ny=args.ny, clusters=args.clusters,
-                                                                          world=args.world_edges))
+            res['cpu_baseline'] = cpu_baseline(args, wk['cpu_graph'](), model.state_dict())
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -492,19 +492,26 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   fa.A[1] = w->z1; fa.ldA[1] = 128;
   fa.slabs = (float*)workspace;
   fa.tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
-  static const int dbg = getenv("HGN_FUSED_DBG") ? atoi(getenv("HGN_FUSED_DBG")) : 0;
-  fa.dbg = dbg;
+  fa.dbg = 0;
   ProfScope ps(14, (double)a->M, stream);
   if (bwd_products() == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
-  else switch (dbg) {                                   // diagnostic instantiations: one ablation each
-    case 2: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 2>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-    case 4: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 4>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-    case 8: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 8>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-    case 12: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 12>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-    case 16: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 16>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-    case 32: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 32>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-    case 63: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 63>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-    default: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  else {
+#if HGN_LAB   // laboratory build only: compile-time ablation instantiations (HGN_FUSED_DBG), one ablation each
+    static const int dbg = getenv("HGN_FUSED_DBG") ? atoi(getenv("HGN_FUSED_DBG")) : 0;
+    fa.dbg = dbg;
+    switch (dbg) {
+      case 2: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 2>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+      case 4: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 4>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+      case 8: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 8>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+      case 12: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 12>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+      case 16: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 16>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+      case 32: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 32>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+      case 63: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 63>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
+      default: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+    }
+#else
+    hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+#endif
   }
   if (hgn_check_launch("hgn_edge_bwd_fused") != HGN_OK) return HGN_E_LAUNCH;
   // fixed-order sums of the per-workgroup partials: three weight gradients + biases, and the LayerNorm-affine gradients

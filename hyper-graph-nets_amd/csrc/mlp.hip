@@ -276,9 +276,11 @@ using namespace hgn;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// weight-stationary edge forward (csrc/ws_fwd.hip): HGN_WS_FWD=1 or hgn_set_ws_fwd(1)
+#if HGN_LAB   // laboratory build only (tools/lab): the weight-stationary edge forward, HGN_WS_FWD=1 or hgn_set_ws_fwd(1)
+extern "C" int hgn_mlp_fwd_ws_eligible(const hgn_mlp_fwd_t* a);
 static int g_ws_fwd = getenv("HGN_WS_FWD") ? 1 : 0;
 extern "C" int hgn_set_ws_fwd(int on) { g_ws_fwd = on ? 1 : 0; return HGN_OK; }
+#endif
 
 #ifdef HGN_STAMP
 extern "C" int hgn_debug_set_flags(int f) {
@@ -310,7 +312,9 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
   if (a->seg_out && (!a->seg_ids || a->out_w != 128 || a->ld_seg_out < 128 || !hgn_mlp_fwd6_eligible(a)))
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: seg_out needs seg_ids, a 128-wide output and the split-bf16 kernel");
+#if HGN_LAB
   if (g_ws_fwd && hgn_mlp_fwd_ws_eligible(a)) return launch_ws_fwd(a, stream);
+#endif
   if (hgn_mlp_fwd6_eligible(a)) return launch_mlp6_fwd(a, stream);
   hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   return hgn_check_launch("hgn_mlp_fwd");

@@ -379,31 +379,34 @@ extern "C" int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* a) {
 }
 
 namespace hgn {
-// HGN_TILE128 (diagnostic): two sub-tiles per wave, 128-row workgroups at 2 waves / SIMD.  Half the weight DMA and operand reads
-// per row, but measured no faster in the product (edge forward 1.18 vs 1.21 ms, backward 1.37 vs 1.34 ms at 1.19 M rows) and
-// worse on small launches (half as many workgroups), so the 64-row kernels stay the default.
+// Forward launches of at least FWD128_MIN_ROWS rows: 128-row workgroups (two sub-tiles per wave, 2 workgroups per CU) -- half the
+// weight DMA, LDS operand reads, waits and barriers per row; edge forward 1.156 -> 1.141 ms, whole step 66.2 -> 65.6 ms at 1.19 M
+// rows, same bits.  (The backward is 4 % SLOWER that way, small launches lose workgroups: both keep 64-row tiles.)
+constexpr long FWD128_MIN_ROWS = 192L * 256 * 2;
+#if HGN_LAB
+// ---- laboratory build only (tools/lab/build_lab.sh; never in the shipped library) --------------------------------------------
+// HGN_TILE128: two sub-tiles per wave in ALL fused MLP launches (measured no faster: forward 1.18 vs 1.21 ms, backward 1.37 vs 1.34
+// ms at 1.19 M rows).  HGN_DIAG_LDS_PAD=bytes: extra dynamic LDS per workgroup (2 or 1 workgroups per CU).  HGN_BIG_TILES /
+// hgn_set_big_tiles: 12-wave workgroups on 192-row tiles (a third of the weight DMA; bit-identical, 1.241 vs 1.231 ms).
 static bool tile128() { static const bool v = getenv("HGN_TILE128") != nullptr; return v; }
-// diagnostic: extra dynamic LDS per workgroup, to see the kernels at 2 or 1 workgroups per CU (HGN_DIAG_LDS_PAD=bytes)
 static unsigned lds_pad() { static const unsigned v = getenv("HGN_DIAG_LDS_PAD") ? (unsigned)atoi(getenv("HGN_DIAG_LDS_PAD")) : 0u; return v; }
-
-// 12-wave workgroups on 192-row tiles (mlp6_fwd_kernel<1, NP, 12>; HGN_BIG_TILES=1 or hgn_set_big_tiles(1)), for launches of at
-// least big_min_rows() rows.  Diagnostic, like HGN_TILE128: a third of the weight DMA, half the barriers and DMA waits per block,
-// bit-identical results -- and the same time (edge forward 1.241 vs 1.231 ms at 1.19 M rows, profiles/r02_edge_kernel_ablation.log).
 static int g_big_tiles = getenv("HGN_BIG_TILES") ? 1 : 0;
-static long big_min_rows() {             // below 2 tiles per CU a 192-row grid leaves CUs idle (HGN_BIG_MIN_ROWS overrides: tests)
-  static const long v = getenv("HGN_BIG_MIN_ROWS") ? atol(getenv("HGN_BIG_MIN_ROWS")) : 192L * 256 * 2;
-  return v;
-}
+static long big_min_rows() { static const long v = getenv("HGN_BIG_MIN_ROWS") ? atol(getenv("HGN_BIG_MIN_ROWS")) : FWD128_MIN_ROWS; return v; }
+static bool tile128_fwd() { static const bool v = getenv("HGN_NO_TILE128_FWD") == nullptr; return v; }
+#else
+static constexpr bool tile128() { return false; }
+static constexpr unsigned lds_pad() { return 0u; }
+static constexpr long big_min_rows() { return FWD128_MIN_ROWS; }
+static constexpr bool tile128_fwd() { return true; }
+#endif
 }  // namespace hgn
+#if HGN_LAB
 extern "C" int hgn_set_big_tiles(int on) { hgn::g_big_tiles = on ? 1 : 0; return HGN_OK; }
+#endif
 namespace hgn {
 
-// Forward launches of at least big_min_rows() rows: 128-row workgroups (two sub-tiles per wave, 2 workgroups per CU) -- half the
-// weight DMA, LDS operand reads, waits and barriers per row; edge forward 1.156 -> 1.141 ms, whole step 66.2 -> 65.6 ms at 1.19 M
-// rows, same bits.  (The backward is 4 % SLOWER that way, small launches lose workgroups: both keep 64-row tiles.)  HGN_NO_TILE128_FWD=1: off.
-static bool tile128_fwd() { static const bool v = getenv("HGN_NO_TILE128_FWD") == nullptr; return v; }
-
 int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
+#if HGN_LAB
   if (g_big_tiles && !tile128() && a->M >= big_min_rows()) {
     const long tiles = (a->M + 191) / 192;
     if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
@@ -411,6 +414,7 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
   }
+#endif
   if ((tile128() || (tile128_fwd() && a->M >= big_min_rows())) && matmul_products() == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
     hipLaunchKernelGGL((mlp6_fwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);

@@ -261,6 +261,7 @@ __device__ __forceinline__ void split3v(const float (&v)[8], bf16x8 (&s)[3]) {
   }
 }
 
+#if HGN_LAB   // the previous split-bf16 weight-gradient kernel: laboratory build only (HGN_WGRAD_RESPLIT=1)
 __global__ __launch_bounds__(WGW, 2) void wgrad6_kernel(const WArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[NS * 2 * DT * 128];      // [slot][A|G][16][128] = 64 KB, NS = 4
   const WTaskDev t = a.t[a.task0 + blockIdx.y];
@@ -351,6 +352,8 @@ __global__ __launch_bounds__(WGW, 2) void wgrad6_kernel(const WArgs a) {
   __syncthreads();
   if (threadIdx.x < 128) slab[128 * 128 + threadIdx.x] = lds[threadIdx.x] + lds[128 + threadIdx.x];
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Split-bf16 weight gradients, every value split ONCE: the two operand tiles of a 32-row contraction block (A and G, 32 x 128
@@ -618,9 +621,12 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
       hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
     } else {                                    // split-bf16 products: 32-row contraction blocks
       wa.rows_per_chunk = rows_per(nch0, 2 * DT);
-      static const bool resplit = getenv("HGN_WGRAD_RESPLIT") != nullptr;     // the previous kernel, kept for comparison
+#if HGN_LAB
+      static const bool resplit = getenv("HGN_WGRAD_RESPLIT") != nullptr;     // the previous kernel, laboratory build only
       if (resplit) hipLaunchKernelGGL(wgrad6_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
-      else if (bwd_products() == 1) hipLaunchKernelGGL(wgrad6s_kernel<1>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+      else
+#endif
+      if (bwd_products() == 1) hipLaunchKernelGGL(wgrad6s_kernel<1>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
       else hipLaunchKernelGGL(wgrad6s_kernel<6>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
     }
   }

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# HGN_LIB: diagnostic builds of the same C-ABI (tools/build_ablations.sh); never set in production
+# HGN_LIB: laboratory / diagnostic builds of the same C-ABI (tools/lab/build_lab.sh, tools/build_ablations.sh); never set in production
 LIB_PATH = os.environ.get('HGN_LIB') or os.path.join(_HERE, 'libhgn_mp.so')
 
 HGN_MAX_SRC = 8
@@ -93,9 +93,6 @@ _SIGS = {
     'hgn_set_matmul_products': (C.c_int, [C.c_int]),
     'hgn_get_matmul_products': (C.c_int, []),
     'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
-    'hgn_mlp_fwd_ws_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
-    'hgn_set_ws_fwd': (C.c_int, [C.c_int]),
-    'hgn_set_big_tiles': (C.c_int, [C.c_int]),
     'hgn_linear_fwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
     'hgn_mlp_bwd6_eligible': (C.c_int, [C.POINTER(MlpBwd)]),

@@ -36,13 +36,6 @@ def set_fused_edge_backward(on) -> None:
     _FUSED_EDGE_BWD = _FUSED_EDGE_BWD_DEFAULT if on is None else bool(on)
 
 
-def set_ws_edge_forward(on: bool) -> None:
-    """True: eligible edge-block forwards run the weight-stationary kernel (csrc/ws_fwd.hip: the three layers' weights in registers,
-    activations through LDS, no weight traffic per tile); False (default): the staged-weights kernel.  Opt-in (or HGN_WS_FWD=1):
-    measured 1.43 ms against 1.29 ms at 1.19 M rows."""
-    _lib.check(_lib.lib().hgn_set_ws_fwd(1 if on else 0), 'hgn_set_ws_fwd')
-
-
 _PRODUCTS = {'fp32': 6, 'bf16': 1, 'fp16': 2}
 
 

@@ -164,6 +164,40 @@ def cylinder_frame(seed: int = 0, nx: int = 30, ny: int = 20, dtype=torch.float3
             'pressure': torch.randn(N, 1, generator=g, dtype=dtype)}
 
 
+def cylinder_remote_sets(nodes: torch.Tensor, pos: torch.Tensor, mesh_set: EdgeSet, K: int, n_balance: int, seed: int) -> MultiGraph:
+    """BASELINE.json configs[4] shape on top of a cylinder_flow frame's mesh graph: a `balance` edge set (what the graph balancer
+    appends, abstract_graph_balancer.py:48-63) and the three remote sets + hyper-node rows of the `hyper` connector
+    (hierarchical_connector.py:85-137), K clusters as contiguous strips along x.  The reference cannot produce this combination
+    (cylinder + any clustering or balancer fails in its normalisers), so the sets are built here from
+    the frame's 2-D positions with the cylinder feature rule (relative mesh position + norm, cylinder.py:85-87).
+    ``nodes`` / ``mesh_set``: the normalised node features [N,6] and mesh edge set of CylinderModel.build_graph (host)."""
+    N = pos.shape[0]
+    gen = torch.Generator().manual_seed(seed)
+
+    def norm(x):
+        return (x - x.mean(0)) / x.std(0).clamp(min=1e-8)
+
+    def rel(a, b):
+        d = a - b
+        return torch.cat([d, d.norm(dim=-1, keepdim=True)], -1)
+    lab = (pos[:, 0] / (pos[:, 0].max() + 1e-6) * K).long().clamp(max=K - 1)
+    cm_pos = torch.stack([pos[lab == c].mean(0) for c in range(K)])
+    hyper = torch.stack([torch.cat([nodes[lab == c].mean(0), torch.tensor([float((lab == c).sum())]),
+                                    (pos[lab == c] - cm_pos[c]).norm(dim=-1).max().reshape(1)]) for c in range(K)])
+    ids, hyp = torch.arange(N), N + lab
+    a = torch.arange(K - 1)
+    cs, cr = torch.cat([a, a + 1, torch.tensor([0, K - 1])]), torch.cat([a + 1, a, torch.tensor([K - 1, 0])])
+    bs = torch.randint(0, N, (n_balance,), generator=gen)
+    br = (bs + 1 + torch.randint(0, N - 1, (n_balance,), generator=gen)) % N
+    b_s, b_r = torch.cat([bs, br]), torch.cat([br, bs])
+    sets = [mesh_set,
+            EdgeSet('balance', norm(rel(pos[b_s], pos[b_r])), b_s, b_r),
+            EdgeSet('intra_cluster_to_mesh', norm(rel(cm_pos[lab], pos)), hyp, ids),
+            EdgeSet('intra_cluster_to_cluster', norm(rel(pos, cm_pos[lab])), ids, hyp),
+            EdgeSet('inter_cluster', norm(rel(cm_pos[cs], cm_pos[cr])), N + cs, N + cr)]
+    return MultiGraph([nodes, norm(hyper)], sets)
+
+
 def _grid_tets(nx: int, ny: int, nz: int, offset: int = 0) -> torch.Tensor:
     """4-vertex cells of an nx x ny x nz node grid: five tetrahedra per cube."""
     def nid(i, j, k):

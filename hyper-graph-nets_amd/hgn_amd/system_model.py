@@ -28,7 +28,11 @@ def _masked_mse(target: Tensor, output: Tensor, mask: Tensor) -> Tensor:
 
 
 class AbstractSystemModel(nn.Module):
-    """abstract_system_model.py:10-190 (the shared constructor logic of flag.py:21-63 / cylinder.py:21-63 lives here)."""
+    """The reference's system-model base (abstract_system_model.py:10-190) together with the constructor logic its three
+    subclasses repeat (flag.py:21-63, cylinder.py:21-63, plate.py:21-67): normalisers, the optional graph balancer and remote
+    message passing stages, and the learned MeshGraphNet over the resulting edge-set names.  Attribute names that the
+    reference's trainer / pickles touch (`learned_model`, `_*_normalizer`, `_rmp`, `_balancer`, `_remote_graph`,
+    `_graph_balancer`, `message_passing_steps`, ...) are kept."""
     _model_type = None
 
     def __init__(self, params, node_size: int, edge_size: int, remote_edge_size: int = 7,
@@ -36,22 +40,25 @@ class AbstractSystemModel(nn.Module):
         super().__init__()
         self._params = params
         self.loss_fn = torch.nn.MSELoss()
-        self._output_normalizer = Normalizer(size=3, name='output_normalizer')
-        self._node_normalizer = Normalizer(size=node_size, name='node_normalizer')
-        self._node_dynamic_normalizer = Normalizer(size=1, name='node_dynamic_normalizer')
-        self._mesh_edge_normalizer = Normalizer(size=edge_size, name='mesh_edge_normalizer')
-        self._intra_edge_normalizer = Normalizer(size=remote_edge_size, name='intra_edge_normalizer')
-        self._inter_edge_normalizer = Normalizer(size=remote_edge_size, name='inter_edge_normalizer')
-        self._hyper_node_normalizer = Normalizer(size=3, name='hyper_node_normalizer')
-        r, b = params.get('rmp'), params.get('graph_balancer')
-        self._rmp = r.get('clustering') != 'none' and r.get('connector') != 'none'
-        self._architecture = self._select_architecture(r.get('connector'))
-        self._multi = r.get('connector') == 'multigraph' and self._rmp
-        self._balancer = b.get('algorithm') != 'none'
+        for attr, (width, name) in {'_output_normalizer': (3, 'output_normalizer'),
+                                    '_node_normalizer': (node_size, 'node_normalizer'),
+                                    '_node_dynamic_normalizer': (1, 'node_dynamic_normalizer'),
+                                    '_mesh_edge_normalizer': (edge_size, 'mesh_edge_normalizer'),
+                                    '_intra_edge_normalizer': (remote_edge_size, 'intra_edge_normalizer'),
+                                    '_inter_edge_normalizer': (remote_edge_size, 'inter_edge_normalizer'),
+                                    '_hyper_node_normalizer': (3, 'hyper_node_normalizer')}.items():
+            setattr(self, attr, Normalizer(size=width, name=name))
+        remote_cfg, balance_cfg = params.get('rmp'), params.get('graph_balancer')
+        connector = remote_cfg.get('connector')
+        # a stage is on unless its YAML entry says 'none' (flag.py:30-35)
+        self._rmp = 'none' not in (remote_cfg.get('clustering'), connector)
+        self._balancer = balance_cfg.get('algorithm') != 'none'
+        self._multi = self._rmp and connector == 'multigraph'
+        self._architecture = self._select_architecture(connector)
+        self._rmp_frequency = remote_cfg.get('frequency')
+        self._balance_frequency = balance_cfg.get('frequency')
         self.message_passing_steps = params.get('message_passing_steps')
         self.message_passing_aggregator = params.get('aggregation')
-        self._balance_frequency = b.get('frequency')
-        self._rmp_frequency = r.get('frequency')
         self._visualized = False
         self._edge_sets = list(edge_sets)
         if self._balancer:
@@ -60,8 +67,8 @@ class AbstractSystemModel(nn.Module):
             self._edge_sets.append('balance')
         if self._rmp:
             self._remote_graph = _rmp.get_rmp(params)
-            self._edge_sets += self._remote_graph.initialize(
-                self._intra_edge_normalizer, self._inter_edge_normalizer, self._hyper_node_normalizer)
+            self._edge_sets.extend(self._remote_graph.initialize(
+                self._intra_edge_normalizer, self._inter_edge_normalizer, self._hyper_node_normalizer))
         self.learned_model = MeshGraphNet(
             output_size=params.get('size'), latent_size=128, num_layers=2,
             message_passing_steps=self.message_passing_steps,
@@ -84,14 +91,22 @@ class AbstractSystemModel(nn.Module):
             self._cells_key, self._cells_edges = cells, (s.contiguous(), r.contiguous())
         return self._cells_edges
 
+    @staticmethod
+    def _refresh_due(step: int, num_steps: int, frequency) -> bool:
+        """A stage configured with `frequency` f recomputes its once-per-period state (balance edges / clusters) at the steps
+        that are multiples of ceil(num_steps / f): f = 1 -> only at step 0 of a trajectory."""
+        return step % math.ceil(num_steps / frequency) == 0
+
     def expand_graph(self, graph: MultiGraphWithPos, step: int, num_steps: int, is_training: bool) -> MultiGraph:
-        """flag.py:130-141 / cylinder.py:108-119."""
+        """The optional stages between build_graph and the network, in the reference's order (flag.py:130-141,
+        cylinder.py:108-119, plate.py:202-216): graph balancer first (appends the `balance` edge set, renormalises the mesh
+        edges), then remote message passing (hyper nodes + remote edge sets)."""
         if self._balancer:
-            if step % math.ceil(num_steps / self._balance_frequency) == 0:
+            if self._refresh_due(step, num_steps, self._balance_frequency):
                 self._graph_balancer.reset_balancer()
             graph = self._graph_balancer.create_graph(graph, self._mesh_edge_normalizer, is_training)
         if self._rmp:
-            if step % math.ceil(num_steps / self._rmp_frequency) == 0:
+            if self._refresh_due(step, num_steps, self._rmp_frequency):
                 self._remote_graph.reset_clusters()
             graph = self._remote_graph.create_graph(graph, is_training)
         return graph
@@ -100,20 +115,34 @@ class AbstractSystemModel(nn.Module):
         return self.learned_model(graph)
 
     def evaluate(self) -> None:
-        self.eval()
-        self.learned_model.eval()
+        """abstract_system_model.py:187-190."""
+        for module in (self, self.learned_model):
+            module.eval()
+
+    # ---- evaluation helpers shared by the three models ------------------------------------------------------------
+    @staticmethod
+    def _first_frame(trajectory: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """Frame 0 of every series of a (possibly batch-of-one) trajectory, on the device."""
+        return {name: torch.squeeze(series, 0)[0].to(device) for name, series in trajectory.items()}
+
+    @staticmethod
+    def _per_step_mse(truth: Tensor, predicted: Tensor) -> Tensor:
+        """[T, N, D] x 2 -> [T]: squared error averaged over components, then over nodes (the reference's two nested means)."""
+        return ((truth - predicted) ** 2).mean(dim=-1).mean(dim=-1).detach()
 
     @torch.no_grad()
     def n_step_computation(self, trajectory: Dict[str, Tensor], n_step: int, num_timesteps=None) -> Tuple[Tensor, Tensor]:
-        """flag.py:248-260."""
-        mse_losses, last_losses = [], []
-        num_timesteps = trajectory['cells'].shape[0] if num_timesteps is None else num_timesteps
-        for step in range(num_timesteps - n_step):
-            eval_traj = {k: v[step: step + n_step + 1] for k, v in trajectory.items()}
-            _, mse_loss = self.rollout(eval_traj, n_step + 1)
-            mse_losses.append(torch.mean(mse_loss).cpu())
-            last_losses.append(mse_loss.cpu()[-1])
-        return torch.mean(torch.stack(mse_losses)), torch.mean(torch.stack(last_losses))
+        """Sliding n-step rollouts (flag.py:248-260): every window of n_step + 1 consecutive frames is rolled out from its
+        first frame; returns (mean over windows of the window's mean error, mean over windows of its final-step error)."""
+        horizon = n_step + 1
+        frames = trajectory['cells'].shape[0] if num_timesteps is None else num_timesteps
+        window_means, window_finals = [], []
+        for start in range(frames - n_step):
+            window = {name: series[start:start + horizon] for name, series in trajectory.items()}
+            errors = self.rollout(window, horizon)[1].cpu()
+            window_means.append(errors.mean())
+            window_finals.append(errors[-1])
+        return torch.stack(window_means).mean(), torch.stack(window_finals).mean()
 
 
 class FlagModel(AbstractSystemModel):
@@ -216,33 +245,28 @@ class FlagModel(AbstractSystemModel):
     @torch.no_grad()
     def rollout(self, trajectory: Dict[str, Tensor], num_steps: int) -> Tuple[Dict[str, Tensor], Tensor]:
         """flag.py:192-225."""
-        num_steps = trajectory['cells'].shape[0] if num_steps is None else num_steps
-        initial_state = {k: torch.squeeze(v, 0)[0].to(device) for k, v in trajectory.items()}
-        mask = torch.eq(initial_state['node_type'][:, 0], NodeType.NORMAL.value)
-        mask = torch.stack((mask, mask, mask), dim=1)
-        prev_pos = initial_state['prev|world_pos']
-        cur_pos = initial_state['world_pos']
-        pred_trajectory = []
-        for i in range(num_steps):
-            prev_pos, cur_pos, pred_trajectory = self._step_fn(initial_state, prev_pos, cur_pos, pred_trajectory, mask, i)
+        if num_steps is None:
+            num_steps = trajectory['cells'].shape[0]
+        start = self._first_frame(trajectory)
+        free = self._loss_mask(start).unsqueeze(1).expand(-1, 3)        # NORMAL nodes move; HANDLE nodes keep their position
+        prev_pos, cur_pos, visited = start['prev|world_pos'], start['world_pos'], []
+        for step in range(num_steps):
+            prev_pos, cur_pos, visited = self._step_fn(start, prev_pos, cur_pos, visited, free, step)
         self._visualized = False
-        predictions = torch.stack(pred_trajectory)
-        traj_ops = {'faces': trajectory['cells'], 'mesh_pos': trajectory['mesh_pos'], 'gt_pos': trajectory['world_pos'],
-                    'pred_pos': predictions}
-        gt = trajectory['world_pos'][:num_steps].to(device)
-        mse_loss = torch.mean(torch.mean((gt - predictions) ** 2, dim=-1), dim=-1).detach()
-        return traj_ops, mse_loss
+        predictions = torch.stack(visited)
+        errors = self._per_step_mse(trajectory['world_pos'][:num_steps].to(device), predictions)
+        return {'faces': trajectory['cells'], 'mesh_pos': trajectory['mesh_pos'], 'gt_pos': trajectory['world_pos'],
+                'pred_pos': predictions}, errors
 
     @torch.no_grad()
     def _step_fn(self, initial_state, prev_pos, cur_pos, trajectory, mask, step):
         """flag.py:227-246."""
-        inputs = {**initial_state, 'prev|world_pos': prev_pos, 'world_pos': cur_pos}
-        graph = self.build_graph(inputs, is_training=False)
-        graph = self.expand_graph(graph, step, 399, is_training=False)
-        prediction = self.update(inputs, self(graph))
-        next_pos = torch.where(mask, prediction, cur_pos)
-        trajectory.append(cur_pos)
-        return cur_pos, next_pos, trajectory
+        frame = dict(initial_state)
+        frame.update({'prev|world_pos': prev_pos, 'world_pos': cur_pos})
+        graph = self.expand_graph(self.build_graph(frame, is_training=False), step, 399, is_training=False)   # 399: flag.py:236
+        integrated = self.update(frame, self(graph))
+        trajectory.append(cur_pos)                              # the trajectory records the state BEFORE the step
+        return cur_pos, torch.where(mask, integrated, cur_pos), trajectory
 
 
 class CylinderModel(AbstractSystemModel):
@@ -304,35 +328,28 @@ class CylinderModel(AbstractSystemModel):
     @torch.no_grad()
     def rollout(self, trajectory: Dict[str, Tensor], num_steps: int):
         """cylinder.py:175-208."""
-        initial_state = {k: torch.squeeze(v, 0)[0].to(device) for k, v in trajectory.items()}
-        num_steps = trajectory['cells'].shape[0]
-        t = initial_state['node_type'][:, 0]
-        mask = torch.logical_or(torch.eq(t, NodeType.NORMAL.value), torch.eq(t, NodeType.OUTFLOW.value))
-        mask = torch.stack((mask, mask), dim=1)
-        velocity, pressure = initial_state['velocity'], initial_state['pressure']
-        pred_trajectory, pred_pressure = [], []
+        num_steps = trajectory['cells'].shape[0]                          # the whole trajectory, whatever was asked (cylinder.py:178)
+        start = self._first_frame(trajectory)
+        free = self._loss_mask(start).unsqueeze(1).expand(-1, 2)        # NORMAL and OUTFLOW nodes are integrated, the rest is prescribed
+        velocity, pressure, velocities, pressures = start['velocity'], start['pressure'], [], []
         for step in range(num_steps):
-            velocity, pressure, pred_trajectory, pred_pressure = self._step_fn(
-                initial_state, velocity, pressure, pred_trajectory, pred_pressure, step, mask)
-        prediction, pressure = torch.stack(pred_trajectory), torch.stack(pred_pressure)
-        traj_ops = {'faces': trajectory['cells'], 'mesh_pos': trajectory['mesh_pos'],
-                    'gt_velocity': trajectory['velocity'], 'gt_pressure': trajectory['pressure'],
-                    'pred_pressure': pressure, 'pred_velocity': prediction}
-        gt = trajectory['velocity'][:num_steps].to(device)
-        mse_loss = torch.mean(torch.mean((gt - prediction) ** 2, dim=-1), dim=-1).detach()
-        return traj_ops, mse_loss
+            velocity, pressure, velocities, pressures = self._step_fn(start, velocity, pressure, velocities, pressures, step, free)
+        pred_velocity = torch.stack(velocities)
+        errors = self._per_step_mse(trajectory['velocity'][:num_steps].to(device), pred_velocity)
+        return {'faces': trajectory['cells'], 'mesh_pos': trajectory['mesh_pos'], 'gt_velocity': trajectory['velocity'],
+                'gt_pressure': trajectory['pressure'], 'pred_pressure': torch.stack(pressures), 'pred_velocity': pred_velocity}, errors
 
     @torch.no_grad()
     def _step_fn(self, initial_state, velocity, pressure, trajectory, pressure_trajectory, step, mask):
         """cylinder.py:210-230."""
-        inputs = {**initial_state, 'velocity': velocity, 'pressure': pressure}
-        graph = self.build_graph(inputs, is_training=False)
-        graph = self.expand_graph(graph, step, 598, is_training=False)
-        prediction, pred_pressure = self.update(inputs, self(graph))
-        next_velocity = torch.where(mask, prediction, velocity)
-        trajectory.append(next_velocity)
-        pressure_trajectory.append(pred_pressure)
-        return next_velocity, pred_pressure, trajectory, pressure_trajectory
+        frame = dict(initial_state)
+        frame.update({'velocity': velocity, 'pressure': pressure})
+        graph = self.expand_graph(self.build_graph(frame, is_training=False), step, 598, is_training=False)   # 598: cylinder.py:218
+        integrated, new_pressure = self.update(frame, self(graph))
+        new_velocity = torch.where(mask, integrated, velocity)
+        trajectory.append(new_velocity)                         # here the state AFTER the step is recorded
+        pressure_trajectory.append(new_pressure)
+        return new_velocity, new_pressure, trajectory, pressure_trajectory
 
 
 class PlateModel(AbstractSystemModel):
@@ -414,42 +431,37 @@ class PlateModel(AbstractSystemModel):
     @torch.no_grad()
     def rollout(self, trajectory: Dict[str, Tensor], num_steps: int):
         """plate.py:266-316."""
-        num_steps = trajectory['cells'].shape[0] if num_steps is None else num_steps
-        initial_state = {k: torch.squeeze(v, 0)[0].to(device) for k, v in trajectory.items()}
-        node_type = initial_state['node_type']
-        mask = torch.eq(node_type[:, 0], NodeType.NORMAL.value)
-        mask = torch.stack((mask, mask, mask), dim=1)
-        cur_pos = initial_state['world_pos']
-        target_pos = trajectory['target|world_pos'].to(device)
-        pred_trajectory, cur_positions, cur_velocities = [], [], []
+        if num_steps is None:
+            num_steps = trajectory['cells'].shape[0]
+        start = self._first_frame(trajectory)
+        free = self._loss_mask(start).unsqueeze(1).expand(-1, 3)        # NORMAL nodes are predicted; obstacle / handle nodes are scripted
+        scripted = trajectory['target|world_pos'].to(device)
+        position, predicted, positions, velocities = start['world_pos'], [], [], []
         for step in range(num_steps):
-            cur_pos, pred_trajectory, cur_positions, cur_velocities = self._step_fn(
-                initial_state, cur_pos, pred_trajectory, cur_positions, cur_velocities, target_pos[step], step, mask,
-                num_steps)
-        prediction, cur_positions, cur_velocities = (torch.stack(pred_trajectory), torch.stack(cur_positions),
-                                                     torch.stack(cur_velocities))
-        faces = trajectory['cells']                      # tetrahedra -> triangles for the viewer (plate.py:289-297)
-        faces_result = torch.stack([torch.cat((f[:, 0:3], torch.cat((f[:, 2:4], f[:, 0:1]), -1)), 0) for f in faces], 0)
-        traj_ops = {'faces': faces_result, 'mesh_pos': trajectory['mesh_pos'],
-                    'mask': torch.eq(node_type[:, 0], NodeType.OBSTACLE.value), 'gt_pos': trajectory['world_pos'],
-                    'pred_pos': prediction, 'cur_positions': cur_positions, 'cur_velocities': cur_velocities}
-        gt = trajectory['world_pos'][:num_steps].to(device)
-        mse_loss = torch.mean(torch.mean((gt - prediction) ** 2, dim=-1), dim=-1).detach()
-        return traj_ops, mse_loss
+            position, predicted, positions, velocities = self._step_fn(start, position, predicted, positions, velocities,
+                                                                       scripted[step], step, free, num_steps)
+        pred_pos = torch.stack(predicted)
+        errors = self._per_step_mse(trajectory['world_pos'][:num_steps].to(device), pred_pos)
+        # the viewer wants triangles: every 4-vertex cell (v0 v1 v2 v3) contributes (v0 v1 v2) and (v2 v3 v0)   plate.py:289-297
+        cells = trajectory['cells']
+        triangles = torch.cat((cells[..., 0:3], cells[..., [2, 3, 0]]), dim=-2)
+        return {'faces': triangles, 'mesh_pos': trajectory['mesh_pos'],
+                'mask': torch.eq(start['node_type'][:, 0], NodeType.OBSTACLE.value), 'gt_pos': trajectory['world_pos'],
+                'pred_pos': pred_pos, 'cur_positions': torch.stack(positions), 'cur_velocities': torch.stack(velocities)}, errors
 
     @torch.no_grad()
     def _step_fn(self, initial_state, cur_pos, trajectory, cur_positions, cur_velocities, target_world_pos, step, mask,
                  num_steps):
         """plate.py:318-340."""
-        inputs = {**initial_state, 'world_pos': cur_pos, 'target|world_pos': target_world_pos}
-        graph = self.build_graph(inputs, is_training=False)
-        graph = self.expand_graph(graph, step, num_steps, is_training=False)
-        prediction, cur_position, cur_velocity = self.update(inputs, self(graph))
-        next_pos = torch.where(mask, prediction, target_world_pos)
-        trajectory.append(next_pos)
-        cur_positions.append(cur_position)
-        cur_velocities.append(cur_velocity)
-        return next_pos, trajectory, cur_positions, cur_velocities
+        frame = dict(initial_state)
+        frame.update({'world_pos': cur_pos, 'target|world_pos': target_world_pos})
+        graph = self.expand_graph(self.build_graph(frame, is_training=False), step, num_steps, is_training=False)
+        integrated, position_before, velocity = self.update(frame, self(graph))
+        new_pos = torch.where(mask, integrated, target_world_pos)       # scripted nodes follow the prescribed motion
+        trajectory.append(new_pos)
+        cur_positions.append(position_before)
+        cur_velocities.append(velocity)
+        return new_pos, trajectory, cur_positions, cur_velocities
 
 
 def get_model(config) -> AbstractSystemModel:

@@ -164,13 +164,6 @@ int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* strea
 int hgn_set_matmul_products(int n /* 6, 1 or 2 */);
 int hgn_get_matmul_products(void);
 int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd will take the split-bf16 kernel */
-/* 1 if the arguments have the edge-block shape of the weight-stationary forward (csrc/ws_fwd.hip: one 128-wide ungathered source,
- * <= 2 gathered pre-projections, LayerNorm, packed weights, six products): the kernel hgn_mlp_fwd then takes for it. */
-int hgn_mlp_fwd_ws_eligible(const hgn_mlp_fwd_t* args /*host*/);
-/* Diagnostic (initial value: environment HGN_BIG_TILES set): 1 = forward launches of >= 98 304 rows run the split-bf16 MLP kernel as
- * 12-wave workgroups on 192-row tiles (one 96 KB weight stage per CU instead of three 48 KB ones).  Same results bit for bit, same speed. */
-int hgn_set_big_tiles(int on);
-int hgn_set_ws_fwd(int on);        /* process-wide switch of that kernel (initial value: environment HGN_WS_FWD set) */
 int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
                     float* out, int64_t ld_out, void* stream);
 

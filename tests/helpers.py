@@ -172,3 +172,55 @@ class GateTransfer:
     def __exit__(self, *exc):
         O.mlp, torch.relu = self._mlp, self._relu
         return False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Conditioning of a test instance, measured on an fp64 oracle run: distance from a ReLU kink / from a max-min tie.
+# ------------------------------------------------------------------------------------------------------------------
+class KinkMargin:
+    """Smallest |x| over every ReLU input of an fp64 oracle run (the distance of the instance from a ReLU kink)."""
+
+    def __enter__(self):
+        self.worst = float('inf')
+        self._orig = torch.relu
+
+        def probe(x):
+            if x.numel():
+                self.worst = min(self.worst, float(x.detach().abs().min()))
+            return self._orig(x)
+        torch.relu = probe
+        return self
+
+    def __exit__(self, *exc):
+        torch.relu = self._orig
+        return False
+
+
+class TieMargin:
+    """Records, over every max/min aggregation of an fp64 oracle run, the smallest lead of a segment's winner over its
+    runner-up (relative to the largest magnitude of that aggregation's input)."""
+
+    def __enter__(self):
+        self.worst = float('inf')
+        self._orig = O.segment_reduce
+
+        def probe(data, segment_ids, num_segments, operation, return_arg=False):
+            if operation in ('max', 'min') and data.dim() == 2 and data.shape[0] > 0:
+                d = (data if operation == 'max' else -data).detach().double()
+                ids = segment_ids.long()
+                idx = ids.unsqueeze(1).expand_as(d)
+                m1 = torch.full((num_segments, d.shape[1]), float('-inf'), dtype=d.dtype).scatter_reduce(0, idx, d, 'amax')
+                top = d == m1[ids]
+                ties = torch.zeros(num_segments, d.shape[1], dtype=d.dtype).scatter_add(0, idx, top.double())
+                m2 = torch.full_like(m1, float('-inf')).scatter_reduce(0, idx, d.masked_fill(top, float('-inf')), 'amax')
+                gap = torch.where(ties > 1, torch.zeros_like(m1), m1 - m2)
+                gap = gap[torch.isfinite(gap)]
+                if gap.numel():
+                    self.worst = min(self.worst, float(gap.min() / d.abs().max().clamp(min=1e-30)))
+            return self._orig(data, segment_ids, num_segments, operation, return_arg)
+        O.segment_reduce = probe
+        return self
+
+    def __exit__(self, *exc):
+        O.segment_reduce = self._orig
+        return False

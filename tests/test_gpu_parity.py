@@ -276,53 +276,6 @@ def test_edge_block_fused_segment_sums(N, max_deg, seed):
         assert H.rel_err(a, b) <= 5e-6
 
 
-_VARIANT_SNIPPET = r"""
-import sys, torch
-sys.path.insert(0, {root!r}); sys.path.insert(0, {pkg!r})
-from hgn_amd import ops, topology
-from tests import synth
-from tests.test_gpu_parity import _mlp_sd, _weights
-g = synth.grid_graph(seed=5, nx=30, ny=17)
-es = g.edge_sets[0]
-N, E = 30 * 17, es.senders.shape[0]
-topo = topology.EdgeTopology(es.senders, es.receivers, N, torch.device('cuda'))
-w, wts = _weights(_mlp_sd(384, 128, True, seed=5), True)
-wn, wnts = _weights(_mlp_sd(256, 128, True, seed=6), True)
-gen = torch.Generator().manual_seed(9)
-h = torch.randn(N, 128, generator=gen).cuda().requires_grad_(True)
-e = torch.randn(E, 128, generator=gen).cuda().requires_grad_(True)
-y, agg = ops.edge_block(h, e, topo, w, ('sum',))
-hn = ops.fused_mlp([h, agg], wn, None, 0)
-(hn.square().sum() + y.square().sum()).backward()
-torch.save([t.detach().cpu() for t in [y, agg, hn, h.grad, e.grad] + [p.grad for p in wts + wnts]], {out!r})
-"""
-
-
-def test_kernel_variants_behind_environment_switches(tmp_path):
-    """The diagnostic kernel variants kept in the library (HGN_TILE128: two sub-tiles per wave; HGN_WGRAD_RESPLIT: the previous
-    weight-gradient kernel; HGN_BIG_TILES: 12-wave workgroups on 192-row tiles) compute the same function as the defaults: one child process per setting (the switches are read
-    once per process), edge block + node MLP forward / backward compared with the default build of the same inputs."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pkg = os.path.join(root, 'hyper-graph-nets_amd')
-    outs = {}
-    for name, env in (('default', {}), ('tile128', {'HGN_TILE128': '1'}), ('resplit', {'HGN_WGRAD_RESPLIT': '1'}), ('big', {'HGN_BIG_TILES': '1', 'HGN_BIG_MIN_ROWS': '1'})):
-        out = str(tmp_path / (name + '.pt'))
-        code = _VARIANT_SNIPPET.format(root=root, pkg=pkg, out=out)
-        r = subprocess.run([sys.executable, '-c', code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs[name] = torch.load(out)
-    for a, b in zip(outs['default'], outs['tile128']):
-        assert H.rel_err(a, b) <= 1e-6
-    for a, b in zip(outs['default'][:5], outs['tile128'][:5]):
-        assert torch.equal(a, b)                               # same arithmetic per row, only the tiling differs
-    for a, b in zip(outs['default'], outs['resplit']):
-        assert H.rel_err(a, b) <= 1e-6
-    for a, b in zip(outs['default'], outs['big']):         # 12-wave workgroups on 192-row tiles (forward): the same bits
-        assert torch.equal(a, b)
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # a4 + whole model: goldens generated by the reference, and oracle parity for every block type
 # ---------------------------------------------------------------------------------------------------------------
@@ -374,53 +327,7 @@ CASES = [
 ]
 
 
-class _KinkMargin:
-    """Smallest |x| over every ReLU input of an fp64 oracle run (the distance of the instance from a ReLU kink)."""
-
-    def __enter__(self):
-        self.worst = float('inf')
-        self._orig = torch.relu
-
-        def probe(x):
-            if x.numel():
-                self.worst = min(self.worst, float(x.detach().abs().min()))
-            return self._orig(x)
-        torch.relu = probe
-        return self
-
-    def __exit__(self, *exc):
-        torch.relu = self._orig
-        return False
-
-
-class _TieMargin:
-    """Records, over every max/min aggregation of an fp64 oracle run, the smallest lead of a segment's winner over its
-    runner-up (relative to the largest magnitude of that aggregation's input)."""
-
-    def __enter__(self):
-        self.worst = float('inf')
-        self._orig = O.segment_reduce
-
-        def probe(data, segment_ids, num_segments, operation, return_arg=False):
-            if operation in ('max', 'min') and data.dim() == 2 and data.shape[0] > 0:
-                d = (data if operation == 'max' else -data).detach().double()
-                ids = segment_ids.long()
-                idx = ids.unsqueeze(1).expand_as(d)
-                m1 = torch.full((num_segments, d.shape[1]), float('-inf'), dtype=d.dtype).scatter_reduce(0, idx, d, 'amax')
-                top = d == m1[ids]
-                ties = torch.zeros(num_segments, d.shape[1], dtype=d.dtype).scatter_add(0, idx, top.double())
-                m2 = torch.full_like(m1, float('-inf')).scatter_reduce(0, idx, d.masked_fill(top, float('-inf')), 'amax')
-                gap = torch.where(ties > 1, torch.zeros_like(m1), m1 - m2)
-                gap = gap[torch.isfinite(gap)]
-                if gap.numel():
-                    self.worst = min(self.worst, float(gap.min() / d.abs().max().clamp(min=1e-30)))
-            return self._orig(data, segment_ids, num_segments, operation, return_arg)
-        O.segment_reduce = probe
-        return self
-
-    def __exit__(self, *exc):
-        O.segment_reduce = self._orig
-        return False
+_KinkMargin, _TieMargin = H.KinkMargin, H.TieMargin      # (instance conditioning probes: tests/helpers.py)
 
 
 @pytest.mark.parametrize('arch,agg,steps,sets,gkw', CASES, ids=[f'{c[0]}-{c[1]}-L{c[2]}-S{len(c[3])}' for c in CASES])
@@ -1003,32 +910,8 @@ def _config4_graph(nx, ny, K, n_balance, seed):
     nodes = g.node_features[0].detach().cpu()
     me = g.edge_sets[0]
     assert me.features.shape[1] == 3                                            # cylinder: rel mesh pos (2) + norm
-    pos = fr['mesh_pos']
-    N = pos.shape[0]
-    gen = torch.Generator().manual_seed(seed)
-
-    def norm(x):
-        return (x - x.mean(0)) / x.std(0).clamp(min=1e-8)
-
-    def rel(a, b):
-        d = a - b
-        return torch.cat([d, d.norm(dim=-1, keepdim=True)], -1)
-    lab = (pos[:, 0] / (pos[:, 0].max() + 1e-6) * K).long().clamp(max=K - 1)
-    cm_pos = torch.stack([pos[lab == c].mean(0) for c in range(K)])
-    hyper = torch.stack([torch.cat([nodes[lab == c].mean(0), torch.tensor([float((lab == c).sum())]),
-                                    (pos[lab == c] - cm_pos[c]).norm(dim=-1).max().reshape(1)]) for c in range(K)])
-    ids, hyp = torch.arange(N), N + lab
-    a = torch.arange(K - 1)
-    cs, cr = torch.cat([a, a + 1, torch.tensor([0, K - 1])]), torch.cat([a + 1, a, torch.tensor([K - 1, 0])])
-    bs = torch.randint(0, N, (n_balance,), generator=gen)
-    br = (bs + 1 + torch.randint(0, N - 1, (n_balance,), generator=gen)) % N
-    b_s, b_r = torch.cat([bs, br]), torch.cat([br, bs])
-    sets = [synth.EdgeSet('mesh_edges', me.features.detach().cpu(), me.senders.cpu(), me.receivers.cpu()),
-            synth.EdgeSet('balance', norm(rel(pos[b_s], pos[b_r])), b_s, b_r),
-            synth.EdgeSet('intra_cluster_to_mesh', norm(rel(cm_pos[lab], pos)), hyp, ids),
-            synth.EdgeSet('intra_cluster_to_cluster', norm(rel(pos, cm_pos[lab])), ids, hyp),
-            synth.EdgeSet('inter_cluster', norm(rel(cm_pos[cs], cm_pos[cr])), N + cs, N + cr)]
-    return synth.MultiGraph([nodes, norm(hyper)], sets)
+    mesh = synth.EdgeSet('mesh_edges', me.features.detach().cpu(), me.senders.cpu(), me.receivers.cpu())
+    return synth.cylinder_remote_sets(nodes, fr['mesh_pos'], mesh, K, n_balance, seed)
 
 
 @pytest.mark.parametrize('steps', [1, 25])
@@ -1268,39 +1151,3 @@ def test_failed_backward_leaves_no_stale_weight_gradient_tasks():
     assert not ops._wq
     torch.cuda.synchronize()
     assert torch.equal(tr.fp.grad, good)
-
-
-@pytest.mark.parametrize('nx,ny,agg', [(7, 5, 'sum'), (40, 40, 'sum'), (120, 100, 'sum'), (23, 17, 'pna')])
-def test_weight_stationary_edge_forward_equals_staged_forward(nx, ny, agg):
-    """csrc/ws_fwd.hip (opt-in: weights of the three edge-MLP layers resident in registers, activations through LDS) against the
-    staged-weights kernel it can replace, through the same autograd function: outputs, aggregates and every gradient (the
-    backward reads the activations / sign words the forward saved) to fp32 rounding -- the first layer adds its bias and gathered
-    pre-projections after the products instead of before, so not bit for bit -- and against the fp64 oracle at the usual
-    tolerances.  Sizes: fewer tiles than workgroups, more, and a ragged last tile; pna: no in-kernel segment sums."""
-    import hgn_amd
-    from hgn_amd import ops
-    graph = synth.grid_graph(seed=4, nx=nx, ny=ny)
-    shapes = O.param_shapes('none', agg, 2, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128)
-    sd = O.init_state_dict_like(shapes, seed=13)
-    N = nx * ny
-    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(4))
-    mask = torch.ones(N, dtype=torch.bool); mask[:2] = False
-    model = H.hip_model('none', agg, 2, ['mesh_edges'], sd)
-    res = {}
-    for ws in (True, False):
-        ops.set_ws_edge_forward(ws)
-        try:
-            res[ws] = H.hip_run(model, graph, target, mask)
-        finally:
-            ops.set_ws_edge_forward(False)
-    (out_w, loss_w, g_w, ig_w), (out_s, loss_s, g_s, ig_s) = res[True], res[False]
-    assert H.rel_err(out_w, out_s) <= 2e-6
-    for kname in g_s:
-        if float(g_s[kname].abs().max()) > 0:
-            # (a ReLU sign flips where |z| is at rounding level -- both results are valid -- and a flipped unit changes its
-            #  row's gradient by O(1): a handful of rows in 72 000 move a weight gradient by up to 1e-4 of its norm)
-            assert H.rel_err(g_w[kname], g_s[kname]) <= 2e-4, kname
-    out_o, _, g_o, _ = H.oracle_run(sd, graph, 'none', agg, target, mask) if agg == 'sum' and N <= 400 else (None, None, None, None)
-    if out_o is not None:
-        assert H.rel_err(out_w, out_o) <= TOL_OUT
-        assert max(H.rel_err(g_w[kname], g_o[kname]) for kname in g_o if float(g_o[kname].abs().max()) > 0) <= TOL_GRAD
