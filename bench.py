@@ -111,7 +111,7 @@ def secondary_configs(args):
                          ['--workload', 'plate', '--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31']),
                         ('cylinder_flow_shape_hyper_pna_L25_balance_fp16_products',
                          ['--workload', 'cylinder', '--arch', 'hyper', '--agg', 'pna', '--layers', '25', '--clusters', '16',
-                          '--precision', 'fp16']),
+                          '--precision', 'fp16', '--batch', '32']),       # (25 layers of saved activations next to the parent's buffers)
                         ('flag_grid_40x40_with_plate_edge_set_structure_hetero_pna_L5_K31',
                          ['--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31', '--world-edges', '300'])):
         try:

@@ -31,9 +31,12 @@ class FlatParams:
 
     def __init__(self, module: nn.Module):
         params = [p for p in module.parameters() if p.requires_grad]
-        for p in params:
-            if isinstance(p, nn.parameter.UninitializedParameter):
-                raise RuntimeError('materialise the lazy layers (run one forward) before flattening')
+        lazy = [p for p in params if isinstance(p, nn.parameter.UninitializedParameter)]
+        if lazy and not any(isinstance(m, nn.Linear) and not isinstance(m, nn.modules.lazy.LazyModuleMixin) for m in module.modules()):
+            raise RuntimeError('materialise the lazy layers (run one forward) before flattening')
+        # still lazy after a forward: modules the block schedule never calls (e.g. the `balance` edge model under a hyper block,
+        # hypergraphnet.py:54 keeps only its five sets).  They have no gradient and no storage: left alone.
+        params = [p for p in params if not isinstance(p, nn.parameter.UninitializedParameter)]
         self.params = params
         # every parameter starts on a 16-byte boundary: the kernels read biases / LayerNorm affine vectors as float4
         self.offsets = []

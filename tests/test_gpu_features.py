@@ -356,47 +356,57 @@ def test_plate_training_step_end_to_end_against_oracle(obstacle_first):
     -> training_step (hetero block over mesh / world / up / down / inter sets, pna, 2 MP layers) -> masked loss and ALL parameter
     gradients, against the fp64 oracle with the same weights and the same cluster labels.
 
-    Two oracles.  (A) the whole chain in fp64: the features feeding the model carry the cancellation noise of the reference's
-    fp32 `E[x^2] - mean^2` normaliser formula (1e-5 .. 2e-4 on near-constant columns), so the bound is 3x the distance of the
-    reference's OWN fp32 chain (the oracle in fp32) from fp64, floor 2e-5.  (B) the model part alone at the usual tolerances:
-    the fp64 oracle fed the very feature tensors the HIP feature kernels produced -- loss <= 1e-5, gradients <= 2e-5 norm-wise
-    on an instance without an fp32-level ReLU kink or max/min tie (seed search on the oracle, as in test_model_vs_oracle)."""
-    from hgn_amd import system_model
+    ReLU gates: of the ~3 M ReLU inputs of this instance a few sit within fp32 rounding of zero on every seed; ONE gate that falls
+    the other way than in fp64 moves the weight gradients it feeds by 1e-3..1e-2 (the reference's own fp32 does the same at other
+    positions, tests/test_gpu_parity.py: test_headline_graph_40x40_L15_vs_oracle_fp64).  So the oracle runs with the gates the HIP
+    forward chose (tests/helpers.py: GateTransfer; they may differ from fp64's own only at |pre-activation| <= 1e-5), and the
+    max / min winners must lead by more than fp32 rounding (seed search on the oracle, as in test_model_vs_oracle).
+
+    Two statements.  (B) the model part at the usual tolerances: fp64 oracle fed the very feature tensors the HIP feature kernels
+    produced -- loss <= 1e-5, gradients <= 2e-5 norm-wise.  (A) the whole chain in fp64: the features feeding the model carry the
+    cancellation noise of the reference's fp32 `E[x^2] - mean^2` normaliser formula (1e-5 .. 2e-4 on near-constant columns), so
+    the bound is 3x the distance of the reference's OWN fp32 chain (the oracle in fp32, same gates) from fp64, floor 2e-5."""
+    import random
+    import numpy as np
+    from hgn_amd import ops, system_model
     from tests import helpers as H
     arch, agg = 'hetero', 'pna'
-    mask_cpu = None
     for seed in range(31, 45):
         fr = synth.plate_frame(seed=seed, obstacle_first=obstacle_first)
-        import random
-        import numpy as np
         random.seed(0); np.random.seed(0); torch.manual_seed(seed)
         model = system_model.PlateModel(dict(plate_params(arch, 4), message_passing_steps=2, aggregation=agg))
         cf = cuda_frame(fr)
         g = model.build_graph(cf, True)
         mg = model.expand_graph(g, 0, 10, True)
-        loss = model.training_step(mg, cf)
+        ops._GATE_LOG = []
+        try:
+            loss = model.training_step(mg, cf)
+            gate_log = ops._GATE_LOG
+        finally:
+            ops._GATE_LOG = None
         loss.backward()
         rmp = model._remote_graph
         nb = [tuple(t.tolist()) for t in rmp._neighbors]
         sd = {k: v.detach().cpu() for k, v in model.learned_model.state_dict().items()}
         mask_cpu = fr['node_type'][:, 0] == 0
-        order = list(model.learned_model.processor.graphnet_blocks[0].set_order) \
-            if hasattr(model.learned_model.processor.graphnet_blocks[0], 'set_order') else None
+        order = list(model.learned_model.processor.graphnet_blocks[0].set_order)
+        gates = H.hip_gates(model.learned_model, gate_log)
 
         def chain(dtype):
             pf = FO.PlateFeatures(dtype=dtype)
             o = pf.build_graph(fr, True)
             m = FO.hierarchical_connect(o, rmp._clusters, nb, pf.intra_edge, pf.inter_edge, pf.hyper_node, True)
             return m, pf.get_target(fr, True)
-        m64, t64 = chain(torch.float64)
-        # (B) model part on the HIP-built features; well-conditioned instance: every max/min winner leads by more than fp32 rounding
+        # (B) model part on the HIP-built features
         hip_graph = O.MultiGraph([x.detach().cpu() for x in mg.node_features],
                                  [O.EdgeSet(e.name, e.features.detach().cpu(), e.senders.cpu(), e.receivers.cpu()) for e in mg.edge_sets])
         target_hip = model.get_target(cf, False).cpu()
-        with H.TieMargin() as tm, H.KinkMargin() as km:
+        with H.TieMargin() as tm, H.GateTransfer(gates) as gt:
             out_b, loss_b, grads_b, _ = H.oracle_run(sd, hip_graph, arch, agg, target_hip, mask_cpu, set_order=order)
-        if tm.worst > 2e-6 and km.worst > 1e-6:
+        if tm.worst > 2e-6:                              # every max / min winner leads by more than fp32 rounding
             break
+    assert gt.flipped <= 50 and gt.max_abs_at_flip <= 1e-5, (gt.flipped, gt.total, gt.max_abs_at_flip)
+    m64, t64 = chain(torch.float64)
     assert [e.name for e in mg.edge_sets] == [e.name for e in m64.edge_sets]
     assert all(torch.equal(a.senders.cpu(), b.senders) and torch.equal(a.receivers.cpu(), b.receivers)
                for a, b in zip(mg.edge_sets, m64.edge_sets))
@@ -410,17 +420,21 @@ def test_plate_training_step_end_to_end_against_oracle(obstacle_first):
     for k in grads_b:                                   # (the last hetero block's hyper-row update feeds nothing: zero in both)
         if k not in live:
             assert float(grads[k].abs().max()) == 0, k
-    # (A) whole chain against fp64, bounded by the reference's own fp32 chain
-    _, loss_a, grads_a, _ = H.oracle_run(sd, m64, arch, agg, t64, mask_cpu, set_order=order)
+    # (A) whole chain against fp64, bounded by the reference's own fp32 chain (all three with the same gates)
+    with H.GateTransfer(gates):
+        _, loss_a, grads_a, _ = H.oracle_run(sd, m64, arch, agg, t64, mask_cpu, set_order=order)
     m32, t32 = chain(torch.float32)
-    _, loss_r, grads_r, _ = H.oracle_run(sd, m32, arch, agg, t32, mask_cpu, set_order=order, dtype=torch.float32)
+    with H.GateTransfer(gates):
+        _, loss_r, grads_r, _ = H.oracle_run(sd, m32, arch, agg, t32, mask_cpu, set_order=order, dtype=torch.float32)
     ref_noise = max(H.rel_err(grads_r[k], grads_a[k]) for k in live)
     worst_a = max((H.rel_err(grads[k], grads_a[k]), k) for k in live)
-    assert abs(float(loss) - float(loss_a)) <= max(2e-5, 3 * abs(float(loss_r) - float(loss_a)) / abs(float(loss_a))) * abs(float(loss_a))
+    ref_loss_noise = abs(float(loss_r) - float(loss_a)) / abs(float(loss_a))
+    assert abs(float(loss) - float(loss_a)) <= max(2e-5, 3 * ref_loss_noise) * abs(float(loss_a)), (float(loss), float(loss_a), ref_loss_noise)
     assert worst_a[0] <= max(2e-5, 3 * ref_noise), (worst_a, ref_noise)
     H._REPORT.append({'test': f'test_plate_training_step_end_to_end_against_oracle[{"first" if obstacle_first else "last"}]',
-                      'what': 'param grads (worst tensor)', 'model_part_norm': worst_b[0], 'whole_chain_norm': worst_a[0],
-                      'ref_fp32_whole_chain_norm': ref_noise, 'seed': seed})
+                      'what': 'param grads (worst tensor), HIP gates transferred', 'model_part_norm': worst_b[0],
+                      'whole_chain_norm': worst_a[0], 'ref_fp32_whole_chain_norm': ref_noise, 'seed': seed,
+                      'gates': gt.total, 'gates_differing_from_fp64': gt.flipped})
 
 
 def test_radius_edges_against_brute_force():
