@@ -1,53 +1,122 @@
 // Edge-block backward with the weight gradients IN THE SAME PASS (include/hgn_mp.h: hgn_edge_bwd_fused).
+// Semantics: autograd of GraphNet._update_edge_features (src/migration/graphnet.py:22-32) -- LayerNorm backward -> W3^T -> relu'
+// -> W2^T -> relu' -> W1e^T + residual -- plus dW3 = dz3^T z2, dW2 = dz2^T z1, their bias sums and the LayerNorm-affine gradients.
 //
-// Why.  The separate kernels hand dz3 / dz2 / dz1 from the data-gradient chain (csrc/mlp6.hip: mlp6_bwd_kernel) to the weight-
-// gradient kernel (csrc/wgrad.hip: wgrad6s_kernel) through HBM: 1.5 KB per edge row written, 3 KB read back, of the ~10.6 KB
-// per edge and layer the whole step moved -- and both kernels were bound by exactly that row traffic.  Here dz3 / dz2 never
-// leave the chip: 3.6 KB per row (read d(e'), x-hat, z2, z1, e; write de, dz1) instead of 6.1 KB for the two launches.
+// Why one pass.  The separate kernels hand dz3 / dz2 from the data-gradient chain (csrc/mlp6.hip: mlp6_bwd_kernel) to the weight-
+// gradient kernel (csrc/wgrad.hip: wgrad6s_kernel) through HBM: 1 KB per edge row written and read back.  Here they never leave
+// the chip: 3.1 KB per row (read d(e'), x-hat, z2, z1, sign words; write de, dz1) instead of 5.6 KB for the two launches.
 //
-// How.  One PERSISTENT 8-wave workgroup per CU walks a contiguous range of 64-row tiles:
-//   waves 0-3  "chain":   the data-gradient chain of mlp6_bwd_kernel for 16 rows each (LayerNorm backward -> W3^T -> relu' ->
-//                         W2^T -> relu' -> W1e^T + residual), packed weights staged half a block at a time by LDS-DMA.  The
-//                         3-way bf16 split of dz3 / dz2 / dz1 that each product needs anyway is ALSO written to LDS as the
-//                         "G" operand of the weight gradients: eight consecutive rows of one feature = one bf16x8 vector.
-//   waves 4-7  "wgrad":   keep dW3, dW2, dW1e (3 x 128 x 128 fp32 = 192 accumulator registers per lane) for the whole row
-//                         range; per layer they load the 64 rows of the other operand (z2 / z1 / e) from HBM, split them
-//                         once, publish them as "A" operand vectors and run dW += G^T A on v_mfma_f32_16x16x32_bf16
-//                         (contraction over rows, six products, as in wgrad6s_kernel).
-// Every SIMD hosts one wave of each kind; both follow the SAME barrier sequence (4 per layer: stage free / half landed / stage
-// free / half landed), so the matrix pipe runs the chain's product for layer l and the weight gradient of layer l side by
-// side, and the chain's weight-DMA waits coincide with the wgrad waves' row loads and splits.
-// LDS: 48 KB weight stage + 48 KB G vectors + 48 KB A vectors + 4 KB LayerNorm partials = 148 KB of the CU's 160 KB.
+// Structure (second version; the first one -- tools/lab/fused_bwd_v1.hip -- staged half a weight block at a time and waited for
+// every one of its six DMAs per tile with the chain idle: 1.57 ms per launch at 1.19 M rows, the parts of the tile time ADDED UP).
+// One PERSISTENT 8-wave workgroup per CU walks a contiguous range of 64-row tiles:
+//   waves 0-3  "chain":  the data-gradient chain for 16 rows each.  The 3-way bf16 split of dz3 / dz2 that each product needs
+//                        anyway is also written to LDS as the "G" operand of the weight gradients (eight consecutive rows of
+//                        one feature = one bf16x8 vector).  They issue no weight DMA and wait for none: a barrier tells them
+//                        that the piece they are about to read has landed.
+//   waves 4-7  "wgrad":  keep dW3 and dW2 (2 x 128 x 128 fp32 = 128 accumulator registers per lane) for the whole row range;
+//                        load the rows of the other operand (z2 / z1) one layer ahead, split them once, publish them as "A"
+//                        operand vectors (32 rows at a time) and run dW += G^T A on v_mfma_f32_16x16x32_bf16 (six products,
+//                        contraction over rows).  They also run the WEIGHT RING: the packed transposed weights stream through
+//                        three 24 KB LDS slots (one contraction block of 32 features each: [split][output block][lane][8]) in
+//                        the fixed order W3^T, W2^T, W1e^T, W3^T, ... -- 12 pieces per tile, piece p + 2 issued (LDS-DMA, 6 per
+//                        wave) at the barrier that opens piece p, i.e. two product phases ahead of its use, and retired by a
+//                        COUNTED s_waitcnt vmcnt(N) in front of the barrier that opens piece p itself.  The DMA is issued from
+//                        inline assembly: the compiler neither tracks it nor drains it at its own waits.
+// Twelve phases per tile, one barrier each (as many as the first version had), none of them behind an exposed DMA:
+//   phase            0            1            2            3          4 .. 7 (layer 2, the same)      8 .. 11 (layer 1)
+//   chain   G(3) rows 32-63,   piece 1      piece 2      piece 3,     ...                             pieces only; next tile's
+//           piece 0                                      then dz2,                                    rows prefetched
+//                                                        split, G(2) rows 0-31
+//   wgrad   A(z2) rows 0-31    dW3 rows     A(z2) rows   dW3 rows     ...                             ring only
+//           published          0-31         32-63        32-63
+// so the matrix pipe runs the chain's products and the weight gradients side by side, the chain's VALU stretches (LayerNorm
+// backward, ReLU masks, splits) lie beside the second weight-gradient block of the previous layer, and the HBM rows of both roles
+// are in flight one layer (wgrad) or one tile (chain) ahead of their use.
+// LDS: 72 KB ring + 48 KB G vectors (64 rows) + 24 KB A vectors (32 rows) + 4.5 KB LayerNorm partials / weights = 148.5 KB.
 // Per-workgroup partial results go to slabs that the existing fixed-order reductions add (deterministic, no float atomics).
 #include <cstdlib>
+#include <type_traits>
 #include "hgn_device.h"
 #include "hgn_host.h"
 #include "mlp_common.h"
 #include "mlp6_device.h"
 
+// Diagnostic build only (-DHGN_FUSED_STAMPS, tools/fusedstamps.py): shader-clock stamps of one mid-launch workgroup's waves 0 (chain),
+// 4 and 6 (weight gradients) at every phase boundary of its 11th tile.  In the shipped library FSTAMP() is empty.
+#ifdef HGN_FUSED_STAMPS
+namespace hgn { __device__ unsigned long long g_fstamps[3 * 64]; }
+#define FSTAMP(role, idx)                                                                                      \
+  do {                                                                                                         \
+    if (blockIdx.x == 37 && (threadIdx.x & 63) == 0 && tile == t_beg + 10) g_fstamps[(role) * 64 + (idx)] = clock64(); \
+  } while (0)
+#else
+#define FSTAMP(role, idx) do {} while (0)
+#endif
+
 namespace hgn {
 
-constexpr int FT = 512;                         // threads: 8 waves
-constexpr int OPS64 = 3 * 8 * 128;              // bf16x8 vectors of one operand array of a 64-row tile: [split][row group][feature]
-constexpr int FSLAB = 128 * 128 + 128;          // floats per (workgroup, layer): dW partial + bias partial (= wgrad.hip SLAB)
-constexpr int FUSED_LDS = HALF_BF16 * 2 + 2 * OPS64 * 16 + 4 * 256 * 4;
+constexpr int FT = 512;                               // threads: 8 waves
+constexpr int PIECE_BYTES = 3 * 8 * 1024;             // one contraction block of a packed block: [split][output block][lane][8 bf16]
+constexpr int RING_BYTES = 3 * PIECE_BYTES;           // 72 KB
+constexpr int G_BYTES = 3 * 8 * 128 * 16;             // [split][row group 0..7][feature] bf16x8: 64 rows, 48 KB
+constexpr int A_BYTES = 3 * 4 * 128 * 16;             // [split][row group 0..3][feature] bf16x8: 32 rows, 24 KB
+constexpr int G_OFF = RING_BYTES, A_OFF = G_OFF + G_BYTES, LN_OFF = A_OFF + A_BYTES, LNG_OFF = LN_OFF + 4 * 256 * 4;
+constexpr int FUSED_LDS = LNG_OFF + 128 * 4;
+constexpr int FSLAB = 128 * 128 + 128;                // floats per (workgroup, layer): dW partial + bias partial (= wgrad.hip SLAB)
+static_assert(FUSED_LDS <= 160 * 1024, "one workgroup per CU");
 
 struct FusedArgs {
-  hgn_mlp_bwd_t b;                              // the data-gradient chain (n_dx == 1, residual, LayerNorm, ReLU sign words)
-  const float* A[2]; long ldA[2];               // other operand of dW3, dW2: z2, z1
-  float* slabs;                                 // [gridDim.x][2][FSLAB]
-  long tiles;                                   // 64-row tiles
-  int dbg;                                      // diagnostic ablations (HGN_FUSED_DBG): 1 no G writes, 2 no A publish, 4 no chain MFMA,
-                                                // 8 no wgrad MFMA, 16 no weight DMA, 32 no row loads in the LayerNorm prologue
+  hgn_mlp_bwd_t b;                                    // the data-gradient chain (n_dx == 1, residual, LayerNorm, ReLU sign words)
+  const float* A[2];                                  // other operand of dW3, dW2: z2, z1 (row stride 128)
+  float* slabs;                                       // [gridDim.x][2][FSLAB]
+  long tiles;                                         // 64-row tiles
 };
 
-__device__ __forceinline__ void bar_lds() {     // every wave's LDS traffic issued so far is complete; global traffic stays in flight
+__device__ __forceinline__ void bar_lds() {           // every wave's LDS traffic issued so far is complete; global traffic stays in flight
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
-__device__ __forceinline__ void bar_all() {     // ... and this wave's global loads / LDS-DMA have landed
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+// ... and all but this wave's KEEP most recently issued vector-memory operations have completed (they retire in order)
+template <int KEEP>
+__device__ __forceinline__ void bar_keep() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
   __builtin_amdgcn_s_barrier();
+}
+
+template <int KEEP>
+__device__ __forceinline__ void wait_keep() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
+}
+
+__device__ __forceinline__ unsigned opaque(unsigned v) {      // one per-lane base register + immediates, never a register per address
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// The LDS-DMA of one ring piece by one wgrad wave (global_load_lds_dwordx4: lane l copies 16 bytes from sbase + voff(l) to M0 + 16 l;
+// 1 KiB per instruction), issued from ONE inline-assembly statement so that it stays outside the compiler's s_waitcnt bookkeeping
+// (the compiler would drain it at its next wait) and costs three instructions per KiB.  Wave ww of the four copies operand tiles
+// i = ww + 4 k, k = 0..5, i.e. split k / 2, output block ww + 4 (k & 1): in the packed block those lie (16 (k / 2) + 4 (k & 1)) KiB
+// behind tile (split 0, output block ww), in the ring slot 4 k KiB.  M0 (the DMA's LDS base) is compiler-reserved and not assumed
+// to survive an asm statement; it is written in the statement that reads it.  s_add_u32 writes SCC: declared, or the compiler keeps
+// a scalar compare result live across the statement (it did: one clamped row index per fetch came out wrong).  Completion: a
+// counted vmcnt of the issuing wave, then a barrier.
+template <int NP>
+__device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: source of tile (0, ww)*/, unsigned voff /*16 * lane*/,
+                                           unsigned lds_dst /*wave-uniform: LDS byte address of tile (0, ww) in the slot*/) {
+  unsigned t;
+  if (NP == 1)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
+                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+  else
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x4000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x5000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x8000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x9000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
+                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc");
 }
 
 __device__ __forceinline__ void split3v8(const float (&v)[8], bf16x8 (&s)[3]) {
@@ -61,18 +130,10 @@ __device__ __forceinline__ void split3v8(const float (&v)[8], bf16x8 (&s)[3]) {
   }
 }
 
-// The chain lane (row n of wave `wave`, feature quarter kq) publishes its split values as G operand: vector (split, row group
-// 2*wave + n/8, feature), element n%8.
-// (Every LDS address below is ONE per-lane base register, made opaque to the optimiser, plus a compile-time offset below the
-// 64 KB reach of the DS instructions' immediate field -- left alone, the compiler materialises a register per (split, block,
-// feature block) combination of the 148 KB image and spills them.)
-__device__ __forceinline__ unsigned opaque(unsigned v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
+// The chain lane (row n of chain wave `wave`, feature quarter kq) publishes its split values as G operand: vector (split, row
+// group 2 * wave + n / 8, feature), element n % 8.  `gbase`: the lane's base inside the G image (see the kernel).
 template <int NP>
-__device__ __forceinline__ void write_gops(unsigned char* __restrict__ gbase /*lane base inside the G image*/, const bf16x8 (&xs)[3][4]) {
+__device__ __forceinline__ void write_gops(unsigned char* __restrict__ gbase, const bf16x8 (&xs)[3][4]) {
   __bf16* gb = reinterpret_cast<__bf16*>(gbase);
 #pragma unroll
   for (int s = 0; s < (NP == 1 ? 1 : 3); ++s)
@@ -85,23 +146,66 @@ __device__ __forceinline__ void write_gops(unsigned char* __restrict__ gbase /*l
       }
 }
 
-// dW_layer += G^T A over the 32 rows of block `blk` of the tile; wave ww owns dW rows [32 ww, 32 ww + 32).
-// The A vectors of feature block nb + 1 are read while block nb multiplies (double-buffered; the sched_barriers keep the compiler
-// from sinking the reads to their use, where every block would start with an exposed LDS round trip).
-template <int NP>
+// acc[ob] += (piece of the packed block: contraction block C) * x, six products per output block, in the order of mfma_half6_sb
+// of the first version and of csrc/mlp6_device.h (smallest terms first; per accumulator c = 0..3 in sequence): the same bits.
+// The fragments of output block ob + 1 are read while block ob multiplies (scheduling barriers keep the reads where they are
+// written: at this kernel's register budget the unconstrained scheduler hoists dozens of fragment reads and then spills).
+template <int C, int NP>
+__device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], const unsigned char* __restrict__ lp /*slot + 16 lane*/) {
+  // two output blocks at a time (two independent accumulation chains), the SIX fragments of the next pair read before the
+  // current pair's twelve products are issued: 192 matrix-pipe cycles between a ds_read_b128 and its use (one block ahead, 96
+  // cycles, left an exposed LDS round trip of 100-300 cycles per block: the sweeps ran at half the matrix rate)
+  constexpr int NSP = NP == 1 ? 1 : 3;
+  bf16x8 fr[2][2][3];
+  auto load_pair = [&](int g, bf16x8 (&f)[2][3]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) f[k][s] = *reinterpret_cast<const bf16x8*>(lp + (s * 8 + 2 * g + k) * 1024);
+  };
+  load_pair(0, fr[0]);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g + 1 < 4) load_pair(g + 1, fr[(g + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 (&a)[2][3] = fr[g & 1];               // a[k][0] hi, [1] mid, [2] lo of output block 2 g + k
+    f32x4 t0 = acc.v[2 * g], t1 = acc.v[2 * g + 1];
+    if (NP == 1) {
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], xs[0][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], xs[0][C], t1, 0, 0, 0);
+    } else {
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][2], xs[0][C], t0, 0, 0, 0);      // smallest terms first
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][2], xs[0][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], xs[2][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], xs[2][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], xs[1][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], xs[1][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], xs[0][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], xs[0][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], xs[1][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], xs[1][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], xs[0][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], xs[0][C], t1, 0, 0, 0);
+    }
+    acc.v[2 * g] = t0; acc.v[2 * g + 1] = t1;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// dW_layer += G^T A over the 32 rows of block `blk` of the tile; wgrad wave ww owns dW rows [32 ww, 32 ww + 32).
+// G: the 64-row image (row groups 4 blk .. 4 blk + 3), A: the 32-row image.  The A vectors of feature block nb + 1 are read while
+// block nb multiplies.
+template <int NP, int STAMP = 0>
 __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], const bf16x8* __restrict__ gp /*lane base: G image*/,
-                                            const bf16x8* __restrict__ ap /*lane base: A image*/, int blk) {
+                                            const bf16x8* __restrict__ ap /*lane base: A image*/, int blk, long tile = 0, long t_beg = 0) {
   constexpr int NS = NP == 1 ? 1 : 3;
   bf16x8 gs[2][3];
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
     for (int s = 0; s < NS; ++s) gs[mb][s] = gp[(s * 8 + blk * 4) * 128 + 16 * mb];
-  bf16x8 as[2][3];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) as[0][s] = ap[(s * 8 + blk * 4) * 128];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {                 // bias gradient: the three split terms add up to the fp32 value exactly
+  for (int mb = 0; mb < 2; ++mb) {                    // bias gradient: the three split terms add up to the fp32 value exactly
     float t = 0.f;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -111,13 +215,17 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], 
     }
     cs[mb] += t;
   }
+  bf16x8 as[2][3];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) as[0][s] = ap[(s * 4) * 128];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
     if (nb + 1 < 8) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) as[(nb + 1) & 1][s] = ap[(s * 8 + blk * 4) * 128 + 16 * (nb + 1)];
+      for (int s = 0; s < NS; ++s) as[(nb + 1) & 1][s] = ap[(s * 4) * 128 + 16 * (nb + 1)];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (STAMP) FSTAMP(1, 48 + nb);
     const bf16x8 (&a)[3] = as[nb & 1];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
@@ -136,43 +244,7 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], 
   }
 }
 
-// mfma_half6 of mlp6_device.h with the operand fragments of one output block at a time (scheduling barrier per block): at the
-// 256-register budget of this kernel the unconstrained scheduler hoists dozens of fragment reads and then spills.
-template <int HALFI, int NP>
-__device__ __forceinline__ void mfma_half6_sb(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
-  const int lane = threadIdx.x & 63;
-  const __bf16* lp = lds + lane * 8;
-  bf16x8 fr[2][3];
-#pragma unroll
-  for (int s = 0; s < (NP == 1 ? 1 : 3); ++s) fr[0][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + 0) * 8 + 0) * TILE_BF16);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {                   // i = 8 * cl + ob
-    const int cl = i >> 3, ob = i & 7, c = 2 * HALFI + cl;
-    if (i + 1 < 16) {
-      const int cl1 = (i + 1) >> 3, ob1 = (i + 1) & 7;
-#pragma unroll
-      for (int s = 0; s < (NP == 1 ? 1 : 3); ++s)
-        fr[(i + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + cl1) * 8 + ob1) * TILE_BF16);
-    }
-    __builtin_amdgcn_sched_barrier(0);             // issued here, ahead of this block's products
-    const bf16x8 (&a)[3] = fr[i & 1];              // a[0] hi, a[1] mid, a[2] lo
-    f32x4 t = acc.v[ob];
-    if (NP == 1) {
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][c], t, 0, 0, 0);
-    } else {
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[0][c], t, 0, 0, 0);      // smallest terms first
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[2][c], t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[1][c], t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[0][c], t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[1][c], t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][c], t, 0, 0, 0);
-    }
-    acc.v[ob] = t;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// Row access with a UNIFORM base pointer and a 32-bit per-lane byte offset (eligibility bounds the arrays to 4 GiB): the
+// Row access with a UNIFORM base pointer and a 32-bit per-lane byte offset (eligibility bounds these arrays to 4 GiB): the
 // address stays one VGPR next to a scalar base instead of a hoisted 64-bit pointer per array that the allocator then spills.
 __device__ __forceinline__ void t_load32(Act& a, const float* __restrict__ base, unsigned byte_off) {
   const char* p = reinterpret_cast<const char*>(base);
@@ -183,18 +255,164 @@ __device__ __forceinline__ void t_store32(const Act& a, float* __restrict__ base
   HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + (byte_off + 64u * fb)) = a.v[fb];
 }
 
-// Counted wait: everything but the `keep` most recently issued vector-memory operations has completed (they retire in order).
-template <int KEEP>
-__device__ __forceinline__ void bar_keep() {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
-  __builtin_amdgcn_s_barrier();
+// ---- the weight ring (wgrad waves) ----------------------------------------------------------------------------------------------
+// Piece q of a tile (q = 0..11): layer q / 4 (W3^T, W2^T, W1e^T), contraction block q % 4, ring slot q % 3 (12 = 0 mod 3: the slot
+// of a piece does not depend on the tile).  DPW = DMA instructions per wgrad wave and piece.
+template <int NP> struct Ring { static constexpr int DPW = NP == 1 ? 2 : 6; };
+
+template <int Q, int NP>
+__device__ __forceinline__ void dma_piece(const __bf16* __restrict__ pk3, const __bf16* __restrict__ pk2, const __bf16* __restrict__ pk1,
+                                          unsigned lds_base, unsigned ww, unsigned voff /*16 * lane*/) {
+  constexpr int layer = Q / 4, c = Q % 4, half = c >> 1, cl = c & 1, slot = Q % 3;
+  const __bf16* blk = layer == 0 ? pk3 : (layer == 1 ? pk2 : pk1);
+  // tile (split 0, output block ww) of contraction block c: uniform -> a scalar register pair
+  const __bf16* src = blk + (half * HALF_BF16 + (cl * 8) * TILE_BF16) + ww * TILE_BF16;
+  glds_piece<NP>(src, voff, lds_base + slot * PIECE_BYTES + ww * 1024);
 }
 
-template <int NP, int DBG>          // DBG: compile-time ablation mask of the diagnostic instantiation (HGN_FUSED_DBG), 0 in the product
+// Schedule of the weight-gradient waves over the 12 phases of a tile T (all four waves run the SAME instruction stream: two code
+// paths, one per row block, made the kernel 63-74 KB of instructions and the instruction cache thrashed):
+//   phase 0  dW3 += G3[rows 0-31]^T  A          (A = z2 rows 0-31 of T, published in phase 11 of T - 1)
+//         1  publish z2 rows 32-63 (buffer xb);  fetch xb <- z1 rows 32-63 of T
+//         3  dW3 += G3[rows 32-63]^T A
+//         4  publish z1 rows 0-31  (buffer xa);  fetch xa <- z2 rows 0-31 of T + 1
+//         5  dW2 += G2[rows 0-31]^T  A
+//         6  publish z1 rows 32-63 (xb);         fetch xb <- z2 rows 32-63 of T + 1
+//         7  dW2 += G2[rows 32-63]^T A
+//        11  publish z2 rows 0-31 of T + 1 (xa); fetch xa <- z1 rows 0-31 of T + 1
+// and in EVERY phase P the DMA of ring piece P + 2, between the publish and the fetch.  The blocks sit in the phases in which the
+// chain has the most work of its own (first piece of a layer + G rows, last piece + ReLU mask + split), the publishes in the rest.
+constexpr bool wg_fetches(int p) { const int q = ((p % 12) + 12) % 12; return q == 1 || q == 4 || q == 6 || q == 11; }
+// vector-memory operations a wgrad wave issues AFTER the DMA of piece P (issued in phase P - 2): the fetch (8 loads) of phase P - 2,
+// the DMA of piece P + 1 (phase P - 1) and the fetch of phase P - 1
+template <int P, int NP>
+struct Keep { static constexpr int value = Ring<NP>::DPW + 8 * (wg_fetches(P - 2) ? 1 : 0) + 8 * (wg_fetches(P - 1) ? 1 : 0); };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- the weight-gradient waves (4-7) of edge_bwd_fused_kernel -----------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* __restrict__ smem, long t_beg, long t_end) {
+  const hgn_mlp_bwd_t& a = fa.b;
+  const long M = a.M;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned ww = (unsigned)__builtin_amdgcn_readfirstlane((tid >> 6) - 4);
+  const int m = lane & 15, kg = lane >> 4;
+  const bf16x8* gp = reinterpret_cast<const bf16x8*>(smem + opaque((unsigned)(G_OFF + (kg * 128 + 32 * ww + m) * 16)));
+  const bf16x8* ap = reinterpret_cast<const bf16x8*>(smem + opaque((unsigned)(A_OFF + (kg * 128 + m) * 16)));
+  // producer role: wave ww loads row group ww (8 rows) of a 32-row block, lane l features 2 l, 2 l + 1 (a wave instruction = one whole
+  // 512-byte row), and publishes 2 x 3 operand vectors
+  bf16x8* apub = reinterpret_cast<bf16x8*>(smem + opaque((unsigned)(A_OFF + (ww * 128 + 2 * lane) * 16)));
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;      // LDS byte address of the ring
+  const __bf16* pk3 = reinterpret_cast<const __bf16*>(a.W3pk_t);
+  const __bf16* pk2 = reinterpret_cast<const __bf16*>(a.W2pk_t);
+  const __bf16* pk1 = reinterpret_cast<const __bf16*>(a.dx[0].Wpk_t);
+  f32x4 acc[2][2][8];
+  float cs[2][2];
+#pragma unroll
+  for (int l = 0; l < 2; ++l)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      cs[l][mb] = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) acc[l][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  // A operand (z2 for layer 3, z1 for layer 2): rows are loaded more than a layer ahead into one of two buffers (xa: row block 0,
+  // xb: row block 1), split once and published.  Rows past the end are clamped (their G rows are zero).
+  f32x2 xa[8], xb[8];
+  auto fetch = [&](f32x2 (&x)[8], int l, long tile, int blk) {
+    const long r0 = tile * TILE_ROWS + blk * 32 + (long)ww * 8;
+    const char* A = reinterpret_cast<const char*>(fa.A[l]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned r = (unsigned)min(r0 + j, M - 1);
+      x[j] = *reinterpret_cast<const f32x2*>(A + (r * (LAT * 4u) + 8u * (unsigned)lane));
+    }
+  };
+  auto publish = [&](f32x2 (&x)[8]) {
+    // (the rows were fetched phases ago; without this fence the compiler converts them right behind the loads -- where the wait
+    // for them stalls a weight-gradient block and, through the barrier, the whole workgroup)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(x[j]));
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = x[j][f];
+      bf16x8 sp[3];
+      split3v8(v, sp);
+#pragma unroll
+      for (int s2 = 0; s2 < (NP == 1 ? 1 : 3); ++s2) apub[s2 * 4 * 128 + f] = sp[s2];
+    }
+  };
+  // One phase: [wait: piece P has landed] barrier; publish; DMA of piece P + 2; fetch; weight-gradient block.  The order inside a
+  // phase is what Keep<> counts.
+  auto phase = [&](auto P_, long tile) {
+    constexpr int P = decltype(P_)::value;
+    FSTAMP(1, 4 * P);
+    bar_keep<Keep<P, NP>::value>();
+    FSTAMP(1, 4 * P + 1);
+    if constexpr (P == 1 || P == 6) publish(xb);
+    if constexpr (P == 4 || P == 11) publish(xa);
+    FSTAMP(1, 4 * P + 2);
+    dma_piece<(P + 2) % 12, NP>(pk3, pk2, pk1, lds_base, ww, opaque((unsigned)lane * 16u));
+    if constexpr (P == 1) fetch(xb, 1, tile, 1);
+    if constexpr (P == 4) fetch(xa, 0, tile + 1, 0);     // (past the last tile: clamped rows -- keeps the operation counts static)
+    if constexpr (P == 6) fetch(xb, 0, tile + 1, 1);
+    if constexpr (P == 11) fetch(xa, 1, tile + 1, 0);
+    FSTAMP(1, 4 * P + 3);
+    if constexpr (P == 0) wgrad_block<NP, 1>(acc[0], cs[0], gp, ap, 0, tile, t_beg);
+    if constexpr (P == 3) wgrad_block<NP>(acc[0], cs[0], gp, ap, 1);
+    if constexpr (P == 5) wgrad_block<NP>(acc[1], cs[1], gp, ap, 0);
+    if constexpr (P == 7) wgrad_block<NP>(acc[1], cs[1], gp, ap, 1);
+  };
+  // prologue = phases 10 and 11 of the tile before the first one: both buffers' z2 rows, piece 0, publish z2 rows 0-31, piece 1,
+  // fetch z1 rows 0-31 (so that the first barrier's count is the steady-state one)
+  fetch(xa, 0, t_beg, 0);
+  fetch(xb, 0, t_beg, 1);
+  dma_piece<0, NP>(pk3, pk2, pk1, lds_base, ww, (unsigned)lane * 16u);
+  publish(xa);
+  dma_piece<1, NP>(pk3, pk2, pk1, lds_base, ww, (unsigned)lane * 16u);
+  fetch(xa, 1, t_beg, 0);
+  bar_lds();                                          // (S)
+  for (long tile = t_beg; tile < t_end; ++tile) {
+    phase(std::integral_constant<int, 0>{}, tile);
+    phase(std::integral_constant<int, 1>{}, tile);
+    phase(std::integral_constant<int, 2>{}, tile);
+    phase(std::integral_constant<int, 3>{}, tile);
+    phase(std::integral_constant<int, 4>{}, tile);
+    phase(std::integral_constant<int, 5>{}, tile);
+    phase(std::integral_constant<int, 6>{}, tile);
+    phase(std::integral_constant<int, 7>{}, tile);
+    phase(std::integral_constant<int, 8>{}, tile);
+    phase(std::integral_constant<int, 9>{}, tile);
+    phase(std::integral_constant<int, 10>{}, tile);
+    phase(std::integral_constant<int, 11>{}, tile);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the two pieces issued past the end have landed before the workgroup's LDS is released
+  bar_lds();                                          // (E)
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    float* slab = fa.slabs + ((long)blockIdx.x * 2 + l) * FSLAB;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(32 * ww + 16 * mb + 4 * kg + r) * 128 + 16 * nb + m] = acc[l][mb][nb][r];
+      float v = cs[l][mb];                            // the four row groups of a feature live in four lanes
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kg == 0) slab[128 * 128 + 32 * ww + 16 * mb + m] = v;
+    }
+  }
+}
+
+template <int NP>
 __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs fa) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[FUSED_LDS];
-  __bf16* wst = reinterpret_cast<__bf16*>(smem);
-  float* lnl = reinterpret_cast<float*>(smem + HALF_BF16 * 2 + 2 * OPS64 * 16);
+  float* lnl = reinterpret_cast<float*>(smem + LN_OFF);
+  float* lng = reinterpret_cast<float*>(smem + LNG_OFF);
   const hgn_mlp_bwd_t& a = fa.b;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the role split is a scalar branch
@@ -204,63 +422,60 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
   const long q8 = G >> 3, r8 = G & 7, xc = bx & 7, ix = bx >> 3;
   const long pos = (xc < r8 ? xc * (q8 + 1) : r8 * (q8 + 1) + (xc - r8) * q8) + ix;
   const long t_beg = pos * fa.tiles / G, t_end = (pos + 1) * fa.tiles / G;
+  if (tid < 128) lng[tid] = a.ln_g[tid];              // LayerNorm weights: read from LDS per tile (visible after the first barrier)
 
   if (wave < 4) {
     // ================================= data-gradient chain =================================
     const hgn_dx_t d = a.dx[0];
-    const __bf16* pk3 = reinterpret_cast<const __bf16*>(a.W3pk_t);
-    const __bf16* pk2 = reinterpret_cast<const __bf16*>(a.W2pk_t);
-    const __bf16* pk1 = reinterpret_cast<const __bf16*>(d.Wpk_t);
-    const bool has_dout = a.d_out != nullptr;
-    Act g[1], t[1], gout;
-    // next tile's d(e') and x-hat rows are loaded into gout / g while this tile's last product runs (both are dead by then)
-    unsigned pf_m1 = 0, pf_m2 = 0, pf_seg = 0;
-    bf16x8 xs[1][3][4];
+    const bool has_dout = a.d_out != nullptr, has_agg = a.agg_dout != nullptr;
+    Act g, t, gout, ga;
+    unsigned pf_m1 = 0, pf_m2 = 0;
+    float pf_rstd = 0.f;
+    int seg_next = 0;
+    bf16x8 xs[3][4];
     int n = lane & 15, kq = lane >> 4;
-    // LayerNorm-affine gradient partials: the 16-row sums of a tile go through 1 KB of LDS per wave (written BEFORE the layer's
-    // weight DMA is issued: the compiler waits for a pending LDS-DMA before any LDS access it cannot tell apart from the stage)
-    // and are accumulated over the tiles in four registers per lane
     float lnacc[4] = {0.f, 0.f, 0.f, 0.f};
-    float* lnw = nullptr;
     const unsigned ld_dout4 = (unsigned)a.ld_dout * 4u;
-    unsigned char* gbase = nullptr;
-    auto prefetch = [&](long tile) {                  // 8 (+ 8 with d_out) row loads, 2 sign-word loads (+ 1 receiver id)
+    // rows of tile `tile`: x-hat -> g, d(e') -> gout, the receiver's d(agg) row -> ga, sign words, 1 / sigma
+    auto prefetch = [&](long tile, int seg) {
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       const unsigned rc = (unsigned)(row < M ? row : M - 1);
-      t_load32(g[0], a.xhat, rc * (LAT * 4u) + 16u * kq);
+      t_load32(g, a.xhat, rc * (LAT * 4u) + 16u * kq);
       if (has_dout) t_load32(gout, a.d_out, rc * ld_dout4 + 16u * kq);
+      if (has_agg) {                                  // `sum` aggregation backward: the receiver's row (cache-resident gather; 64-bit offset)
+        const char* ar = reinterpret_cast<const char*>(a.agg_dout) + ((long)seg * a.ld_agg * 4 + 16 * kq);
+        HGN_FOR_B(fb) ga.v[fb] = *reinterpret_cast<const f32x4*>(ar + 64 * fb);
+      }
       const unsigned* bits = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.relu_bits) + (rc * 32u + 4u * kq));
       pf_m1 = bits[0];
       pf_m2 = bits[4];
-      pf_seg = a.agg_dout ? (unsigned)a.agg_seg[rc] : 0u;      // receiver of the row: its d(agg) row is gathered at the tile's start
+      pf_rstd = row < M ? a.rstd[rc] : 0.f;           // rows past the end contribute nothing to any gradient
     };
-    if (t_beg < t_end && !(DBG & 32)) prefetch(t_beg);
+    auto seg_of = [&](long tile) -> int {
+      const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
+      return has_agg ? a.agg_seg[row < M ? row : M - 1] : 0;
+    };
+    prefetch(t_beg, seg_of(t_beg));
+    bar_lds();                                        // (S) LayerNorm weights in LDS; pairs with the wgrad waves' first barrier
     for (long tile = t_beg; tile < t_end; ++tile) {
       // everything per-lane is re-derived from an opaque lane id inside the loop: otherwise the compiler hoists two dozen loop-
-      // invariant 64-bit addresses and the 32 LayerNorm weights of the lane out of the loop and spills them
+      // invariant addresses out of the loop and spills them
       const int lane_i = (int)opaque((unsigned)lane);
       n = lane_i & 15; kq = lane_i >> 4;
       // row n of this wave = row group 2 * wave + n / 8, element n % 8 of the G vectors; features 4 kq + ... of every 16-block
-      gbase = smem + (unsigned)(HALF_BF16 * 2 + ((2 * wave + (n >> 3)) * 128 + 4 * kq) * 16 + (n & 7) * 2);
-      lnw = reinterpret_cast<float*>(smem + (unsigned)(HALF_BF16 * 2 + 2 * OPS64 * 16 + (wave * 256 + 4 * kq) * 4));
+      unsigned char* gbase = smem + opaque((unsigned)(G_OFF + ((2 * wave + (n >> 3)) * 128 + 4 * kq) * 16 + (n & 7) * 2));
+      float* lnw = reinterpret_cast<float*>(smem + opaque((unsigned)(LN_OFF + (wave * 256 + 4 * kq) * 4)));
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       const bool valid = row < M;
-      const long rc = valid ? row : M - 1;
-      // ---- layer 3: LayerNorm backward -> dz3 (g); t = W3^T dz3 ------------------------------------------------------
-      bar_lds();
+      FSTAMP(0, 0);
+      seg_next = seg_of(tile + 1);                    // consumed by the prefetch in layer 1
       const unsigned mb1 = pf_m1, mb2 = pf_m2;
+      // ---- LayerNorm backward -> dz3 (g) ------------------------------------------------------------------------------------
       {
-        Act& xh = t[0];
-        if (DBG & 32) { t_zero(gout); t_zero(xh); }
-        else {
-          xh = g[0];
-          if (!has_dout) t_zero(gout);
-          if (a.agg_dout) {                           // `sum` aggregation backward: the receiver's d(agg) row (cache-resident gather)
-            const unsigned r = pf_seg;
-            const char* ar = reinterpret_cast<const char*>(a.agg_dout) + (r * ((unsigned)a.ld_agg * 4u) + 16u * kq);
-            HGN_FOR_B(fb) gout.v[fb] += *reinterpret_cast<const f32x4*>(ar + 64 * fb);
-          }
-        }
+        Act& xh = t;
+        xh = g;
+        if (!has_dout) t_zero(gout);
+        if (has_agg) HGN_FOR_B(fb) gout.v[fb] += ga.v[fb];
         HGN_FOR_B(fb) {                               // LayerNorm-affine gradient partials of this wave's rows
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
@@ -271,68 +486,77 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        HGN_FOR_B(fb) g[0].v[fb] = gout.v[fb] * *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
-        const float m1 = row_sum(g[0]) * (1.f / LAT);
+        HGN_FOR_B(fb) g.v[fb] = gout.v[fb] * *reinterpret_cast<const f32x4*>(lng + 16 * fb + 4 * kq);
+        const float m1 = row_sum(g) * (1.f / LAT);
         float q0 = 0.f, q1 = 0.f;
         HGN_FOR_B(fb) {
-          q0 += g[0].v[fb][0] * xh.v[fb][0] + g[0].v[fb][1] * xh.v[fb][1];
-          q1 += g[0].v[fb][2] * xh.v[fb][2] + g[0].v[fb][3] * xh.v[fb][3];
+          q0 += g.v[fb][0] * xh.v[fb][0] + g.v[fb][1] * xh.v[fb][1];
+          q1 += g.v[fb][2] * xh.v[fb][2] + g.v[fb][3] * xh.v[fb][3];
         }
         float qs = q0 + q1;
         qs += __shfl_xor(qs, 16);
         qs += __shfl_xor(qs, 32);
         const float m2 = qs * (1.f / LAT);
-        const float r = valid ? a.rstd[rc] : 0.f;     // rows past the end contribute nothing to any weight gradient
-        HGN_FOR_B(fb) g[0].v[fb] = r * (g[0].v[fb] - m1 - xh.v[fb] * m2);
-      }
-      if (!(DBG & 16)) stage_half6<NP>(wst, pk3);       // (after the LayerNorm partials went to LDS, see above)
-      split3(g[0], xs[0]);
-      t_zero(t[0]);
-      bar_all();
-      if (!(DBG & 1)) write_gops<NP>(gbase, xs[0]);
+        const float r = pf_rstd;
+        HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - xh.v[fb] * m2);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) lnacc[k] += lnl[wave * 256 + lane + 64 * k];      // this wave's own partials of this tile
-      if (!(DBG & 4)) mfma_half6_sb<0, NP>(t[0], xs[0], wst);
-      bar_lds();
-      if (!(DBG & 16)) stage_half6<NP>(wst, pk3 + HALF_BF16);
-      bar_all();
-      if (!(DBG & 4)) mfma_half6_sb<1, NP>(t[0], xs[0], wst);
-      relu_mask_bits(t[0], mb2);                      // dz2
-      // ---- layer 2: g = W2^T dz2 -------------------------------------------------------------------------------------
-      bar_lds();
-      if (!(DBG & 16)) stage_half6<NP>(wst, pk2);
-      split3(t[0], xs[0]);
-      t_zero(g[0]);
-      bar_all();
-      if (!(DBG & 1)) write_gops<NP>(gbase, xs[0]);
-      if (!(DBG & 4)) mfma_half6_sb<0, NP>(g[0], xs[0], wst);
-      bar_lds();
-      if (!(DBG & 16)) stage_half6<NP>(wst, pk2 + HALF_BF16);
-      bar_all();
-      if (!(DBG & 4)) mfma_half6_sb<1, NP>(g[0], xs[0], wst);
-      relu_mask_bits(g[0], mb1);                      // dz1
-      // (whole 64-row tiles are stored: rows past M land in the padding the caller provides)
-      t_store32(g[0], a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
-      // ---- layer 1: de = d_out_eff + dz1 W1e -------------------------------------------------------------------------
-      bar_lds();
-      if (!(DBG & 16)) stage_half6<NP>(wst, pk1);
-      split3(g[0], xs[0]);
-      t[0] = gout;                                    // the skip connection is the accumulator's start value
-      // g and gout are dead: the next tile's rows start their way now and stay in flight across the next barrier (counted
-      // wait: only the weight DMA issued before them has to have landed) and the first product half; the wait for the second
-      // weight half then completes them (vector memory retires in order).  Past the last tile the clamped rows are unused.
-      if (DBG & 32) bar_all();
-      else {
-        prefetch(tile + 1);
-        if (a.agg_dout) { if (has_dout) bar_keep<19>(); else bar_keep<11>(); }
-        else { if (has_dout) bar_keep<18>(); else bar_keep<10>(); }
+        for (int k = 0; k < 4; ++k) lnacc[k] += lnl[wave * 256 + lane + 64 * k];      // this wave's own partials (same-wave LDS order)
       }
-      if (!(DBG & 4)) mfma_half6_sb<0, NP>(t[0], xs[0], wst);
-      bar_lds();
-      if (!(DBG & 16)) stage_half6<NP>(wst, pk1 + HALF_BF16);
-      bar_all();
-      if (!(DBG & 4)) mfma_half6_sb<1, NP>(t[0], xs[0], wst);
-      if (valid) t_store32(t[0], d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
+      t_zero(t);
+      FSTAMP(0, 1);
+      // ---- layers 3 and 2: ONE copy of the code (a run-time loop: fully unrolled the kernel is 63 KB of instructions and the two
+      // kinds of wave thrash the instruction cache).  Entering layer `li`: g = the gradient to multiply (dz3, dz2), t = 0.
+      // li = 0: t = W3^T dz3; 1: t = W2^T dz2.  Ring slot of piece (li, c): (4 li + c) mod 3.
+#pragma unroll 1
+      for (int li = 0; li < 2; ++li) {
+        split3(g, xs);
+        if (wave < 2) write_gops<NP>(gbase, xs);                // rows 0-31 of G: free since the previous layer's first weight-gradient block
+        const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 1 : 0) * PIECE_BYTES));
+        FSTAMP(0, 2 + 8 * li);
+        bar_lds();                                              // ---- phase 4 li
+        FSTAMP(0, 3 + 8 * li);
+        if (wave >= 2) write_gops<NP>(gbase, xs);               // rows 32-63: free now (the previous layer's second block is done)
+        sweep_piece<0, NP>(t, xs, ring);
+        ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 2 : 1) * PIECE_BYTES));
+        FSTAMP(0, 4 + 8 * li); bar_lds(); FSTAMP(0, 5 + 8 * li);
+        sweep_piece<1, NP>(t, xs, ring);                        // ---- phase 4 li + 1
+        ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 0 : 2) * PIECE_BYTES));
+        FSTAMP(0, 6 + 8 * li); bar_lds(); FSTAMP(0, 7 + 8 * li);
+        sweep_piece<2, NP>(t, xs, ring);                        // ---- phase 4 li + 2
+        ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 1 : 0) * PIECE_BYTES));
+        FSTAMP(0, 8 + 8 * li); bar_lds(); FSTAMP(0, 9 + 8 * li);
+        sweep_piece<3, NP>(t, xs, ring);                        // ---- phase 4 li + 3
+        relu_mask_bits(t, li == 0 ? mb2 : mb1);                 // dz2 / dz1
+        g = t;                                                  // the next layer's operand
+        t_zero(t);
+      }
+      // ---- layer 1: de = d_out_eff + dz1 W1e; the next tile's rows start their way, one array per phase (one burst of all of
+      // them holds up every other memory instruction of the CU -- the ring's DMA among them -- for thousands of cycles) -------------
+      // (dz1: whole 64-row tiles are stored; rows past M land in the padding the caller provides)
+      t_store32(g, a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
+      split3(g, xs);
+      t = gout;                                                 // the skip connection is the accumulator's start value
+      const long nrow = (tile + 1) * TILE_ROWS + wave * WAVE_ROWS + n;
+      const unsigned nrc = (unsigned)(nrow < M ? nrow : M - 1);
+      const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16));
+      t_load32(g, a.xhat, nrc * (LAT * 4u) + 16u * kq);
+      FSTAMP(0, 18); bar_lds(); FSTAMP(0, 19); sweep_piece<0, NP>(t, xs, ring + 2 * PIECE_BYTES);                // ---- phase 8
+      if (has_dout) t_load32(gout, a.d_out, nrc * ld_dout4 + 16u * kq);
+      FSTAMP(0, 20); bar_lds(); FSTAMP(0, 21); sweep_piece<1, NP>(t, xs, ring + 0 * PIECE_BYTES);                // ---- phase 9
+      if (has_agg) {                                  // `sum` aggregation backward: the receiver's row (cache-resident gather; 64-bit offset)
+        const char* ar = reinterpret_cast<const char*>(a.agg_dout) + ((long)seg_next * a.ld_agg * 4 + 16 * kq);
+        HGN_FOR_B(fb) ga.v[fb] = *reinterpret_cast<const f32x4*>(ar + 64 * fb);
+      }
+      {
+        const unsigned* bits = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.relu_bits) + (nrc * 32u + 4u * kq));
+        pf_m1 = bits[0];
+        pf_m2 = bits[4];
+        pf_rstd = nrow < M ? a.rstd[nrc] : 0.f;       // rows past the end contribute nothing to any gradient
+      }
+      FSTAMP(0, 22); bar_lds(); FSTAMP(0, 23); sweep_piece<2, NP>(t, xs, ring + 1 * PIECE_BYTES);                // ---- phase 10
+      FSTAMP(0, 24); bar_lds(); FSTAMP(0, 25); sweep_piece<3, NP>(t, xs, ring + 2 * PIECE_BYTES);                // ---- phase 11
+      FSTAMP(0, 26);
+      if (valid) t_store32(t, d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) lnl[wave * 256 + lane + 64 * k] = lnacc[k];
@@ -340,91 +564,8 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     const float sum = (lnl[tid] + lnl[256 + tid]) + (lnl[512 + tid] + lnl[768 + tid]);
     a.ln_ws[(long)blockIdx.x * 256 + tid] = sum;
   } else {
-    // ================================= weight gradients of layers 3 and 2 =================================
-    const int ww = wave - 4, tw = tid - 256;
-    const int blkp = tw >> 7, kgp = (tw >> 5) & 3, qd = tw & 31;      // producer role: 8 rows x 4 features of the A operand
-    const int m = lane & 15, kg = lane >> 4;
-    const bf16x8* gp = reinterpret_cast<const bf16x8*>(smem + opaque((unsigned)(HALF_BF16 * 2 + (kg * 128 + 32 * ww + m) * 16)));
-    const bf16x8* ap = reinterpret_cast<const bf16x8*>(smem + opaque((unsigned)(HALF_BF16 * 2 + OPS64 * 16 + (kg * 128 + m) * 16)));
-    bf16x8* apub = reinterpret_cast<bf16x8*>(smem + opaque((unsigned)(HALF_BF16 * 2 + OPS64 * 16 + ((blkp * 4 + kgp) * 128 + 4 * qd) * 16)));
-    f32x4 acc[2][2][8];
-    float cs[2][2];
-#pragma unroll
-    for (int l = 0; l < 2; ++l)
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        cs[l][mb] = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) acc[l][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    // A operand (z2 for layer 3, z1 for layer 2) of a whole 64-row tile: this lane loads 4 features of 8 consecutive rows one
-    // phase ahead, splits them once and publishes 4 x 3 operand vectors.
-    f32x4 x[8];
-    auto fetch = [&](int l, long tile) {
-      const long r0 = tile * TILE_ROWS + blkp * 32 + kgp * 8;
-      const char* A = reinterpret_cast<const char*>(fa.A[l]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned r = (unsigned)min(r0 + j, M - 1);
-        x[j] = *reinterpret_cast<const f32x4*>(A + (r * (LAT * 4u) + 16u * qd));
-      }
-    };
-    auto publish = [&]() {
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = x[j][f];
-        bf16x8 sp[3];
-        split3v8(v, sp);
-#pragma unroll
-        for (int s2 = 0; s2 < (NP == 1 ? 1 : 3); ++s2) apub[s2 * 8 * 128 + f] = sp[s2];
-      }
-    };
-    // Interleaving with the chain (same four barriers per layer; the matrix pipe alternates between the two kinds of wave):
-    //   chain:  VALU (next dz, split) | write G(l), product half 0 | wait for weight half 1 | product half 1
-    //   wgrad:  dW(l+1) rows 32-63    | publish A(l), fetch next A | dW(l) rows 0-31        | -
-    const bool pub = !(DBG & 2), mm = !(DBG & 8);
-    if (t_beg < t_end && pub) fetch(0, t_beg);
-    for (long tile = t_beg; tile < t_end; ++tile) {
-      // chain layer 3 / dW3 (A = z2)
-      bar_lds();
-      bar_lds();
-      if (pub) { publish(); fetch(1, tile); }
-      bar_lds();
-      if (mm) wgrad_block<NP>(acc[0], cs[0], gp, ap, 0);
-      bar_lds();
-      // chain layer 2 / dW2 (A = z1)
-      bar_lds();
-      if (mm) wgrad_block<NP>(acc[0], cs[0], gp, ap, 1);
-      bar_lds();
-      if (pub) { publish(); if (tile + 1 < t_end) fetch(0, tile + 1); }
-      bar_lds();
-      if (mm) wgrad_block<NP>(acc[1], cs[1], gp, ap, 0);
-      bar_lds();
-      // chain layer 1: no weight gradient here (dW1e = dz1^T e goes through the streaming kernel: dz1 is in memory anyway)
-      bar_lds();
-      if (mm) wgrad_block<NP>(acc[1], cs[1], gp, ap, 1);
-      bar_lds();
-      bar_lds();
-      bar_lds();
-    }
-    bar_lds();                                        // (E)
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-      float* slab = fa.slabs + ((long)blockIdx.x * 2 + l) * FSLAB;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) slab[(32 * ww + 16 * mb + 4 * kg + r) * 128 + 16 * nb + m] = acc[l][mb][nb][r];
-        float v = cs[l][mb];                          // the four row groups of a feature live in four lanes
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (kg == 0) slab[128 * 128 + 32 * ww + 16 * mb + m] = v;
-      }
-    }
+    // ================================= weight gradients of layers 3 and 2, and the weight ring =================================
+    wgrad_role<NP>(fa, smem, t_beg, t_end);
   }
 }
 
@@ -441,7 +582,7 @@ static long fused_grid(int64_t M) {
       hipDeviceProp_t pr;
       if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
     }
-    return (long)cus;                                 // one 8-wave workgroup per CU (148 KB of LDS each)
+    return (long)cus;                                 // one 8-wave workgroup per CU (148.5 KB of LDS each)
   }();
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   return tiles < cap ? tiles : cap;
@@ -459,7 +600,8 @@ extern "C" int hgn_edge_bwd_fused_eligible(const hgn_mlp_bwd_t* a) {
   if (a->n_dx != 1 || !a->dx[0].residual || a->dx[0].K != 128 || a->seg_dz1 || !a->dz1) return 0;
   if (a->agg_dout && (a->n_agg_ops != 1 || a->agg_ops[0] != HGN_OP_SUM)) return 0;      // several aggregates (pna): the two-launch path
   const int64_t ldmax = a->ld_dout > a->dx[0].ld ? a->ld_dout : a->dx[0].ld;
-  if (a->M * (ldmax > 128 ? ldmax : 128) * 4 >= ((int64_t)1 << 32)) return 0;      // 32-bit row offsets inside the kernel
+  // 32-bit row offsets inside the kernel for the edge-row arrays (d(e'), x-hat, z1 / z2, dz1, de); the d(agg) gather is 64-bit
+  if ((a->M + TILE_ROWS) * (ldmax > 128 ? ldmax : 128) * 4 >= ((int64_t)1 << 32)) return 0;
   return 1;
 }
 
@@ -488,33 +630,15 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   const long G = fused_grid(a->M);
   FusedArgs fa;
   fa.b = *a;
-  fa.A[0] = w->z2; fa.ldA[0] = 128;
-  fa.A[1] = w->z1; fa.ldA[1] = 128;
+  fa.A[0] = w->z2;
+  fa.A[1] = w->z1;
   fa.slabs = (float*)workspace;
   fa.tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
-  fa.dbg = 0;
   ProfScope ps(14, (double)a->M, stream);
-  if (bwd_products() == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
-  else {
-#if HGN_LAB   // laboratory build only: compile-time ablation instantiations (HGN_FUSED_DBG), one ablation each
-    static const int dbg = getenv("HGN_FUSED_DBG") ? atoi(getenv("HGN_FUSED_DBG")) : 0;
-    fa.dbg = dbg;
-    switch (dbg) {
-      case 2: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 2>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-      case 4: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 4>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-      case 8: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 8>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-      case 12: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 12>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-      case 16: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 16>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-      case 32: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 32>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-      case 63: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 63>), dim3((unsigned)G), dim3(FT), 0, stream, fa); break;
-      default: hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
-    }
-#else
-    hipLaunchKernelGGL((edge_bwd_fused_kernel<6, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
-#endif
-  }
+  if (bwd_products() == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  else hipLaunchKernelGGL((edge_bwd_fused_kernel<6>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
   if (hgn_check_launch("hgn_edge_bwd_fused") != HGN_OK) return HGN_E_LAUNCH;
-  // fixed-order sums of the per-workgroup partials: three weight gradients + biases, and the LayerNorm-affine gradients
+  // fixed-order sums of the per-workgroup partials: two weight gradients + biases, and the LayerNorm-affine gradients
   SlabReduceTask rt[2];
   float* dW[2] = {w->dW3, w->dW2};
   float* db[2] = {w->db3, w->db2};
@@ -528,3 +652,10 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   if (launch_ln_reduce(a->ln_ws, G, a->ln_ws + G * 256, a->d_gamma, a->d_beta, a->ln_accumulate, stream) != HGN_OK) return HGN_E_LAUNCH;
   return hgn_check_launch("hgn_edge_bwd_fused (reductions)");
 }
+
+#ifdef HGN_FUSED_STAMPS
+extern "C" int hgn_debug_fused_stamps(unsigned long long* host192) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host192, HIP_SYMBOL(hgn::g_fstamps), 3 * 64 * 8) == hipSuccess ? HGN_OK : HGN_E_LAUNCH;
+}
+#endif
