@@ -53,12 +53,17 @@ namespace hgn { __device__ unsigned long long g_fstamps[3 * 64]; }
 #define FSTAMP(role, idx) do {} while (0)
 #endif
 
+#ifndef HGN_FEXP
+#define HGN_FEXP 0      // diagnostic builds only (compile-time ablations for timing; the results are then WRONG): 1 no weight DMA, 2 no operand
+                        // fetch, 4 no dz1 / de stores, 8 no chain row loads, 32 no weight-gradient blocks, 64 no chain products, 128 no publish
+#endif
+
 namespace hgn {
 
 constexpr int FT = 512;                               // threads: 8 waves
 constexpr int PIECE_BYTES = 3 * 8 * 1024;             // one contraction block of a packed block: [split][output block][lane][8 bf16]
 constexpr int RING_BYTES = 3 * PIECE_BYTES;           // 72 KB
-constexpr int G_BYTES = 3 * 8 * 128 * 16;             // [split][row group 0..7][feature] bf16x8: 64 rows, 48 KB
+constexpr int G_BYTES = 3 * 64 * 256;                 // [split][row 0..63][feature] bf16, row-major and swizzled: 48 KB
 constexpr int A_BYTES = 3 * 4 * 128 * 16;             // [split][row group 0..3][feature] bf16x8: 32 rows, 24 KB
 constexpr int G_OFF = RING_BYTES, A_OFF = G_OFF + G_BYTES, LN_OFF = A_OFF + A_BYTES, LNG_OFF = LN_OFF + 4 * 256 * 4;
 constexpr int FUSED_LDS = LNG_OFF + 128 * 4;
@@ -130,20 +135,58 @@ __device__ __forceinline__ void split3v8(const float (&v)[8], bf16x8 (&s)[3]) {
   }
 }
 
-// The chain lane (row n of chain wave `wave`, feature quarter kq) publishes its split values as G operand: vector (split, row
-// group 2 * wave + n / 8, feature), element n % 8.  `gbase`: the lane's base inside the G image (see the kernel).
+// ---- the G image (dz3 / dz2 as weight-gradient operand): ROW-MAJOR bf16, [split][row 0..63][feature 0..127], 256-byte rows whose
+// sixteen 16-byte chunks are XOR-swizzled with the row:  off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))).
+// The chain lane (row, feature quarter kq) holds, per 16-feature block, four consecutive features = 8 bytes of one row: 24
+// ds_write_b64 per layer (2-way bank conflicts).  The weight-gradient waves need the TRANSPOSE (eight consecutive rows of one
+// feature per lane): gfx950's ds_read_b64_tr_b16 delivers a 4-row x 16-column block column-major, conflict-free on this image --
+// two of them make one bf16x8 operand.  (The first layout stored operand vectors and was written two bytes at a time: 288
+// ds_write_b16 per layer and lane, 2.3 k cycles of the chain's issue time, and an LDS queue full of conflicting writes behind
+// which the first weight-gradient block of every tile ran at a seventh of its speed.)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int G_SPLIT_BYTES = 64 * 256;               // one split of the image: 16 KB
+
+// gw[c] / gw[4 + c]: the lane's byte addresses (inside smem) of the chunks that hold features 32 c + 4 kq .. + 3 and 32 c + 16 + 4 kq .. + 3
+__device__ __forceinline__ void g_write_addrs(unsigned (&gw)[8], int wave, int n, int kq) {
+  const unsigned a = n & 3, b = (n >> 2) & 3, u = (unsigned)(kq >> 1) ^ b;
+  const unsigned rowb = (unsigned)(G_OFF + (16 * wave + n) * 256 + 8 * (kq & 1));
+#pragma unroll
+  for (unsigned c = 0; c < 4; ++c) {
+    gw[c] = rowb + 64u * (c ^ a) + 16u * u;            // chunk 4 c + (kq >> 1), swizzled
+    gw[4 + c] = rowb + 64u * (c ^ a) + 16u * (u ^ 2u); // chunk 4 c + 2 + (kq >> 1)
+  }
+}
 template <int NP>
-__device__ __forceinline__ void write_gops(unsigned char* __restrict__ gbase, const bf16x8 (&xs)[3][4]) {
-  __bf16* gb = reinterpret_cast<__bf16*>(gbase);
+__device__ __forceinline__ void write_gops(unsigned char* __restrict__ smem, const unsigned (&gw)[8], const bf16x8 (&xs)[3][4]) {
 #pragma unroll
   for (int s = 0; s < (NP == 1 ? 1 : 3); ++s)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<bf16x4*>(smem + gw[c] + s * G_SPLIT_BYTES) = __builtin_shufflevector(xs[s][c], xs[s][c], 0, 1, 2, 3);
+      *reinterpret_cast<bf16x4*>(smem + gw[4 + c] + s * G_SPLIT_BYTES) = __builtin_shufflevector(xs[s][c], xs[s][c], 4, 5, 6, 7);
+    }
+}
+// Weight-gradient side.  Lane l = 16 kg + 4 q + p of wave ww reads, for its 16-feature block mb and row half hh, the 8 bytes
+// of row 8 kg + 4 hh + q (of the 32-row block), columns 32 ww + 16 mb + 4 p .. + 3; the transposed read hands lane 16 kg + i
+// feature 32 ww + 16 mb + i of those four rows.  gr[2 mb + hh]: the lane's byte address for row block 0, split 0.
+__device__ __forceinline__ void g_read_addrs(unsigned (&gr)[4], unsigned ww, int lane) {
+  const unsigned kg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int fofs = 32 * c + (j < 4 ? j : 16 + (j - 4));          // + 4 kq: in the lane base
-        gb[(s * 8 * 128 + fofs) * 8] = xs[s][c][j];
-      }
+  for (unsigned mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (unsigned hh = 0; hh < 2; ++hh) {
+      const unsigned r = 8 * kg + 4 * hh + q;
+      const unsigned ch = 4 * ww + 2 * mb + (p >> 1);
+      gr[2 * mb + hh] = (unsigned)G_OFF + 256u * r + 16u * (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) + 8u * (p & 1);
+    }
+}
+__device__ __forceinline__ bf16x8 g_read(const unsigned char* __restrict__ smem, unsigned lo, unsigned hi, int off) {
+  const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + lo + off));
+  const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + hi + off));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 z = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, z);
 }
 
 // acc[ob] += (piece of the packed block: contraction block C) * x, six products per output block, in the order of mfma_half6_sb
@@ -155,6 +198,7 @@ __device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], 
   // two output blocks at a time (two independent accumulation chains), the SIX fragments of the next pair read before the
   // current pair's twelve products are issued: 192 matrix-pipe cycles between a ds_read_b128 and its use (one block ahead, 96
   // cycles, left an exposed LDS round trip of 100-300 cycles per block: the sweeps ran at half the matrix rate)
+  if (HGN_FEXP & 64) return;
   constexpr int NSP = NP == 1 ? 1 : 3;
   bf16x8 fr[2][2][3];
   auto load_pair = [&](int g, bf16x8 (&f)[2][3]) {
@@ -193,17 +237,17 @@ __device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], 
 }
 
 // dW_layer += G^T A over the 32 rows of block `blk` of the tile; wgrad wave ww owns dW rows [32 ww, 32 ww + 32).
-// G: the 64-row image (row groups 4 blk .. 4 blk + 3), A: the 32-row image.  The A vectors of feature block nb + 1 are read while
+// G: rows 32 blk .. 32 blk + 31 of the row-major image (transposed reads), A: the 32-row vector image.  The A vectors of feature block nb + 1 are read while
 // block nb multiplies.
 template <int NP, int STAMP = 0>
-__device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], const bf16x8* __restrict__ gp /*lane base: G image*/,
+__device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], const unsigned char* __restrict__ smem, const unsigned (&gr)[4],
                                             const bf16x8* __restrict__ ap /*lane base: A image*/, int blk, long tile = 0, long t_beg = 0) {
   constexpr int NS = NP == 1 ? 1 : 3;
   bf16x8 gs[2][3];
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) gs[mb][s] = gp[(s * 8 + blk * 4) * 128 + 16 * mb];
+    for (int s = 0; s < NS; ++s) gs[mb][s] = g_read(smem, gr[2 * mb], gr[2 * mb + 1], s * G_SPLIT_BYTES + blk * 32 * 256);
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {                    // bias gradient: the three split terms add up to the fp32 value exactly
     float t = 0.f;
@@ -267,7 +311,7 @@ __device__ __forceinline__ void dma_piece(const __bf16* __restrict__ pk3, const 
   const __bf16* blk = layer == 0 ? pk3 : (layer == 1 ? pk2 : pk1);
   // tile (split 0, output block ww) of contraction block c: uniform -> a scalar register pair
   const __bf16* src = blk + (half * HALF_BF16 + (cl * 8) * TILE_BF16) + ww * TILE_BF16;
-  glds_piece<NP>(src, voff, lds_base + slot * PIECE_BYTES + ww * 1024);
+  if (!(HGN_FEXP & 1)) glds_piece<NP>(src, voff, lds_base + slot * PIECE_BYTES + ww * 1024);
 }
 
 // Schedule of the weight-gradient waves over the 12 phases of a tile T (all four waves run the SAME instruction stream: two code
@@ -298,7 +342,8 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned ww = (unsigned)__builtin_amdgcn_readfirstlane((tid >> 6) - 4);
   const int m = lane & 15, kg = lane >> 4;
-  const bf16x8* gp = reinterpret_cast<const bf16x8*>(smem + opaque((unsigned)(G_OFF + (kg * 128 + 32 * ww + m) * 16)));
+  unsigned gr[4];
+  g_read_addrs(gr, ww, lane);
   const bf16x8* ap = reinterpret_cast<const bf16x8*>(smem + opaque((unsigned)(A_OFF + (kg * 128 + m) * 16)));
   // producer role: wave ww loads row group ww (8 rows) of a 32-row block, lane l features 2 l, 2 l + 1 (a wave instruction = one whole
   // 512-byte row), and publishes 2 x 3 operand vectors
@@ -330,6 +375,7 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
     }
   };
   auto publish = [&](f32x2 (&x)[8]) {
+    if (HGN_FEXP & 128) return;
     // (the rows were fetched phases ago; without this fence the compiler converts them right behind the loads -- where the wait
     // for them stalls a weight-gradient block and, through the barrier, the whole workgroup)
 #pragma unroll
@@ -356,15 +402,15 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
     if constexpr (P == 4 || P == 11) publish(xa);
     FSTAMP(1, 4 * P + 2);
     dma_piece<(P + 2) % 12, NP>(pk3, pk2, pk1, lds_base, ww, opaque((unsigned)lane * 16u));
-    if constexpr (P == 1) fetch(xb, 1, tile, 1);
-    if constexpr (P == 4) fetch(xa, 0, tile + 1, 0);     // (past the last tile: clamped rows -- keeps the operation counts static)
-    if constexpr (P == 6) fetch(xb, 0, tile + 1, 1);
-    if constexpr (P == 11) fetch(xa, 1, tile + 1, 0);
+    if constexpr (P == 1 && !(HGN_FEXP & 2)) fetch(xb, 1, tile, 1);
+    if constexpr (P == 4 && !(HGN_FEXP & 2)) fetch(xa, 0, tile + 1, 0);     // (past the last tile: clamped rows -- keeps the operation counts static)
+    if constexpr (P == 6 && !(HGN_FEXP & 2)) fetch(xb, 0, tile + 1, 1);
+    if constexpr (P == 11 && !(HGN_FEXP & 2)) fetch(xa, 1, tile + 1, 0);
     FSTAMP(1, 4 * P + 3);
-    if constexpr (P == 0) wgrad_block<NP, 1>(acc[0], cs[0], gp, ap, 0, tile, t_beg);
-    if constexpr (P == 3) wgrad_block<NP>(acc[0], cs[0], gp, ap, 1);
-    if constexpr (P == 5) wgrad_block<NP>(acc[1], cs[1], gp, ap, 0);
-    if constexpr (P == 7) wgrad_block<NP>(acc[1], cs[1], gp, ap, 1);
+    if constexpr (P == 0 && !(HGN_FEXP & 32)) wgrad_block<NP, 1>(acc[0], cs[0], smem, gr, ap, 0, tile, t_beg);
+    if constexpr (P == 3 && !(HGN_FEXP & 32)) wgrad_block<NP>(acc[0], cs[0], smem, gr, ap, 1);
+    if constexpr (P == 5 && !(HGN_FEXP & 32)) wgrad_block<NP>(acc[1], cs[1], smem, gr, ap, 0);
+    if constexpr (P == 7 && !(HGN_FEXP & 32)) wgrad_block<NP>(acc[1], cs[1], smem, gr, ap, 1);
   };
   // prologue = phases 10 and 11 of the tile before the first one: both buffers' z2 rows, piece 0, publish z2 rows 0-31, piece 1,
   // fetch z1 rows 0-31 (so that the first barrier's count is the steady-state one)
@@ -462,8 +508,6 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       // invariant addresses out of the loop and spills them
       const int lane_i = (int)opaque((unsigned)lane);
       n = lane_i & 15; kq = lane_i >> 4;
-      // row n of this wave = row group 2 * wave + n / 8, element n % 8 of the G vectors; features 4 kq + ... of every 16-block
-      unsigned char* gbase = smem + opaque((unsigned)(G_OFF + ((2 * wave + (n >> 3)) * 128 + 4 * kq) * 16 + (n & 7) * 2));
       float* lnw = reinterpret_cast<float*>(smem + opaque((unsigned)(LN_OFF + (wave * 256 + 4 * kq) * 4)));
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       const bool valid = row < M;
@@ -510,12 +554,14 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
 #pragma unroll 1
       for (int li = 0; li < 2; ++li) {
         split3(g, xs);
-        if (wave < 2) write_gops<NP>(gbase, xs);                // rows 0-31 of G: free since the previous layer's first weight-gradient block
+        unsigned gw[8];
+        g_write_addrs(gw, wave, (int)opaque((unsigned)n), kq);   // (8 address registers, alive for the two write sites of this layer only)
+        if (wave < 2) write_gops<NP>(smem, gw, xs);             // rows 0-31 of G: free since the previous layer's first weight-gradient block
         const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 1 : 0) * PIECE_BYTES));
         FSTAMP(0, 2 + 8 * li);
         bar_lds();                                              // ---- phase 4 li
         FSTAMP(0, 3 + 8 * li);
-        if (wave >= 2) write_gops<NP>(gbase, xs);               // rows 32-63: free now (the previous layer's second block is done)
+        if (wave >= 2) write_gops<NP>(smem, gw, xs);            // rows 32-63: free now (the previous layer's second block is done)
         sweep_piece<0, NP>(t, xs, ring);
         ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 2 : 1) * PIECE_BYTES));
         FSTAMP(0, 4 + 8 * li); bar_lds(); FSTAMP(0, 5 + 8 * li);
@@ -533,17 +579,17 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       // ---- layer 1: de = d_out_eff + dz1 W1e; the next tile's rows start their way, one array per phase (one burst of all of
       // them holds up every other memory instruction of the CU -- the ring's DMA among them -- for thousands of cycles) -------------
       // (dz1: whole 64-row tiles are stored; rows past M land in the padding the caller provides)
-      t_store32(g, a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
+      if (!(HGN_FEXP & 4)) t_store32(g, a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
       split3(g, xs);
       t = gout;                                                 // the skip connection is the accumulator's start value
       const long nrow = (tile + 1) * TILE_ROWS + wave * WAVE_ROWS + n;
       const unsigned nrc = (unsigned)(nrow < M ? nrow : M - 1);
       const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16));
-      t_load32(g, a.xhat, nrc * (LAT * 4u) + 16u * kq);
+      if (!(HGN_FEXP & 8)) t_load32(g, a.xhat, nrc * (LAT * 4u) + 16u * kq);
       FSTAMP(0, 18); bar_lds(); FSTAMP(0, 19); sweep_piece<0, NP>(t, xs, ring + 2 * PIECE_BYTES);                // ---- phase 8
-      if (has_dout) t_load32(gout, a.d_out, nrc * ld_dout4 + 16u * kq);
+      if (has_dout && !(HGN_FEXP & 8)) t_load32(gout, a.d_out, nrc * ld_dout4 + 16u * kq);
       FSTAMP(0, 20); bar_lds(); FSTAMP(0, 21); sweep_piece<1, NP>(t, xs, ring + 0 * PIECE_BYTES);                // ---- phase 9
-      if (has_agg) {                                  // `sum` aggregation backward: the receiver's row (cache-resident gather; 64-bit offset)
+      if (has_agg && !(HGN_FEXP & 8)) {               // `sum` aggregation backward: the receiver's row (cache-resident gather; 64-bit offset)
         const char* ar = reinterpret_cast<const char*>(a.agg_dout) + ((long)seg_next * a.ld_agg * 4 + 16 * kq);
         HGN_FOR_B(fb) ga.v[fb] = *reinterpret_cast<const f32x4*>(ar + 64 * fb);
       }
@@ -556,7 +602,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       FSTAMP(0, 22); bar_lds(); FSTAMP(0, 23); sweep_piece<2, NP>(t, xs, ring + 1 * PIECE_BYTES);                // ---- phase 10
       FSTAMP(0, 24); bar_lds(); FSTAMP(0, 25); sweep_piece<3, NP>(t, xs, ring + 2 * PIECE_BYTES);                // ---- phase 11
       FSTAMP(0, 26);
-      if (valid) t_store32(t, d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
+      if (valid && !(HGN_FEXP & 4)) t_store32(t, d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) lnl[wave * 256 + lane + 64 * k] = lnacc[k];
