@@ -379,3 +379,54 @@ def test_intra_cluster_sampling_matches_reference_clusters():
     clusters = alg.run(g)
     assert [c.tolist() for c in clusters] == [c.tolist() for c in ex['clusters']]
     assert sum(len(c) for c in clusters) < 168                     # a strict subset of the nodes is connected upwards
+
+
+def test_fused_backward_ring_counts_match_the_emitted_instructions(tmp_path):
+    """csrc/fused_bwd.hip retires its weight-ring LDS-DMA with COUNTED waits (s_waitcnt vmcnt(N) in front of every phase barrier of
+    the weight-gradient waves): N is the number of vector-memory instructions the wave issues after the DMA of the piece the
+    phase reads -- the next piece's DMA (6 instructions) and the operand fetches (8 loads) of the two phases in between.  The
+    fetches are ordinary loads emitted by the compiler: if a toolchain merges, splits, duplicates or spills anything in that
+    loop, the counts are wrong and the chain reads weights that have not landed.  So the build is checked here, on the
+    disassembly: per phase of the weight-gradient loop exactly 6 DMA instructions, 8 loads in the four fetch phases and none
+    elsewhere, no store and no scratch access, and the wait immediates are the table of fused_bwd.hip (Keep<>)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = os.path.join(ROOT, 'hyper-graph-nets_amd', 'csrc', 'fused_bwd.hip')
+    out = str(tmp_path / 'fb.s')
+    r = subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
+                        '--cuda-device-only', '-S', src, '-o', out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    name = '_ZN3hgn21edge_bwd_fused_kernelILi6EEEvNS_9FusedArgsE'
+    body = text[text.index(name + ':'):text.index('.Lfunc_end', text.index(name + ':'))]
+    assert 'scratch_' not in body, 'register spills in the fused backward: their memory traffic breaks the counted waits'
+    lines = [l.strip() for l in body.splitlines()]
+    # the weight-gradient loop: the innermost loop that holds LDS-DMA instructions
+    heads = [i for i, l in enumerate(lines) if 'Loop Header' in l]
+    dma_lines = [i for i, l in enumerate(lines) if l.startswith('global_load_lds_dwordx4')]
+    start = max(h for h in heads if sum(1 for d in dma_lines if d > h) >= 72)      # (the prologue's 12 DMAs lie before it)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith('s_cbranch') and sum(1 for d in dma_lines if start < d < i) >= 72)
+    loop = lines[start:end]
+    phases, cur = [], None
+    for l in loop:
+        if l.startswith('s_barrier'):
+            cur = {'dma': 0, 'loads': 0, 'stores': 0, 'wait': None}
+            phases.append(cur)
+        elif cur is not None:
+            if l.startswith('global_load_lds'):
+                cur['dma'] += 1
+            elif l.startswith(('global_load', 'buffer_load', 'flat_load')):
+                cur['loads'] += 1
+            elif l.startswith(('global_store', 'buffer_store', 'flat_store', 'global_atomic')):
+                cur['stores'] += 1
+    waits = [int(re.search(r'vmcnt\((\d+)\)', l).group(1)) for l in loop if l.startswith('s_waitcnt vmcnt(') and 'lgkmcnt(0)' in l]
+    assert len(phases) == 12 and len(waits) == 12, (len(phases), len(waits))
+    fetch = {1, 4, 6, 11}
+    for p, ph in enumerate(phases):
+        assert ph['dma'] == 6 and ph['stores'] == 0, (p, ph)
+        assert ph['loads'] == (8 if p in fetch else 0), (p, ph)
+        keep = 6 + 8 * (((p - 2) % 12) in fetch) + 8 * (((p - 1) % 12) in fetch)
+        assert waits[p] == keep, (p, waits[p], keep)
