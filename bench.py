@@ -76,6 +76,8 @@ def parse():
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong-scaling mode: TOTAL graphs over all ranks (BASELINE.json configs[3]: 8 graphs over 8 GPUs = 1 per rank); '
                          'default 0 = weak scaling with --batch graphs per GPU')
+    ap.add_argument('--buckets', type=int, default=4, help='N>1: contiguous ranges the flat gradient buffer is all-reduced in (eager launches: each '
+                    'range goes out as soon as the backward pass has left its layers; captured step: back to back after the replay)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
 
@@ -423,7 +425,7 @@ def main():
     torch.cuda.synchronize()
     log('first forward done')
     use_graph = not args.eager
-    trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph, wgrad_stream=args.side_stream)
+    trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph, wgrad_stream=args.side_stream, buckets=args.buckets)
     n_params = trainer.fp.numel
 
     def barrier():
@@ -496,6 +498,30 @@ def main():
                 'note': 'per step, 128-graph batch; replayed step with warm tensors = ms_per_step above',
                 'topology_cache': dict(topo_mod.stats)}
         log(f'cold steps: content hit {t_hit:.2f} ms, rebuild {t_miss:.2f} ms')
+    collective = None
+    if world > 1:             # the collective by itself, outside the timed region: the whole flat gradient buffer, then its ranges
+        buf = torch.zeros_like(trainer.fp.grad_ext)
+        def timed(fn, n=10):
+            fn(); barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e6
+        bounds = [0] + list(trainer.bucket_starts) + [buf.numel()]
+        def ranges():
+            ws = [dist.all_reduce(buf[lo:hi], async_op=True) for lo, hi in zip(bounds[:-1], bounds[1:])]
+            for w in ws:
+                w.wait()
+        collective = {'ranks_reported_by_torch_distributed': dist.get_world_size(), 'backend': dist.get_backend(),
+                      'flat_gradient_bytes': buf.numel() * 4, 'buckets': len(bounds) - 1,
+                      'bucket_bytes': [(hi - lo) * 4 for lo, hi in zip(bounds[:-1], bounds[1:])],
+                      'all_reduce_whole_buffer_us': timed(lambda: dist.all_reduce(buf)),
+                      'all_reduce_in_ranges_us': timed(ranges),
+                      'overlapped_with_backward': bool(trainer.overlap),
+                      'note': 'measured after the timed region, nothing else running; in the step the ranges are launched from inside the backward '
+                              'pass (eager) or back to back behind the replayed graph (default)'}
+        log(f'collective: {collective}')
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -605,6 +631,8 @@ def main():
                 res['roofline_aggregation'] = {'kernel': f'seg_fwd128 ({which})', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
                                                'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
                                                'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3}
+        if collective is not None:
+            res['collective'] = collective
         if 'graph_build' in wk:
             res['config']['graph_build'] = wk['graph_build']
         if cold is not None:

@@ -96,6 +96,7 @@ class GraphedShardStep:
 
     def __init__(self, trainer, example: MultiGraph, target: torch.Tensor, mask: torch.Tensor, warmup: int = 2):
         self.trainer = trainer
+        trainer.overlap = False          # the backward pass is ONE replayed graph: the ranges are reduced after it, back to back
         self.static = _static_copy(example)
         self.target = target.detach().clone()
         self.maskf = mask.detach().to(torch.float32).unsqueeze(1).clone()
@@ -116,6 +117,7 @@ class GraphedShardStep:
         from . import ops
         tr = self.trainer
         tr.fp.zero_grad()
+        tr._pending, tr._done_upto = [], None
         if tr.side is not None:
             tr.side.wait_stream(torch.cuda.current_stream())
             ops.set_wgrad_stream(tr.side)

@@ -7,9 +7,11 @@ single-process step on the concatenated batch (MeshSimulator.py:141-152 with Fla
   * the loss is a mean over all NORMAL nodes of the *global* batch: each rank back-propagates its local SUM of squared
     errors, the NORMAL-node count rides in a spare slot behind the gradients, and after the all-reduce everything is scaled
     by 1 / (n_global * out_dim) -- the gradient of the global mean, with no collective between forward and backward;
-  * gradients live in ONE flat fp32 buffer (parameter .grad tensors are views into it), summed -- together with that
-    count -- by a SINGLE all-reduce per step: 9.3 MB for the 15-layer model; xGMI is point-to-point, so one large
-    collective per step beats many small ones -- and consumed by one fused Adam launch on the flat parameter buffer;
+  * gradients live in ONE flat fp32 buffer (parameter .grad tensors are views into it) and are summed -- together with that
+    count -- by a handful of LARGE all-reduces over contiguous ranges of it (default 4 buckets, 9.3 MB in all for the 15-layer
+    model: xGMI is point-to-point, ring collectives are per-link bound, so few large collectives beat many small ones), each
+    launched as soon as the backward pass has left the layers it covers (last layers first) so that it runs beside the rest
+    of the backward pass, and consumed by one fused Adam launch on the flat parameter buffer;
   * Normalizer statistics are sum-reduced across ranks at every accumulate (normalizer.py:53-63) so all replicas
     normalise identically.
 """
@@ -46,10 +48,11 @@ class FlatParams:
             total += (p.numel() + 3) // 4 * 4
         dev = params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        # gradients + one spare 16-byte slot: [grad (total) | NORMAL-node count | 0 0 0] travel in ONE collective
+        # one spare 16-byte slot IN FRONT of the gradients: [NORMAL-node count 0 0 0 | grad (total)].  The count travels with the
+        # range that holds the FIRST parameters, i.e. with the bucket that is reduced last (the backward pass reaches them last).
         self.grad_ext = torch.zeros(total + 4, dtype=torch.float32, device=dev)
-        self.grad = self.grad_ext[:total]
-        self.count = self.grad_ext[total:total + 1]
+        self.grad = self.grad_ext[4:]
+        self.count = self.grad_ext[0:1]
         for p, off in zip(params, self.offsets):
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
@@ -76,12 +79,53 @@ def _torch_adam(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
     p.addcdiv_(m, (v.sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
 
 
+def _map_tensors(obj, fn):
+    """Apply fn to every tensor of a nested output (tensor, list / tuple, dict, or an object with `nodes` / `edges` such as
+    modules._Latent); returns a structure of the same kind."""
+    if isinstance(obj, torch.Tensor):
+        return fn(obj)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(x, fn) for x in obj)
+    if isinstance(obj, dict):
+        return type(obj)((k, _map_tensors(v, fn)) for k, v in obj.items())
+    if hasattr(obj, 'nodes') and hasattr(obj, 'edges'):
+        import copy
+        out = copy.copy(obj)
+        out.nodes, out.edges = _map_tensors(obj.nodes, fn), _map_tensors(obj.edges, fn)
+        return out
+    return obj
+
+
+class _BucketMark(torch.autograd.Function):
+    """Identity on every tensor that crosses a bucket boundary of the model.  Its backward runs when the gradients of ALL of
+    them are ready, i.e. when the backward pass has left every layer behind the boundary: the gradients of those layers'
+    parameters are then complete (enqueued on the stream) and their range of the flat buffer can be reduced."""
+
+    @staticmethod
+    def forward(ctx, on_backward, *xs):
+        ctx.on_backward = on_backward
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ctx.on_backward()
+        return (None, *gs)
+
+
 class DataParallelTrainer:
-    """fwd -> global-mean masked MSE -> bwd -> one all-reduce -> fused Adam, on this rank's shard of the batch."""
+    """fwd -> global-mean masked MSE -> bwd beside bucketed all-reduces -> fused Adam, on this rank's shard of the batch.
+
+    ``buckets``: number of contiguous ranges the flat gradient buffer is reduced in (world > 1).  Boundaries are put between the
+    message-passing blocks of a MeshGraphNet (``model.processor.graphnet_blocks``; ``bucket_after`` names other modules) so
+    that the ranges hold about equal numbers of parameters; range k is all-reduced (asynchronously: RCCL's own stream, after
+    the gradient kernels enqueued so far) from an autograd node at its boundary, while the backward pass goes on through the
+    earlier layers.  The range of the first parameters goes last, after ``backward()`` has returned, and carries the node
+    count.  The result is the same sum as one all-reduce of the whole buffer (every element is reduced exactly once)."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  group: Optional[dist.ProcessGroup] = None, adam_fn: Optional[Callable] = None,
-                 device_step: bool = False, wgrad_stream: bool = False):
+                 device_step: bool = False, wgrad_stream: bool = False, buckets: int = 4, bucket_after=None):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = group
@@ -99,13 +143,82 @@ class DataParallelTrainer:
             adam_fn = ops.adam_step
         self.adam_fn = adam_fn
         self.side = torch.cuda.Stream() if (wgrad_stream and self.fp.flat.is_cuda) else None
+        self.overlap = True                                        # False: every range after the backward pass (graphs.GraphedShardStep)
+        self._pending, self._done_upto = [], None
+        self.bucket_starts = self._plan_buckets(max(1, int(buckets)), bucket_after) if self.world > 1 else []
+
+    # ---- bucket plan ------------------------------------------------------------------------------------------------
+    def _plan_buckets(self, n_buckets: int, bucket_after):
+        """-> ascending offsets (into grad_ext) at which a new range starts; installs the boundary hooks."""
+        if bucket_after is None:
+            proc = getattr(getattr(self.model, 'processor', None), 'graphnet_blocks', None)
+            blocks = list(proc) if proc is not None else []
+            offset_of = {id(p): off for p, off in zip(self.fp.params, self.fp.offsets)}
+            firsts = []                                            # (flat offset of a block's first parameter, block before it)
+            for i in range(1, len(blocks)):
+                ps = [p for p in blocks[i].parameters() if id(p) in offset_of]
+                if ps:
+                    firsts.append((min(offset_of[id(p)] for p in ps), blocks[i - 1]))
+            chosen = []
+            for k in range(1, n_buckets):                          # the boundary nearest to k / n_buckets of the buffer
+                want = self.fp.numel * k / n_buckets
+                if firsts:
+                    best = min(firsts, key=lambda f: abs(f[0] - want))
+                    if best not in chosen:
+                        chosen.append(best)
+            boundaries = sorted(chosen, key=lambda f: f[0])
+        else:
+            offset_of = {id(p): off for p, off in zip(self.fp.params, self.fp.offsets)}
+            boundaries = []
+            for mod_before, mod_after in bucket_after:            # explicit: (module whose output is the boundary, first module behind it)
+                ps = [p for p in mod_after.parameters() if id(p) in offset_of]
+                boundaries.append((min(offset_of[id(p)] for p in ps), mod_before))
+            boundaries.sort(key=lambda f: f[0])
+        starts = []
+        for off, module in boundaries:
+            start = off + 4                                        # (grad_ext = [count slot | grad])
+            starts.append(start)
+            module.register_forward_hook(self._make_hook(start))
+        return starts
+
+    def _make_hook(self, start: int):
+        def on_backward():
+            self._reduce_from(start)
+
+        def hook(module, inputs, output):
+            if not (self.overlap and torch.is_grad_enabled()):
+                return None
+            tensors = []
+            _map_tensors(output, lambda x: tensors.append(x) or x)
+            live = [x for x in tensors if x.requires_grad]
+            if not live:
+                return None
+            marked = iter(_BucketMark.apply(on_backward, *live))
+            return _map_tensors(output, lambda x: next(marked) if x.requires_grad else x)
+        return hook
+
+    def _reduce_from(self, start: int):
+        """All-reduce grad_ext[start : the range already under way), asynchronously."""
+        end = self._done_upto if self._done_upto is not None else self.fp.grad_ext.numel()
+        if start >= end:
+            return
+        if self.fp.flat.is_cuda:
+            from . import ops
+            ops.flush_wgrad()                                      # queued node-level weight-gradient tasks of these layers
+            if self.side is not None:
+                torch.cuda.current_stream().wait_stream(self.side)
+        self._pending.append(dist.all_reduce(self.fp.grad_ext[start:end], group=self.group, async_op=True))
+        self._done_upto = start
 
     def step(self, graph, target: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         self.fp.zero_grad()
+        self._pending, self._done_upto = [], None
         if self.side is not None:
             from . import ops
             self.side.wait_stream(torch.cuda.current_stream())      # the zeroed gradient buffer is visible to the side stream
             ops.set_wgrad_stream(self.side)
+        # (the count rides in the LAST range: written before the backward pass, reduced after it)
+        self.fp.count.copy_(mask.sum().to(torch.float32).reshape(1))
         out = self.model(graph)
         diff = (out - target) * mask.unsqueeze(1).to(out.dtype)       # masked without boolean indexing: no host sync, capturable
         sq = diff.square().sum()                                      # local SUM; scaled to the global mean after the collective
@@ -113,14 +226,23 @@ class DataParallelTrainer:
         if self.side is not None:
             ops.set_wgrad_stream(None)
             torch.cuda.current_stream().wait_stream(self.side)      # join: all weight gradients are in the flat buffer
-        self.fp.count.copy_(mask.sum().to(torch.float32).reshape(1))
         return self.reduce_and_update(sq.detach(), out.shape[1])
 
     def reduce_and_update(self, sq_local: torch.Tensor, width: int) -> torch.Tensor:
-        """[gradients of the local squared-error sum | local NORMAL-node count] -> ONE all-reduce -> scale to the gradient of the
-        global mean (flag.py:150-152 over the whole batch) -> fused Adam.  Returns this rank's share of the global-mean loss."""
+        """[local NORMAL-node count | gradients of the local squared-error sum] -> all-reduce (the ranges not yet under way; with
+        nothing under way: ONE collective over the whole buffer) -> scale to the gradient of the global mean (flag.py:150-152
+        over the whole batch) -> fused Adam.  Returns this rank's share of the global-mean loss."""
         if self.world > 1:
-            dist.all_reduce(self.fp.grad_ext, group=self.group)               # the only collective of the step
+            if self._done_upto is None and not self.overlap:
+                # no boundary fired (captured backward: graphs.GraphedShardStep): the same ranges, one after the other
+                bounds = [0] + list(self.bucket_starts) + [self.fp.grad_ext.numel()]
+                for lo, hi in reversed(list(zip(bounds[:-1], bounds[1:]))):
+                    self._pending.append(dist.all_reduce(self.fp.grad_ext[lo:hi], group=self.group, async_op=True))
+            else:
+                self._reduce_from(0)                                   # the first parameters + the count: the last range
+            for w in self._pending:
+                w.wait()
+            self._pending, self._done_upto = [], None
         inv = 1.0 / (self.fp.count * width)
         self.fp.grad.mul_(inv)
         self.t += 1

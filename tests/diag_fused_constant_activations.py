@@ -1,6 +1,6 @@
 """Diagnostic: edge MLP with z1 == 1 and z2 == 2 for every row (W1 = 0, b1 = 1, W2 = 0, b2 = 2): dW2[j][:] must equal db2[j], dW3[j][:] = 2 db3[j]."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (diagnostic script, run by hand: python tests/diag_...py [nx ny])
 for p in (ROOT, os.path.join(ROOT, 'hyper-graph-nets_amd')):
     sys.path.insert(0, p)
 import torch

@@ -1,6 +1,6 @@
 """Fused edge backward vs the two-launch backward on one small graph: relative error of every gradient (diagnostic)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (diagnostic script, run by hand: python tests/diag_...py [nx ny])
 for p in (ROOT, os.path.join(ROOT, 'hyper-graph-nets_amd')):
     sys.path.insert(0, p)
 import torch

@@ -59,6 +59,10 @@ def _dp_worker(rank, world, port, out, graphed):
     with torch.no_grad():
         model(g)
     tr = parallel.DataParallelTrainer(model, lr=LR, device_step=graphed)
+    assert len(tr.bucket_starts) >= 1                        # the flat buffer goes out in >= 2 ranges (eager: overlapped with the backward pass)
+    reduces = []
+    orig = tr._reduce_from
+    tr._reduce_from = lambda start, _o=orig: (reduces.append(start), _o(start))[1]
     step = hg.GraphedShardStep(tr, g, target, mask, warmup=1) if graphed else (lambda: tr.step(g, target, mask))
     losses, grad1 = [], None
     for i in range(STEPS):
@@ -71,6 +75,8 @@ def _dp_worker(rank, world, port, out, graphed):
     flat0 = tr.fp.flat.clone().cpu()
     dist.broadcast(flat0, src=0)
     assert torch.equal(flat0, tr.fp.flat.cpu()), 'replicas diverged'
+    if not graphed:                                          # every step: the boundary's range from inside the backward pass, then the rest
+        assert reduces[-2:] == [tr.bucket_starts[-1], 0] or reduces[-len(tr.bucket_starts) - 1:] == list(reversed(tr.bucket_starts)) + [0], reduces
     if rank == 0:
         torch.save({'flat': tr.fp.flat.cpu(), 'grad1': grad1.cpu(), 'losses': total}, out)
     dist.destroy_process_group()

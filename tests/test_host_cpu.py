@@ -273,6 +273,94 @@ def test_data_parallel_equals_single_process_on_concatenated_batch(tmp_path):
     assert float(res['acc_count']) == 32.0
 
 
+class _LayeredNet(torch.nn.Module):
+    """Stand-in with the module layout the bucket planner looks for (`processor.graphnet_blocks`, MeshGraphNet's): encoder ->
+    six residual blocks over a (node rows, edge rows) pair -> decoder.  Rows are independent, so sharding rows over ranks is
+    sharding graphs."""
+
+    class Block(torch.nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.node, self.edge = torch.nn.Linear(d, d), torch.nn.Linear(d, d)
+
+        def forward(self, x):
+            nodes, edges = x
+            edges = edges + torch.tanh(self.edge(edges))
+            nodes = nodes + torch.tanh(self.node(nodes)) * edges.detach()
+            return nodes, edges
+
+    def __init__(self, d=8, blocks=6):
+        super().__init__()
+        self.encoder = torch.nn.Linear(5, d)
+        self.processor = torch.nn.Module()
+        self.processor.graphnet_blocks = torch.nn.Sequential(*[self.Block(d) for _ in range(blocks)])
+        self.decoder = torch.nn.Linear(d, 3)
+
+    def forward(self, x):
+        nodes, edges = self.processor.graphnet_blocks((self.encoder(x), self.encoder(x).detach() * 0.5 + self.encoder(x) * 0.1))
+        return self.decoder(nodes) + 0.01 * edges.sum(1, keepdim=True)
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hgn_amd import parallel
+    torch.set_num_threads(1)
+    gen = torch.Generator().manual_seed(5)
+    x, y = torch.randn(40, 5, generator=gen), torch.randn(40, 3, generator=gen)
+    mask = torch.ones(40, dtype=torch.bool); mask[:7] = False        # unequal NORMAL-node counts on the two ranks
+    mine = torch.arange(rank, 40, world)
+    res = {}
+    for buckets in (1, 3):
+        torch.manual_seed(100 + rank)                                   # different initial weights per rank: the broadcast fixes it
+        model = _LayeredNet()
+        tr = parallel.DataParallelTrainer(model, lr=1e-2, adam_fn=parallel._torch_adam, buckets=buckets)
+        calls = []
+        orig = tr._reduce_from
+        tr._reduce_from = lambda start, _o=orig, _c=calls: (_c.append((start, tr._done_upto)), _o(start))[1]
+        if rank == 0 and buckets == 3:
+            torch.manual_seed(100)
+            start_weights = torch.cat([torch.nn.functional.pad(p.detach().reshape(-1), (0, (-p.numel()) % 4)) for p in _LayeredNet().parameters()])
+            assert torch.equal(tr.fp.flat, start_weights)
+        losses = [float(tr.step(x[mine], y[mine], mask[mine])) for _ in range(3)]
+        res[buckets] = {'flat': tr.fp.flat.clone(), 'losses': losses, 'starts': list(tr.bucket_starts), 'calls': calls[-3:] if buckets == 3 else calls[-1:],
+                        'numel': tr.fp.grad_ext.numel()}
+    if rank == 0:
+        torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_all_reduce_equals_one_all_reduce_and_single_process(tmp_path):
+    """The flat gradient buffer reduced in three ranges, each launched from an autograd node at its boundary (last layers first,
+    while the backward pass goes on; the range of the first parameters -- with the NORMAL-node count in its spare slot -- after
+    it): same parameters and losses as ONE all-reduce of the whole buffer, bit for bit on gloo, and as single-process Adam on the
+    concatenated batch with the global mean (flag.py:150-152)."""
+    port = 23500 + (os.getpid() % 2000)
+    out = str(tmp_path / 'bk.pt')
+    mp.spawn(_bucket_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    one, three = res[1], res[3]
+    assert one['starts'] == [] and len(three['starts']) == 2 and three['starts'] == sorted(three['starts'])
+    # the three ranges of a step: [second boundary, end), [first boundary, second), [0, first) -- every element exactly once
+    (s0, u0), (s1, u1), (s2, u2) = three['calls']
+    assert (s0, u0) == (three['starts'][1], None) and (s1, u1) == (three['starts'][0], three['starts'][1]) and (s2, u2) == (0, three['starts'][0])
+    assert torch.equal(one['flat'], three['flat']) and one['losses'] == three['losses']
+    gen = torch.Generator().manual_seed(5)
+    x, y = torch.randn(40, 5, generator=gen), torch.randn(40, 3, generator=gen)
+    mask = torch.ones(40, dtype=torch.bool); mask[:7] = False
+    torch.manual_seed(100)
+    model = _LayeredNet()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for _ in range(3):
+        opt.zero_grad()
+        loss = ((model(x) - y)[mask] ** 2).mean()
+        loss.backward()
+        opt.step()
+    flat = torch.cat([torch.nn.functional.pad(p.detach().reshape(-1), (0, (-p.numel()) % 4)) for p in model.parameters()])
+    torch.testing.assert_close(three['flat'], flat, rtol=2e-5, atol=2e-6)
+
+
 def test_batcher_matches_reference_golden_g6():
     """f1: vectorised batcher; reference_compat mode reproduces MeshSimulator._get_batched's index arithmetic (golden G6,
     generated by the reference itself), the default mode keeps every graph's remote edges inside that graph."""
