@@ -76,8 +76,8 @@ def parse():
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong-scaling mode: TOTAL graphs over all ranks (BASELINE.json configs[3]: 8 graphs over 8 GPUs = 1 per rank); '
                          'default 0 = weak scaling with --batch graphs per GPU')
-    ap.add_argument('--buckets', type=int, default=4, help='N>1: contiguous ranges the flat gradient buffer is all-reduced in (eager launches: each '
-                    'range goes out as soon as the backward pass has left its layers; captured step: back to back after the replay)')
+    ap.add_argument('--buckets', type=int, default=4, help='N>1 with --eager: contiguous ranges the flat gradient buffer is all-reduced in, each launched as soon as the '
+                    'backward pass has left its layers; with the captured step (default) the buffer goes out in one collective after the replay')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
 

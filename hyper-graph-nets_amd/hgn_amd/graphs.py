@@ -96,7 +96,7 @@ class GraphedShardStep:
 
     def __init__(self, trainer, example: MultiGraph, target: torch.Tensor, mask: torch.Tensor, warmup: int = 2):
         self.trainer = trainer
-        trainer.overlap = False          # the backward pass is ONE replayed graph: the ranges are reduced after it, back to back
+        trainer.overlap = False          # the backward pass is ONE replayed graph: nothing to overlap with, one collective behind it
         self.static = _static_copy(example)
         self.target = target.detach().clone()
         self.maskf = mask.detach().to(torch.float32).unsqueeze(1).clone()

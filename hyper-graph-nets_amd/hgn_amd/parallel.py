@@ -230,16 +230,12 @@ class DataParallelTrainer:
 
     def reduce_and_update(self, sq_local: torch.Tensor, width: int) -> torch.Tensor:
         """[local NORMAL-node count | gradients of the local squared-error sum] -> all-reduce (the ranges not yet under way; with
-        nothing under way: ONE collective over the whole buffer) -> scale to the gradient of the global mean (flag.py:150-152
+        nothing under way -- captured backward pass -- ONE collective over the whole buffer) -> scale to the gradient of the global mean (flag.py:150-152
         over the whole batch) -> fused Adam.  Returns this rank's share of the global-mean loss."""
         if self.world > 1:
-            if self._done_upto is None and not self.overlap:
-                # no boundary fired (captured backward: graphs.GraphedShardStep): the same ranges, one after the other
-                bounds = [0] + list(self.bucket_starts) + [self.fp.grad_ext.numel()]
-                for lo, hi in reversed(list(zip(bounds[:-1], bounds[1:]))):
-                    self._pending.append(dist.all_reduce(self.fp.grad_ext[lo:hi], group=self.group, async_op=True))
-            else:
-                self._reduce_from(0)                                   # the first parameters + the count: the last range
+            # (no boundary fired -- world of one bucket, or a captured backward pass, graphs.GraphedShardStep, where nothing can
+            # be overlapped: ONE collective over the whole buffer; otherwise the range of the first parameters + the count)
+            self._reduce_from(0)
             for w in self._pending:
                 w.wait()
             self._pending, self._done_upto = [], None
