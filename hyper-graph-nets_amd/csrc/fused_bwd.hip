@@ -41,8 +41,10 @@
 #include "mlp_common.h"
 #include "mlp6_device.h"
 
-// Diagnostic build only (-DHGN_FUSED_STAMPS, tools/fusedstamps.py): shader-clock stamps of one mid-launch workgroup's waves 0 (chain),
-// 4 and 6 (weight gradients) at every phase boundary of its 11th tile.  In the shipped library FSTAMP() is empty.
+// Diagnostic build only (-DHGN_FUSED_STAMPS, tools/fusedstamps.py): shader-clock stamps of one mid-launch workgroup's waves 0 (chain)
+// and 4 (weight gradients) at every phase boundary of its 11th tile.  In the shipped library FSTAMP() is empty.  Read them with
+// care: a stamp is an s_memtime plus a full lgkmcnt drain (~300-1000 cycles under load) -- the stamped tile takes 56 k cycles,
+// an unstamped one 46 k; per-phase ORDER of magnitude only.  What each part costs is measured by the HGN_FEXP ablations.
 #ifdef HGN_FUSED_STAMPS
 namespace hgn { __device__ unsigned long long g_fstamps[3 * 64]; }
 #define FSTAMP(role, idx)                                                                                      \
@@ -239,9 +241,9 @@ __device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], 
 // dW_layer += G^T A over the 32 rows of block `blk` of the tile; wgrad wave ww owns dW rows [32 ww, 32 ww + 32).
 // G: rows 32 blk .. 32 blk + 31 of the row-major image (transposed reads), A: the 32-row vector image.  The A vectors of feature block nb + 1 are read while
 // block nb multiplies.
-template <int NP, int STAMP = 0>
+template <int NP>
 __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], const unsigned char* __restrict__ smem, const unsigned (&gr)[4],
-                                            const bf16x8* __restrict__ ap /*lane base: A image*/, int blk, long tile = 0, long t_beg = 0) {
+                                            const bf16x8* __restrict__ ap /*lane base: A image*/, int blk) {
   constexpr int NS = NP == 1 ? 1 : 3;
   bf16x8 gs[2][3];
 #pragma unroll
@@ -269,7 +271,6 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], 
       for (int s = 0; s < NS; ++s) as[(nb + 1) & 1][s] = ap[(s * 4) * 128 + 16 * (nb + 1)];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (STAMP) FSTAMP(1, 48 + nb);
     const bf16x8 (&a)[3] = as[nb & 1];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
@@ -407,7 +408,7 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
     if constexpr (P == 6 && !(HGN_FEXP & 2)) fetch(xb, 0, tile + 1, 1);
     if constexpr (P == 11 && !(HGN_FEXP & 2)) fetch(xa, 1, tile + 1, 0);
     FSTAMP(1, 4 * P + 3);
-    if constexpr (P == 0 && !(HGN_FEXP & 32)) wgrad_block<NP, 1>(acc[0], cs[0], smem, gr, ap, 0, tile, t_beg);
+    if constexpr (P == 0 && !(HGN_FEXP & 32)) wgrad_block<NP>(acc[0], cs[0], smem, gr, ap, 0);
     if constexpr (P == 3 && !(HGN_FEXP & 32)) wgrad_block<NP>(acc[0], cs[0], smem, gr, ap, 1);
     if constexpr (P == 5 && !(HGN_FEXP & 32)) wgrad_block<NP>(acc[1], cs[1], smem, gr, ap, 0);
     if constexpr (P == 7 && !(HGN_FEXP & 32)) wgrad_block<NP>(acc[1], cs[1], smem, gr, ap, 1);

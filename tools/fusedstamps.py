@@ -26,5 +26,3 @@ for role, w in ((1, 4),):
         nxt = s[4 * (P + 1)] if P < 11 else None
         print(f'  phase {P:2d}: bar {s[4 * P + 1] - s[4 * P]:6d}  pub {s[4 * P + 2] - s[4 * P + 1]:6d}  dma/fetch {s[4 * P + 3] - s[4 * P + 2]:6d}  block {(nxt - s[4 * P + 3]) if nxt else -1:6d}')
 
-blk = st[64 + 48: 64 + 56]
-print('inside the phase-0 block of wave 4 (cycles from its dma/fetch stamp), before the products of feature block nb = 0..7:', [v - st[64 + 3] for v in blk])
