@@ -1,7 +1,7 @@
 #!/bin/bash
 # Measurement set of a round (one gpurun call):  bash tools/measure_round.sh r02 <commit>
 # default bench line, kernel trace + per-launch split, PMC traffic passes (separate runs), other configurations, N=2 rehearsal.
-R=${1:-r02}; COMMIT=${2:-unknown}
+R=${1:-r03}; COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R; mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default done rc=$?"
@@ -11,15 +11,15 @@ cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/d
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cold --no-secondary > $O/pmc_f.json 2> $O/pmc_f.err; echo "pmc fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cold --no-secondary > $O/pmc_w.json 2> $O/pmc_w.err; echo "pmc write rc=$?"
 python tools/make_traffic_json.py $O/pmc_f $O/pmc_w 1188096 204800 $COMMIT > $O/pmc_traffic.json; echo "traffic json rc=$?"
-for cfg in "pna --agg pna" "hyper --arch hyper --agg pna --layers 5 --clusters 16" "hetero --arch hetero --agg pna --layers 5 --clusters 31 --world-edges 300" "b1 --batch 1" "b8 --batch 8" "b21 --batch 21" "b64 --batch 64" "b256 --batch 256" "eager --eager" "bf16 --precision bf16" "fp16 --precision fp16"; do
+for cfg in "pna --agg pna" "hyper --arch hyper --agg pna --layers 5 --clusters 16" "plate --workload plate --arch hetero --agg pna --layers 5 --clusters 31" "cylinder_fp16 --workload cylinder --arch hyper --agg pna --layers 25 --clusters 16 --precision fp16 --batch 32" "b1 --batch 1" "b8 --batch 8" "b21 --batch 21" "b64 --batch 64" "b256 --batch 256" "eager --eager" "bf16 --precision bf16" "fp16 --precision fp16"; do
   set -- $cfg; n=$1; shift
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 "$@" > $O/bench_$n.json 2> $O/bench_$n.err || echo "config $n failed"
   python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true
 done
 HGN_NO_FUSED_BWD=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 > $O/bench_two_launch_bwd.json 2> $O/bench_two_launch_bwd.err
-HGN_WS_FWD=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 > $O/bench_ws_fwd.json 2> $O/bench_ws_fwd.err
-HGN_BIG_TILES=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 > $O/bench_big_tiles.json 2> $O/bench_big_tiles.err
-for n in two_launch_bwd ws_fwd big_tiles; do python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true; done
+for n in two_launch_bwd; do python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true; done
 timeout -k 10 600 python bench.py --gpus 2 --backend gloo --no-cold --no-secondary --steps 10 --warmup 3 --batch 64 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2_gloo.err; echo "gpus2 rc=$?"
+timeout -k 10 600 python bench.py --gpus 2 --backend gloo --no-cold --no-secondary --steps 10 --warmup 3 --global-batch 2 > $O/bench_gpus2_gloo_strong.json 2> $O/bench_gpus2_gloo_strong.err; echo "gpus2 strong rc=$?"
+timeout -k 10 600 python bench.py --gpus 2 --backend gloo --eager --no-cold --no-secondary --steps 10 --warmup 3 --batch 16 > $O/bench_gpus2_gloo_eager_buckets.json 2> $O/bench_gpus2_gloo_eager_buckets.err; echo "gpus2 eager rc=$?"
 rm -rf $O/trace/*/*.db $O/pmc_f/*/*.db $O/pmc_w/*/*.db 2>/dev/null
 python -c "import json;d=json.load(open('$O/bench_default.json'));print('default', d['ms_per_step'], d['value'], json.dumps(d['roofline']), json.dumps(d.get('cpu_baseline')), json.dumps(d.get('cold_step')), json.dumps(d.get('secondary')))"

@@ -2,7 +2,7 @@
     python tools/update_profiles.py gpurun_out/r02g <commit> [round tag, default r02]"""
 import json, os, shutil, subprocess, sys
 O, C = sys.argv[1], sys.argv[2]
-R = sys.argv[3] if len(sys.argv) > 3 else 'r02'
+R = sys.argv[3] if len(sys.argv) > 3 else 'r03'
 subprocess.run(f'python tools/make_traffic_json.py {O}/pmc_f {O}/pmc_w 1188096 204800 {C} > /tmp/pmc_traffic.json', shell=True, check=True)
 shutil.copy('/tmp/pmc_traffic.json', 'profiles/pmc_traffic.json'); shutil.copy('/tmp/pmc_traffic.json', f'profiles/{R}_pmc_traffic.json')
 for a, b in (('kernel_split.csv', f'{R}_kernel_split.csv'), ('kernel_stats.csv', f'{R}_kernel_stats.csv'),
@@ -17,14 +17,17 @@ def last_json(path):
 
 
 out = {}
-for n in ('pna', 'hyper', 'hetero', 'b1', 'b8', 'b21', 'b64', 'b256', 'eager', 'bf16', 'fp16', 'two_launch_bwd', 'ws_fwd', 'big_tiles'):
+for n in ('pna', 'hyper', 'plate', 'cylinder_fp16', 'b1', 'b8', 'b21', 'b64', 'b256', 'eager', 'bf16', 'fp16', 'two_launch_bwd'):
     if os.path.exists(f'{O}/bench_{n}.json'):
         d = last_json(f'{O}/bench_{n}.json')
         out[n] = {'ms_per_step': d['ms_per_step'], 'edges_per_s': d['value'], 'edges_per_step': d['config'].get('edges_per_step'),
                   'steps': d['steps'], 'workload': d['config']['workload'], 'graphs_per_gpu': d['config'].get('graphs_per_gpu')}
-d = last_json(f'{O}/bench_gpus2_gloo.json')
-out['gpus2_gloo_one_gpu_rehearsal'] = {'ms_per_step': d['ms_per_step'], 'edges_per_s': d['value'], 'n_gpus': d['n_gpus'], 'config': d['config']}
-out['_note'] = ('two_launch_bwd = HGN_NO_FUSED_BWD=1 (the round-1 edge backward), ws_fwd = HGN_WS_FWD=1, big_tiles = HGN_BIG_TILES=1, fp16 / bf16 = '
+for tag, f in (('gpus2_gloo_one_gpu_rehearsal', 'bench_gpus2_gloo.json'), ('gpus2_gloo_one_gpu_rehearsal_strong_1_graph_per_rank', 'bench_gpus2_gloo_strong.json'),
+               ('gpus2_gloo_one_gpu_rehearsal_eager_4_buckets', 'bench_gpus2_gloo_eager_buckets.json')):
+    if os.path.exists(f'{O}/{f}'):
+        d = last_json(f'{O}/{f}')
+        out[tag] = {'ms_per_step': d['ms_per_step'], 'edges_per_s': d['value'], 'n_gpus': d['n_gpus'], 'scaling': d['scaling'], 'config': d['config'], 'collective': d.get('collective')}
+out['_note'] = ('two_launch_bwd = HGN_NO_FUSED_BWD=1 (the round-1 edge backward), fp16 / bf16 = '
                 f'--precision; everything else the defaults; one box, tools/measure_round.sh at commit {C}')
 json.dump(out, open(f'profiles/{R}_other_configs.json', 'w'), indent=1)
 t = json.load(open('profiles/pmc_traffic.json'))
