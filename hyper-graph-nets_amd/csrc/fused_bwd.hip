@@ -22,17 +22,14 @@
 //                        wave) at the barrier that opens piece p, i.e. two product phases ahead of its use, and retired by a
 //                        COUNTED s_waitcnt vmcnt(N) in front of the barrier that opens piece p itself.  The DMA is issued from
 //                        inline assembly: the compiler neither tracks it nor drains it at its own waits.
-// Twelve phases per tile, one barrier each (as many as the first version had), none of them behind an exposed DMA:
-//   phase            0            1            2            3          4 .. 7 (layer 2, the same)      8 .. 11 (layer 1)
-//   chain   G(3) rows 32-63,   piece 1      piece 2      piece 3,     ...                             pieces only; next tile's
-//           piece 0                                      then dz2,                                    rows prefetched
-//                                                        split, G(2) rows 0-31
-//   wgrad   A(z2) rows 0-31    dW3 rows     A(z2) rows   dW3 rows     ...                             ring only
-//           published          0-31         32-63        32-63
-// so the matrix pipe runs the chain's products and the weight gradients side by side, the chain's VALU stretches (LayerNorm
-// backward, ReLU masks, splits) lie beside the second weight-gradient block of the previous layer, and the HBM rows of both roles
-// are in flight one layer (wgrad) or one tile (chain) ahead of their use.
-// LDS: 72 KB ring + 48 KB G vectors (64 rows) + 24 KB A vectors (32 rows) + 4.5 KB LayerNorm partials / weights = 148.5 KB.
+// Twelve phases per tile, one barrier each (as many as the first version had), none of them behind an exposed DMA.  Chain: phase
+// 4 (3 - l) + c multiplies contraction block c of layer l = 3, 2, 1 (ring piece = phase number); phase 0 opens with the LayerNorm
+// backward and the split of dz3 into G, phases 4 and 8 with the ReLU mask and the split of dz2 into G / the store of dz1; phases
+// 8-10 also issue the next tile's row loads, a third each.  Weight-gradient waves: see the schedule above wg_fetches() -- blocks
+// in phases 0, 3, 5, 7, operand publishes in 1, 4, 6, 11, the DMA of ring piece P + 2 in EVERY phase P.
+// So the matrix pipe runs the chain's products and the weight gradients side by side and the HBM rows of both roles are in flight
+// half a layer (wgrad) or one tile (chain) ahead of their use.
+// LDS: 72 KB ring + 48 KB G image (64 rows) + 24 KB A vectors (32 rows) + 4.5 KB LayerNorm partials / weights = 148.5 KB.
 // Per-workgroup partial results go to slabs that the existing fixed-order reductions add (deterministic, no float atomics).
 #include <cstdlib>
 #include <type_traits>
@@ -315,8 +312,9 @@ __device__ __forceinline__ void dma_piece(const __bf16* __restrict__ pk3, const 
   if (!(HGN_FEXP & 1)) glds_piece<NP>(src, voff, lds_base + slot * PIECE_BYTES + ww * 1024);
 }
 
-// Schedule of the weight-gradient waves over the 12 phases of a tile T (all four waves run the SAME instruction stream: two code
-// paths, one per row block, made the kernel 63-74 KB of instructions and the instruction cache thrashed):
+// Schedule of the weight-gradient waves over the 12 phases of a tile T (all four waves run the SAME instruction stream: wave w
+// fetches and publishes row group w of whichever 32-row block is due; one code path instead of one per row block is what
+// compiles without scratch, and 40 KB of instructions instead of 63-74 KB):
 //   phase 0  dW3 += G3[rows 0-31]^T  A          (A = z2 rows 0-31 of T, published in phase 11 of T - 1)
 //         1  publish z2 rows 32-63 (buffer xb);  fetch xb <- z1 rows 32-63 of T
 //         3  dW3 += G3[rows 32-63]^T A
@@ -549,8 +547,9 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       }
       t_zero(t);
       FSTAMP(0, 1);
-      // ---- layers 3 and 2: ONE copy of the code (a run-time loop: fully unrolled the kernel is 63 KB of instructions and the two
-      // kinds of wave thrash the instruction cache).  Entering layer `li`: g = the gradient to multiply (dz3, dz2), t = 0.
+      // ---- layers 3 and 2: ONE copy of the code (a run-time loop: fully unrolled the kernel is 63 KB of instructions; the
+      // counters show no instruction-cache misses either way, the loop is kept for build time and register pressure).
+      // Entering layer `li`: g = the gradient to multiply (dz3, dz2), t = 0.
       // li = 0: t = W3^T dz3; 1: t = W2^T dz2.  Ring slot of piece (li, c): (4 li + c) mod 3.
 #pragma unroll 1
       for (int li = 0; li < 2; ++li) {
