@@ -78,6 +78,9 @@ def parse():
                          'default 0 = weak scaling with --batch graphs per GPU')
     ap.add_argument('--buckets', type=int, default=4, help='N>1 with --eager: contiguous ranges the flat gradient buffer is all-reduced in, each launched as soon as the '
                     'backward pass has left its layers; with the captured step (default) the buffer goes out in one collective after the replay')
+    ap.add_argument('--dp-rehearsal', action='store_true',
+                    help='one rank, but through the N>1 code path: RCCL communicator of one rank, forward+backward replayed (or eager with '
+                         'bucketed all-reduces), collective + scaling + Adam eager -- what a rank of the multi-GPU job runs besides waiting for its peers')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
 
@@ -388,8 +391,13 @@ def main():
     local = local % torch.cuda.device_count()          # several ranks may share a GPU only in a gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    dp = world > 1 or args.dp_rehearsal
+    if dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1 and 'MASTER_PORT' not in os.environ:
+            with socket.socket() as s:
+                s.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(s.getsockname()[1])
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -425,11 +433,12 @@ def main():
     torch.cuda.synchronize()
     log('first forward done')
     use_graph = not args.eager
-    trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph, wgrad_stream=args.side_stream, buckets=args.buckets)
+    trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph, wgrad_stream=args.side_stream, buckets=args.buckets,
+                                           force_collectives=args.dp_rehearsal)
     n_params = trainer.fp.numel
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -442,7 +451,7 @@ def main():
         from hgn_amd import graphs
         try:
             # N=1: the whole step (incl. Adam) is one graph; N>1: forward+backward is the graph, all-reduce and Adam eager
-            gstep = (graphs.GraphedTrainStep if world == 1 else graphs.GraphedShardStep)(trainer, graph, target, mask, warmup=1)
+            gstep = (graphs.GraphedShardStep if dp else graphs.GraphedTrainStep)(trainer, graph, target, mask, warmup=1)
             gstep()
             step = lambda: gstep()
         except Exception as ex:                          # capture refused: measure the eager launches instead
@@ -472,7 +481,7 @@ def main():
     # 159-234 re-batch each trajectory), same mesh.  (i) topology found again by content fingerprint, captured step replayed
     # (graphs.GraphedStepCache); (ii) nothing cached: both radix sorts and their read-backs every step, eager launches.
     cold = None
-    if world == 1 and not args.no_cold:
+    if not dp and not args.no_cold:
         from hgn_amd import graphs as hg, topology as topo_mod
 
         def fresh():
@@ -499,7 +508,7 @@ def main():
                 'topology_cache': dict(topo_mod.stats)}
         log(f'cold steps: content hit {t_hit:.2f} ms, rebuild {t_miss:.2f} ms')
     collective = None
-    if world > 1:             # the collective by itself, outside the timed region: the whole flat gradient buffer, then its ranges
+    if dp:                    # the collective by itself, outside the timed region: the whole flat gradient buffer, then its ranges
         buf = torch.zeros_like(trainer.fp.grad_ext)
         def timed(fn, n=10):
             fn(); barrier()
@@ -523,7 +532,7 @@ def main():
                               'pass (eager) or back to back behind the replayed graph (default)'}
         log(f'collective: {collective}')
     tmax = torch.tensor([dt], device=dev)
-    if world > 1:
+    if dp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     ms_per_step = dt / args.steps * 1e3
@@ -536,9 +545,9 @@ def main():
                'dtype': 'f32' if args.precision == 'fp32' else args.precision + ' (reduced precision run, not the headline metric)', 'data': 'synthetic',
                'config': {'workload': wk['workload'],
                           'graphs_per_gpu': B, 'global_batch': total_graphs, 'edges_per_step': E_rank * world,
-                          'params': n_params, 'parallelism': f'dp{world}', 'loss': float(loss), 'hip_graph': bool(use_graph),
-                          'ranks': dist.get_world_size() if world > 1 else 1,
-                          'collective_backend': (dist.get_backend() if world > 1 else None),
+                          'params': n_params, 'parallelism': f'dp{world}' + (' (one rank through the N>1 code path)' if args.dp_rehearsal and world == 1 else ''), 'loss': float(loss), 'hip_graph': bool(use_graph),
+                          'ranks': dist.get_world_size() if dp else 1,
+                          'collective_backend': (dist.get_backend() if dp else None),
                           'gpus_visible_per_rank': torch.cuda.device_count()}}
         if prof:
             k = ops.prof_collect()
@@ -637,12 +646,12 @@ def main():
             res['config']['graph_build'] = wk['graph_build']
         if cold is not None:
             res['cold_step'] = cold
-        if world == 1 and not args.no_secondary:
+        if not dp and not args.no_secondary:
             res['secondary'] = secondary_configs(args)
-        if world == 1 and not args.no_cpu_baseline:
+        if not dp and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, wk['cpu_graph'](), model.state_dict())
         print(json.dumps(res))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

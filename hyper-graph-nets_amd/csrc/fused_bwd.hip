@@ -54,7 +54,8 @@ namespace hgn { __device__ unsigned long long g_fstamps[3 * 64]; }
 
 #ifndef HGN_FEXP
 #define HGN_FEXP 0      // diagnostic builds only (compile-time ablations for timing; the results are then WRONG): 1 no weight DMA, 2 no operand
-                        // fetch, 4 no dz1 / de stores, 8 no chain row loads, 32 no weight-gradient blocks, 64 no chain products, 128 no publish
+                        // fetch, 4 no dz1 / de stores, 8 no chain row loads, 32 no weight-gradient blocks, 64 no chain products, 128 no publish,
+                        // 16 / 256 chain row loads / stores in a whole-row pattern (same bytes, an eighth of the cache-line requests)
 #endif
 
 namespace hgn {
@@ -296,6 +297,19 @@ __device__ __forceinline__ void t_store32(const Act& a, float* __restrict__ base
   char* p = reinterpret_cast<char*>(base);
   HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + (byte_off + 64u * fb)) = a.v[fb];
 }
+
+#if HGN_FEXP & (16 | 256)
+// timing experiments only (WRONG rows): the same bytes with every instruction covering two whole rows (8 cache lines) instead of
+// 64 B of each of 16 rows (64 quarter-line touches)
+__device__ __forceinline__ void t_load32c(Act& a, const float* __restrict__ base, unsigned byte_off) {
+  const char* p = reinterpret_cast<const char*>(base);
+  HGN_FOR_B(fb) a.v[fb] = *reinterpret_cast<const f32x4*>(p + (byte_off + 1024u * fb));
+}
+__device__ __forceinline__ void t_store32c(const Act& a, float* __restrict__ base, unsigned byte_off) {
+  char* p = reinterpret_cast<char*>(base);
+  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + (byte_off + 1024u * fb)) = a.v[fb];
+}
+#endif
 
 // ---- the weight ring (wgrad waves) ----------------------------------------------------------------------------------------------
 // Piece q of a tile (q = 0..11): layer q / 4 (W3^T, W2^T, W1e^T), contraction block q % 4, ring slot q % 3 (12 = 0 mod 3: the slot
@@ -579,15 +593,28 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       // ---- layer 1: de = d_out_eff + dz1 W1e; the next tile's rows start their way, one array per phase (one burst of all of
       // them holds up every other memory instruction of the CU -- the ring's DMA among them -- for thousands of cycles) -------------
       // (dz1: whole 64-row tiles are stored; rows past M land in the padding the caller provides)
+#if HGN_FEXP & 256
+      t_store32c(g, a.dz1, ((unsigned)(row - n) + (lane_i >> 5)) * (LAT * 4u) + 16u * (lane_i & 31));
+#else
       if (!(HGN_FEXP & 4)) t_store32(g, a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
+#endif
       split3(g, xs);
       t = gout;                                                 // the skip connection is the accumulator's start value
       const long nrow = (tile + 1) * TILE_ROWS + wave * WAVE_ROWS + n;
       const unsigned nrc = (unsigned)(nrow < M ? nrow : M - 1);
       const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16));
+#if HGN_FEXP & 16
+      const unsigned nrcc = (unsigned)(nrow - n + 16 <= M ? nrow - n : 0) + (lane_i >> 5);
+      t_load32c(g, a.xhat, nrcc * (LAT * 4u) + 16u * (lane_i & 31));
+#else
       if (!(HGN_FEXP & 8)) t_load32(g, a.xhat, nrc * (LAT * 4u) + 16u * kq);
+#endif
       FSTAMP(0, 18); bar_lds(); FSTAMP(0, 19); sweep_piece<0, NP>(t, xs, ring + 2 * PIECE_BYTES);                // ---- phase 8
+#if HGN_FEXP & 16
+      if (has_dout) t_load32c(gout, a.d_out, nrcc * ld_dout4 + 16u * (lane_i & 31));
+#else
       if (has_dout && !(HGN_FEXP & 8)) t_load32(gout, a.d_out, nrc * ld_dout4 + 16u * kq);
+#endif
       FSTAMP(0, 20); bar_lds(); FSTAMP(0, 21); sweep_piece<1, NP>(t, xs, ring + 0 * PIECE_BYTES);                // ---- phase 9
       if (has_agg && !(HGN_FEXP & 8)) {               // `sum` aggregation backward: the receiver's row (cache-resident gather; 64-bit offset)
         const char* ar = reinterpret_cast<const char*>(a.agg_dout) + ((long)seg_next * a.ld_agg * 4 + 16 * kq);
@@ -602,7 +629,11 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       FSTAMP(0, 22); bar_lds(); FSTAMP(0, 23); sweep_piece<2, NP>(t, xs, ring + 1 * PIECE_BYTES);                // ---- phase 10
       FSTAMP(0, 24); bar_lds(); FSTAMP(0, 25); sweep_piece<3, NP>(t, xs, ring + 2 * PIECE_BYTES);                // ---- phase 11
       FSTAMP(0, 26);
+#if HGN_FEXP & 256
+      t_store32c(t, d.dx, ((unsigned)(row - n) + (lane_i >> 5)) * ((unsigned)d.ld * 4u) + 16u * (lane_i & 31));
+#else
       if (valid && !(HGN_FEXP & 4)) t_store32(t, d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
+#endif
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) lnl[wave * 256 + lane + 64 * k] = lnacc[k];

@@ -226,6 +226,27 @@ __device__ __forceinline__ void t_add(Act& a, const float* __restrict__ row, int
 __device__ __forceinline__ void t_store(const Act& a, float* __restrict__ row, int kq) {
   HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(row + 16 * fb + 4 * kq) = a.v[fb];
 }
+// Row-contiguous store of a wave's 16 x 128 fp32 tile.  In the MFMA C layout a store instruction writes 64 B of each of 16
+// rows -- 64 quarter-line requests; measured on the edge forward (-DHGN_ABL=512: the same bytes as whole rows) that pattern
+// costs 7 % of the kernel.  Here the tile goes through 4 KB of LDS private to the wave, half a row (256 B) at a time: written
+// in the C layout (chunk c = 4 (fb & 3) + kq of row n at slot c ^ n: 16 lanes of one kq hit 16 distinct 16-byte slots), read
+// back with lane l holding chunk l & 15 of row l >> 4 (+ 4, 8, 12), stored as 4 rows x 256 B = 8 whole lines per instruction.
+// Same values, same addresses: only the lane that carries each 16 bytes changes.  `st`: this wave's 1024 floats.
+__device__ __forceinline__ void t_store_rows(const Act& a, float* __restrict__ base, long row0, long ld, long M, float* st) {
+  const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+  const int r = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(st + n * 64 + 4 * ((4 * q + kq) ^ n)) = a.v[4 * h + q];
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(st + (r + 4 * q) * 64 + 4 * (c ^ (r + 4 * q)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (row0 + r + 4 * q < M) *reinterpret_cast<f32x4*>(base + (row0 + r + 4 * q) * ld + 64 * h + 4 * c) = v[q];
+  }
+}
 __device__ __forceinline__ void t_store_masked(const Act& a, float* __restrict__ row, int kq, int w) {
   HGN_FOR_B(fb) {
 #pragma unroll

@@ -63,6 +63,21 @@ __global__ void pack_bf16x3_kernel(const PackArgs a) {
 // NWV = 12 ("big": one 12-wave workgroup per CU on a 192-row tile instead of three 4-wave workgroups on 64 rows each): the three
 // groups share ONE weight stage, which can then hold a whole 96 KB block -- a third of the L2 -> LDS traffic, one DMA wait and
 // two barriers per block instead of two and four (gemm6_big).  Same per-row arithmetic, bit for bit.
+#if HGN_ABL & 512
+// timing experiment only (WRONG rows): every store instruction covers two whole rows instead of 64 B of each of 16 rows
+__device__ __forceinline__ void t_store_rows_x(const Act& a, float* __restrict__ p0, long ld) {
+  const int lane = threadIdx.x & 63;
+  float* p = p0 + (lane >> 5) * ld + (lane & 31) * 4;
+  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + 2 * fb * ld) = a.v[fb];
+}
+#define HGN_TSTORE(act, base, ld, u) do { if (R.row[u] - (threadIdx.x & 15) + 16 <= a.M) t_store_rows_x(act, (base) + (R.row[u] - (threadIdx.x & 15)) * (long)(ld), ld); } while (0)
+#else
+// (128-row workgroups -- every big launch: rows go out as whole cache lines through the wave's LDS stage, hgn_device.h: t_store_rows)
+#define HGN_TSTORE(act, base, ld, u) do {                                                                        \
+    if constexpr (STAGED) t_store_rows(act, base, R.row[u] - (threadIdx.x & 15), ld, a.M, stage_lds[threadIdx.x >> 6]); \
+    else if (R.valid[u]) t_store(act, (base) + R.row[u] * (ld), kq);                                             \
+  } while (0)
+#endif
 template <int NS, int NP, int NWV = WG / 64>
 __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
   constexpr bool BIG = NWV != WG / 64;
@@ -72,6 +87,8 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
   __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_BF16];
   __shared__ int seg_ids_lds[GROUPS][SEG_PRE_INTS];   // see SegPre
   static_assert(HALF_BF16 * 2 >= SEG_LDS_FLOATS * 4, "the weight stage doubles as the segment-sum tile");
+  constexpr bool STAGED = NS == 2 && !BIG;            // 2 workgroups / CU: 48 KB weight stage + 16 KB store stage each
+  __shared__ __attribute__((aligned(16))) float stage_lds[STAGED ? WG / 64 : 1][STAGED ? 1024 : 4];
   const int kq = (threadIdx.x & 63) >> 4;
   const Rows<NS, NWV> R(a.M);
   const int grp = BIG ? (int)(threadIdx.x >> 8) : 0, ltid = BIG ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     relu6(acc[u]);
-    if (!(HGN_ABL & 4) && a.z1 && R.valid[u]) t_store(acc[u], a.z1 + R.row[u] * LAT, kq);
+    if (!(HGN_ABL & 4) && a.z1) HGN_TSTORE(acc[u], a.z1, LAT, u);
     if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + kq] = relu_bits_of(acc[u]);
   }
   block(b, acc, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
@@ -145,7 +162,7 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     relu6(b[u]);
-    if (!(HGN_ABL & 4) && a.z2 && R.valid[u]) t_store(b[u], a.z2 + R.row[u] * LAT, kq);
+    if (!(HGN_ABL & 4) && a.z2) HGN_TSTORE(b[u], a.z2, LAT, u);
     if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + 4 + kq] = relu_bits_of(b[u]);
   }
   block(acc, b, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
       const float var = row_sum_sq(acc[u]) * (1.f / LAT);
       const float rstd = 1.f / sqrtf(var + 1e-5f);
       HGN_FOR_B(fb) acc[u].v[fb] *= rstd;
-      if (!(HGN_ABL & 4) && a.xhat && R.valid[u]) t_store(acc[u], a.xhat + R.row[u] * LAT, kq);
+      if (!(HGN_ABL & 4) && a.xhat) HGN_TSTORE(acc[u], a.xhat, LAT, u);
       if (a.rstd && R.valid[u] && kq == 0) a.rstd[R.row[u]] = rstd;
       HGN_FOR_B(fb) {
         const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
       }
     }
     if (a.res) HGN_FOR_B(fb) acc[u].v[fb] += b[u].v[fb];
-    if (R.valid[u]) t_store(acc[u], a.out + R.row[u] * a.ld_out, kq);
+    HGN_TSTORE(acc[u], a.out, a.ld_out, u);
   }
   HGN_STAMP();                                      // epilogue stores issued
   if (a.seg_out) {                                  // (waits for none of the stores above: see SegPre)

@@ -125,13 +125,16 @@ class DataParallelTrainer:
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  group: Optional[dist.ProcessGroup] = None, adam_fn: Optional[Callable] = None,
-                 device_step: bool = False, wgrad_stream: bool = False, buckets: int = 4, bucket_after=None):
+                 device_step: bool = False, wgrad_stream: bool = False, buckets: int = 4, bucket_after=None,
+                 force_collectives: bool = False):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # (force_collectives: a world of ONE rank still broadcasts / all-reduces -- the N > 1 code path rehearsed on one GPU over RCCL)
+        self.collectives = self.world > 1 or (force_collectives and dist.is_available() and dist.is_initialized())
         self.fp = FlatParams(model)
-        if self.world > 1:                                         # identical replicas: rank 0's weights win
+        if self.collectives:                                         # identical replicas: rank 0's weights win
             dist.broadcast(self.fp.flat, src=0, group=group)
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
@@ -145,7 +148,7 @@ class DataParallelTrainer:
         self.side = torch.cuda.Stream() if (wgrad_stream and self.fp.flat.is_cuda) else None
         self.overlap = True                                        # False: every range after the backward pass (graphs.GraphedShardStep)
         self._pending, self._done_upto = [], None
-        self.bucket_starts = self._plan_buckets(max(1, int(buckets)), bucket_after) if self.world > 1 else []
+        self.bucket_starts = self._plan_buckets(max(1, int(buckets)), bucket_after) if self.collectives else []
 
     # ---- bucket plan ------------------------------------------------------------------------------------------------
     def _plan_buckets(self, n_buckets: int, bucket_after):
@@ -232,7 +235,7 @@ class DataParallelTrainer:
         """[local NORMAL-node count | gradients of the local squared-error sum] -> all-reduce (the ranges not yet under way; with
         nothing under way -- captured backward pass -- ONE collective over the whole buffer) -> scale to the gradient of the global mean (flag.py:150-152
         over the whole batch) -> fused Adam.  Returns this rank's share of the global-mean loss."""
-        if self.world > 1:
+        if self.collectives:
             # (no boundary fired -- world of one bucket, or a captured backward pass, graphs.GraphedShardStep, where nothing can
             # be overlapped: ONE collective over the whole buffer; otherwise the range of the first parameters + the count)
             self._reduce_from(0)

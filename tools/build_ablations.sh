@@ -8,6 +8,6 @@ make -s
 mkdir -p ../hgn_amd/abl
 for n in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -I../../include -DHGN_ABL=$n -c mlp6.hip -o /tmp/mlp6_abl$n.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../hgn_amd/abl/libhgn_mp_abl$n.so mlp.o /tmp/mlp6_abl$n.o ws_fwd.o fused_bwd.o segment.o wgrad.o features.o host.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../hgn_amd/abl/libhgn_mp_abl$n.so mlp.o /tmp/mlp6_abl$n.o fused_bwd.o segment.o wgrad.o features.o host.o
   echo built abl$n
 done
