@@ -78,22 +78,45 @@ __device__ __forceinline__ void t_store_rows_x(const Act& a, float* __restrict__
     else if (R.valid[u]) t_store(act, (base) + R.row[u] * (ld), kq);                                             \
   } while (0)
 #endif
+// NWV = 5 ("latency form", small launches): four compute waves on a 64-row tile + one loader wave that streams the packed weights
+// through a ring of three 48 KB slots (mlp6_device.h: lat_loader / gemm6_lat).  Same per-row arithmetic, bit for bit.
 template <int NS, int NP, int NWV = WG / 64>
 __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
-  constexpr bool BIG = NWV != WG / 64;
+  constexpr bool LATF = NWV == 5 || NWV == 6 || NWV == 8;      // 1, 2 or 4 loader waves (LAT is the latent width)
+  constexpr int NL = LATF ? NWV - 4 : 1;
+  constexpr bool BIG = NWV != WG / 64 && !LATF;
   constexpr int GROUPS = BIG ? NWV / 4 : NS;          // 64-row sub-tiles of the workgroup's tile
   static_assert(!BIG || (NS == 1 && NWV % 4 == 0), "big workgroups: one 16-row sub-tile per wave, whole 64-row groups");
-  constexpr int LDS_BF16 = BIG ? (BLOCK_BF16 > GROUPS * SEG_LDS_FLOATS * 2 ? BLOCK_BF16 : GROUPS * SEG_LDS_FLOATS * 2) : HALF_BF16;
+  static_assert(!LATF || NS == 1, "latency form: one 16-row sub-tile per compute wave");
+  constexpr int LDS_BF16 = LATF ? 3 * HALF_BF16 : BIG ? (BLOCK_BF16 > GROUPS * SEG_LDS_FLOATS * 2 ? BLOCK_BF16 : GROUPS * SEG_LDS_FLOATS * 2) : HALF_BF16;
   __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_BF16];
   __shared__ int seg_ids_lds[GROUPS][SEG_PRE_INTS];   // see SegPre
   static_assert(HALF_BF16 * 2 >= SEG_LDS_FLOATS * 4, "the weight stage doubles as the segment-sum tile");
   constexpr bool STAGED = NS == 2 && !BIG;            // 2 workgroups / CU: 48 KB weight stage + 16 KB store stage each
   __shared__ __attribute__((aligned(16))) float stage_lds[STAGED ? WG / 64 : 1][STAGED ? 1024 : 4];
   const int kq = (threadIdx.x & 63) >> 4;
-  const Rows<NS, NWV> R(a.M);
+  if constexpr (LATF) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {       // a loader wave: the blocks in the order of the code below
+      int si = 0, k0 = 0, tail = 0;
+      lat_loader<NP, NL>(lds, (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - 4u, [&]() -> const __bf16* {
+        if (si < a.n_src) {
+          const __bf16* p = reinterpret_cast<const __bf16*>(a.src[si].Wpk) + (long)(k0 >> 7) * BLOCK_BF16;
+          k0 += 128;
+          if (k0 >= a.src[si].K) { ++si; k0 = 0; }
+          return p;
+        }
+        ++tail;
+        return tail == 1 ? reinterpret_cast<const __bf16*>(a.W2pk) : tail == 2 ? reinterpret_cast<const __bf16*>(a.W3pk) : nullptr;
+      });
+      return;
+    }
+  }
+  const Rows<NS, LATF ? WG / 64 : NWV> R(a.M);
   const int grp = BIG ? (int)(threadIdx.x >> 8) : 0, ltid = BIG ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
+  int ring_slot = 0;
   auto block = [&](Act (&acc_)[NS], Act (&b_)[NS], const __bf16* pk_, auto&& between_, auto&& post_) {
-    if constexpr (BIG) gemm6_big<NS, NP, NWV>(acc_, b_, lds, pk_, between_, post_);
+    if constexpr (LATF) gemm6_lat<NP>(acc_, b_, lds, ring_slot, between_, post_);
+    else if constexpr (BIG) gemm6_big<NS, NP, NWV>(acc_, b_, lds, pk_, between_, post_);
     else gemm6<NS, NP>(acc_, b_, lds, pk_, between_, post_);
   };
   auto nothing = [](Act (&)[NS]) {};
@@ -400,6 +423,9 @@ namespace hgn {
 // weight DMA, LDS operand reads, waits and barriers per row; edge forward 1.156 -> 1.141 ms, whole step 66.2 -> 65.6 ms at 1.19 M
 // rows, same bits.  (The backward is 4 % SLOWER that way, small launches lose workgroups: both keep 64-row tiles.)
 constexpr long FWD128_MIN_ROWS = 192L * 256 * 2;
+// Forward launches of at most LAT_MAX_TILES 64-row tiles (one per CU): the latency form (mlp6_fwd_kernel<1, NP, 5>).
+constexpr long LAT_MAX_TILES = 256;
+constexpr int LAT_LOADERS = 2;                     // loader waves of the latency form (1 / 2 / 4 measured: DESIGN section 9 f4)
 #if HGN_LAB
 // ---- laboratory build only (tools/lab/build_lab.sh; never in the shipped library) --------------------------------------------
 // HGN_TILE128: two sub-tiles per wave in ALL fused MLP launches (measured no faster: forward 1.18 vs 1.21 ms, backward 1.37 vs 1.34
@@ -410,7 +436,9 @@ static unsigned lds_pad() { static const unsigned v = getenv("HGN_DIAG_LDS_PAD")
 static int g_big_tiles = getenv("HGN_BIG_TILES") ? 1 : 0;
 static long big_min_rows() { static const long v = getenv("HGN_BIG_MIN_ROWS") ? atol(getenv("HGN_BIG_MIN_ROWS")) : FWD128_MIN_ROWS; return v; }
 static bool tile128_fwd() { static const bool v = getenv("HGN_NO_TILE128_FWD") == nullptr; return v; }
+static long lat_max_tiles() { static const long v = getenv("HGN_LAT_MAX_TILES") ? atol(getenv("HGN_LAT_MAX_TILES")) : LAT_MAX_TILES; return v; }
 #else
+static constexpr long lat_max_tiles() { return LAT_MAX_TILES; }
 static constexpr bool tile128() { return false; }
 static constexpr unsigned lds_pad() { return 0u; }
 static constexpr long big_min_rows() { return FWD128_MIN_ROWS; }
@@ -432,6 +460,19 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
   }
 #endif
+  if ((a->M + TILE_ROWS - 1) / TILE_ROWS <= lat_max_tiles()) {     // a tile per CU at most: nothing to hide a weight DMA behind but loader waves
+    const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
+#if HGN_LAB
+    static const int nl = getenv("HGN_LAT_LOADERS") ? atoi(getenv("HGN_LAT_LOADERS")) : LAT_LOADERS;
+    if (matmul_products() == 6 && nl == 1) { hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 5>), dim3((unsigned)tiles), dim3(320), 0, (hipStream_t)stream, *a); return hgn_check_launch("hgn_mlp_fwd (latency form, 1 loader)"); }
+    if (matmul_products() == 6 && nl == 4) { hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 8>), dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *a); return hgn_check_launch("hgn_mlp_fwd (latency form, 4 loaders)"); }
+#endif
+    constexpr int T = 64 * (4 + LAT_LOADERS);
+    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+    else if (matmul_products() == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+    return hgn_check_launch("hgn_mlp_fwd (split-bf16, latency form)");
+  }
   if ((tile128() || (tile128_fwd() && a->M >= big_min_rows())) && matmul_products() == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
     hipLaunchKernelGGL((mlp6_fwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);

@@ -14,13 +14,16 @@
 #define HGN_ABL 0
 #endif
 #if HGN_ABL & 16
+#ifndef HGN_STAMP_BLOCK
+#define HGN_STAMP_BLOCK 5000
+#endif
 namespace hgn {
 static __device__ unsigned long long g_hgn_stamps[256];      // (one copy per translation unit: only csrc/mlp6.hip reads its own)
 static __device__ int g_hgn_stamp_n;
 }
 #define HGN_STAMP()                                                                      \
   do {                                                                                   \
-    if (blockIdx.x == 5000 && threadIdx.x == 0 && g_hgn_stamp_n < 120) {                 \
+    if (blockIdx.x == HGN_STAMP_BLOCK && threadIdx.x == 0 && g_hgn_stamp_n < 120) {      \
       g_hgn_stamps[128 + g_hgn_stamp_n] = clock64();      /* shader cycles: with the 100 MHz stamps, the in-kernel clock */ \
       g_hgn_stamps[g_hgn_stamp_n++] = wall_clock64();                                    \
     }                                                                                    \
@@ -186,7 +189,10 @@ __device__ __forceinline__ void mfma_half6_pipe2(Act& acc, const bf16x8 (&xs)[3]
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int s = 0; s < NSP; ++s) f[k][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + cl) * 8 + ob0 + k) * TILE_BF16);
+      for (int s = 0; s < NSP; ++s) {
+        if (HGN_ABL & 1024) f[k][s] = xs[s][k];        // (timing experiment: no fragment reads)
+        else f[k][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + cl) * 8 + ob0 + k) * TILE_BF16);
+      }
   };
   load_pair(0, fr[0]);
 #pragma unroll
@@ -264,6 +270,76 @@ template <int NS, int NP, class F>
 __device__ __forceinline__ void gemm6(Act (&acc)[NS], const Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
                                       F&& between) {
   gemm6<NS, NP>(acc, const_cast<Act (&)[NS]>(b), lds, pk, between, [](Act (&)[NS]) {});
+}
+
+// ---- latency form (small launches: at most a tile or two per CU, csrc/mlp6.hip: mlp6_fwd_kernel<1, NP, 5>) -----------------------
+// A workgroup that has its CU to itself (rollout: one 1 600-node graph = 146 edge tiles, 25 node tiles) spends most of a block
+// of gemm6 waiting for its own weight DMA: issue -> 2 us of L2 latency -> barrier -> products, twice per block.  Here NL extra
+// waves do nothing but stream the packed halves through a ring of three 48 KB LDS slots, two halves ahead of the products, and
+// retires each with a counted wait of its own (its vector-memory queue holds the DMAs and nothing else); the four compute waves
+// meet it at ONE barrier per half and never wait for a transfer.  Slot of half h = h mod 3; at barrier h every compute wave has
+// finished the products of half h - 1, whose slot the loader then refills with half h + 2.
+template <int NP> struct LatRing { static constexpr int PER = NP != 6 ? HALF_TILES / 3 : HALF_TILES; };   // DMA instructions per half
+
+// loader wave l of NL issues the operand tiles l, l + NL, ... of a half
+template <int NP, int NL>
+__device__ __forceinline__ void lat_issue_half(__bf16* __restrict__ slot, const __bf16* __restrict__ gsrc, unsigned l) {
+  unsigned lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+#pragma unroll
+  for (unsigned i = 0; i < (unsigned)(LatRing<NP>::PER / NL); ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (i * NL + l) * TILE_BF16 + lane * 8),
+                                     (__attribute__((address_space(3))) void*)(slot + (i * NL + l) * TILE_BF16), 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void lat_wait_keep() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+// A loader wave (l of NL): `next()` yields the packed blocks in the order the compute waves multiply them (nullptr = no more).
+template <int NP, int NL, class Next>
+__device__ __forceinline__ void lat_loader(__bf16* __restrict__ lds, unsigned l, Next&& next) {
+  static_assert(LatRing<NP>::PER % NL == 0, "whole tiles per loader wave");
+  constexpr int MINE = LatRing<NP>::PER / NL;
+  int j = 0, slot = 0;
+  for (const __bf16* pk = next(); pk != nullptr; pk = next()) {
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if (j >= 2) {                                 // half j - 2 has landed (half j - 1 may still fly); then its barrier
+        lat_wait_keep<MINE>();
+        __builtin_amdgcn_s_barrier();
+      }
+      lat_issue_half<NP, NL>(lds + slot * HALF_BF16, pk + half * HALF_BF16, l);
+      slot = slot == 2 ? 0 : slot + 1;
+      ++j;
+    }
+  }
+  lat_wait_keep<MINE>();
+  __builtin_amdgcn_s_barrier();                     // barrier H - 2
+  lat_wait_keep<0>();
+  __builtin_amdgcn_s_barrier();                     // barrier H - 1
+}
+
+// A compute wave's block: the same products in the same order as gemm6 (identical bits); `slot` is the ring position of the
+// block's first half and is advanced by two.
+template <int NP, class F, class G>
+__device__ __forceinline__ void gemm6_lat(Act (&acc)[1], Act (&b)[1], __bf16* __restrict__ lds, int& slot, F&& between, G&& post_split) {
+  bf16x8 xs[1][3][4];
+  HGN_STAMP();                                      // 0: block entered
+  between();
+  HGN_STAMP();                                      // 1: caller's loads issued
+  wg_barrier_lds();                                 // half 2 b has landed
+  HGN_STAMP();                                      // 2: past the barrier of half 0
+  split_np<NP>(b[0], xs[0]);
+  post_split(b);
+  HGN_STAMP();                                      // 3: split (the caller's loads have arrived)
+  if (!(HGN_ABL & 2)) mfma_half6_sel<0, 1, NP>(acc, xs, lds + slot * HALF_BF16);
+  slot = slot == 2 ? 0 : slot + 1;
+  HGN_STAMP();                                      // 4: products of half 0 issued
+  wg_barrier_lds();                                 // half 2 b + 1 has landed
+  HGN_STAMP();                                      // 5: past the barrier of half 1
+  if (!(HGN_ABL & 2)) mfma_half6_sel<1, 1, NP>(acc, xs, lds + slot * HALF_BF16);
+  slot = slot == 2 ? 0 : slot + 1;
+  HGN_STAMP();                                      // 6: products of half 1 issued
 }
 
 // The same block for a BIG workgroup (NWV waves, one per CU) that can afford a 96 KB stage: both halves are fetched at once, so
