@@ -78,7 +78,10 @@ __device__ __forceinline__ void t_store_rows_x(const Act& a, float* __restrict__
     else if (R.valid[u]) t_store(act, (base) + R.row[u] * (ld), kq);                                             \
   } while (0)
 #endif
-// NWV = 5 ("latency form", small launches): four compute waves on a 64-row tile + one loader wave that streams the packed weights
+// Forward launches of at most LAT_MAX_TILES 64-row tiles (one per CU): the latency form (mlp6_fwd_kernel<1, NP, 4 + LAT_LOADERS>, linear6_fwd_kernel<NP, true>).
+constexpr long LAT_MAX_TILES = 256;
+constexpr int LAT_LOADERS = 2;                     // loader waves of the latency form (1 / 2 / 4 measured: DESIGN section 9 f4)
+// NWV = 5 / 6 / 8 ("latency form", small launches): four compute waves on a 64-row tile + 1 / 2 / 4 loader waves that stream the packed weights
 // through a ring of three 48 KB slots (mlp6_device.h: lat_loader / gemm6_lat).  Same per-row arithmetic, bit for bit.
 template <int NS, int NP, int NWV = WG / 64>
 __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) void mlp6_fwd_kernel(const hgn_mlp_fwd_t a) {
@@ -235,17 +238,29 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
 // single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
 struct Lin6Args { const float* x; long ldx; long M; const __bf16* pk[4]; int n_blocks; float* out; long ld_out; };
 
-template <int NP>
-__global__ __launch_bounds__(WG, 3) void linear6_fwd_kernel(const Lin6Args a) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+// LATF: the latency form (see mlp6_fwd_kernel<1, NP, 6>): 4 compute waves + LAT_LOADERS loader waves, ring of three 48 KB slots
+template <int NP, bool LATF = false>
+__global__ __launch_bounds__(LATF ? 64 * (4 + LAT_LOADERS) : WG, LATF ? 1 : 3) void linear6_fwd_kernel(const Lin6Args a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[LATF ? 3 * HALF_BF16 : HALF_BF16];
   const int kq = (threadIdx.x & 63) >> 4;
+  if constexpr (LATF) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {
+      int blk = 0;
+      lat_loader<NP, LAT_LOADERS>(lds, (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - 4u,
+                                  [&]() -> const __bf16* { return blk < a.n_blocks ? a.pk[blk++] : nullptr; });
+      return;
+    }
+  }
   const Rows<1> R(a.M);
   Act acc[1], b[1];
+  int ring_slot = 0;
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    gemm6<1, NP>(acc, b, lds, a.pk[blk], [&] {
+    auto between = [&] {
       if (blk == 0) t_load(b[0], a.x + R.rc[0] * a.ldx, kq);
       t_zero(acc[0]);
-    });
+    };
+    if constexpr (LATF) gemm6_lat<NP>(acc, b, lds, ring_slot, between, [](Act (&)[1]) {});
+    else gemm6<1, NP>(acc, b, lds, a.pk[blk], between);
     if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out + 128 * blk, kq);
   }
 }
@@ -423,9 +438,6 @@ namespace hgn {
 // weight DMA, LDS operand reads, waits and barriers per row; edge forward 1.156 -> 1.141 ms, whole step 66.2 -> 65.6 ms at 1.19 M
 // rows, same bits.  (The backward is 4 % SLOWER that way, small launches lose workgroups: both keep 64-row tiles.)
 constexpr long FWD128_MIN_ROWS = 192L * 256 * 2;
-// Forward launches of at most LAT_MAX_TILES 64-row tiles (one per CU): the latency form (mlp6_fwd_kernel<1, NP, 5>).
-constexpr long LAT_MAX_TILES = 256;
-constexpr int LAT_LOADERS = 2;                     // loader waves of the latency form (1 / 2 / 4 measured: DESIGN section 9 f4)
 #if HGN_LAB
 // ---- laboratory build only (tools/lab/build_lab.sh; never in the shipped library) --------------------------------------------
 // HGN_TILE128: two sub-tiles per wave in ALL fused MLP launches (measured no faster: forward 1.18 vs 1.21 ms, backward 1.37 vs 1.34
@@ -498,6 +510,13 @@ extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const voi
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(7, (double)M, (hipStream_t)stream);
+  if (tiles <= hgn::lat_max_tiles()) {
+    constexpr int T = 64 * (4 + hgn::LAT_LOADERS);
+    if (matmul_products() == 1) hipLaunchKernelGGL((linear6_fwd_kernel<1, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    else if (matmul_products() == 2) hipLaunchKernelGGL((linear6_fwd_kernel<2, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((linear6_fwd_kernel<6, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    return hgn_check_launch("hgn_linear_fwd6 (latency form)");
+  }
   if (matmul_products() == 1) hipLaunchKernelGGL(linear6_fwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else if (matmul_products() == 2) hipLaunchKernelGGL(linear6_fwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear6_fwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);

@@ -137,6 +137,33 @@ def _weights(sd, ln):
     return ops.MLPWeights(*ts), ts
 
 
+@pytest.mark.parametrize('widths', [[128], [128, 128], [7]], ids=['latent', 'node2src', 'encoder7'])
+def test_latency_form_forward_equals_the_throughput_kernels_bit_for_bit(widths):
+    """Launches of at most 256 tiles (one workgroup per CU: a rollout step, every small case of this file) take the latency form of
+    the forward -- loader waves streaming the packed weights through an LDS ring, csrc/mlp6_device.h: lat_loader / gemm6_lat --,
+    bigger ones the 64-row (<= 98 303 rows) or 128-row workgroups with staged weights.  Rows are independent, the products and
+    their order per accumulator are the same in all three: the first rows of a big launch must equal a small launch on those
+    rows BIT FOR BIT, saved activations and ReLU sign words included (what the backward kernels read)."""
+    from hgn_amd import ops
+    gen = torch.Generator().manual_seed(11 + len(widths))
+    sd = _mlp_sd(sum(widths), 128, True, seed=5)
+    w, _ = _weights(sd, True)
+    small, mid, big = 1000, 20000, 99000                       # 16 / 313 / 774 (x 128 rows) tiles
+    srcs = [torch.randn(big, wd, generator=gen).cuda() for wd in widths]
+    res = 0 if widths[0] == 128 else -1
+    outs = {}
+    for M in (small, mid, big):
+        use = [x[:M].clone().requires_grad_(True) for x in srcs]
+        y = ops.fused_mlp(use, w, [None] * len(use), res)
+        saved = [(t, t.shape[0] // M) for t in y.grad_fn.saves if torch.is_tensor(t) and t.dim() >= 1 and t.shape[0] >= M and t.shape[0] % M == 0]
+        outs[M] = (y.detach(), saved)
+    for M in (mid, big):
+        assert torch.equal(outs[M][0][:small], outs[small][0]), M
+        assert len(outs[M][1]) == len(outs[small][1]) and len(outs[small][1]) >= 4     # z1, z2, x-hat, rstd / sign words
+        for (a, ka), (b, kb) in zip(outs[M][1], outs[small][1]):
+            assert ka == kb and torch.equal(a[:small * ka], b[:small * kb]), (M, a.shape)
+
+
 @pytest.mark.parametrize('M', [1, 31, 128, 333])
 @pytest.mark.parametrize('case', ['encoder7', 'encoder_idx', 'node2src', 'node_pna', 'decoder3', 'latent_res'])
 def test_fused_mlp_vs_oracle(M, case):
