@@ -21,5 +21,11 @@ for n in two_launch_bwd; do python -c "import json;d=json.load(open('$O/bench_$n
 timeout -k 10 600 python bench.py --gpus 2 --backend gloo --no-cold --no-secondary --steps 10 --warmup 3 --batch 64 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2_gloo.err; echo "gpus2 rc=$?"
 timeout -k 10 600 python bench.py --gpus 2 --backend gloo --no-cold --no-secondary --steps 10 --warmup 3 --global-batch 2 > $O/bench_gpus2_gloo_strong.json 2> $O/bench_gpus2_gloo_strong.err; echo "gpus2 strong rc=$?"
 timeout -k 10 600 python bench.py --gpus 2 --backend gloo --eager --no-cold --no-secondary --steps 10 --warmup 3 --batch 16 > $O/bench_gpus2_gloo_eager_buckets.json 2> $O/bench_gpus2_gloo_eager_buckets.err; echo "gpus2 eager rc=$?"
-rm -rf $O/trace/*/*.db $O/pmc_f/*/*.db $O/pmc_w/*/*.db 2>/dev/null
+for v in "graph" "eager --eager" "eager1 --eager --buckets 1"; do
+  set -- $v; n=$1; shift
+  timeout -k 10 300 python bench.py --dp-rehearsal --no-prof --steps 20 --warmup 5 "$@" > $O/bench_dp_rehearsal_$n.json 2> $O/bench_dp_rehearsal_$n.err; echo "dp rehearsal $n rc=$?"
+done
+timeout -k 10 300 python tools/rolloutbench.py > $O/rollout.json 2> $O/rollout.err; echo "rollout rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rollout_trace -- python3 tools/rolloutbench.py --no-cpu --steps 20 > /dev/null 2> $O/rollout_trace.err; python tools/kernel_split.py $O/rollout_trace > $O/rollout_kernels.csv
+rm -rf $O/trace/*/*.db $O/pmc_f/*/*.db $O/pmc_w/*/*.db $O/rollout_trace/*/*.db 2>/dev/null
 python -c "import json;d=json.load(open('$O/bench_default.json'));print('default', d['ms_per_step'], d['value'], json.dumps(d['roofline']), json.dumps(d.get('cpu_baseline')), json.dumps(d.get('cold_step')), json.dumps(d.get('secondary')))"

@@ -30,5 +30,18 @@ for tag, f in (('gpus2_gloo_one_gpu_rehearsal', 'bench_gpus2_gloo.json'), ('gpus
 out['_note'] = ('two_launch_bwd = HGN_NO_FUSED_BWD=1 (the round-1 edge backward), fp16 / bf16 = '
                 f'--precision; everything else the defaults; one box, tools/measure_round.sh at commit {C}')
 json.dump(out, open(f'profiles/{R}_other_configs.json', 'w'), indent=1)
+dp = {'_note': 'bench.py --dp-rehearsal --no-prof --steps 20 --warmup 5: ONE rank through the N>1 code path over a one-rank RCCL communicator '
+               '(GraphedShardStep replay / eager with bucketed all-reduces; collective + scaling + Adam eager)'}
+for tag, n in (('captured_forward_backward_one_collective', 'graph'), ('eager_4_buckets_overlapped', 'eager'), ('eager_1_bucket', 'eager1')):
+    if os.path.exists(f'{O}/bench_dp_rehearsal_{n}.json'):
+        d = last_json(f'{O}/bench_dp_rehearsal_{n}.json')
+        dp[tag] = {k: d[k] for k in ('ms_per_step', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'scaling', 'collective')}
+        dp[tag]['parallelism'] = d['config']['parallelism']
+if len(dp) > 1:
+    json.dump(dp, open(f'profiles/{R}_dp_rehearsal.json', 'w'), indent=1)
+if os.path.exists(f'{O}/rollout.json'):
+    json.dump(last_json(f'{O}/rollout.json'), open(f'profiles/{R}_rollout.json', 'w'), indent=1)
+if os.path.exists(f'{O}/rollout_kernels.csv'):
+    shutil.copy(f'{O}/rollout_kernels.csv', f'profiles/{R}_rollout_kernels_latency_form.csv')
 t = json.load(open('profiles/pmc_traffic.json'))
 print('kernel sources', t['kernel_source_sha'], 'edge-level bytes per edge and layer', round(t['edge_level_bytes_per_edge_and_layer']))
