@@ -611,8 +611,26 @@ class EdgeBlockFn(torch.autograd.Function):
         # backward kernel itself when the segments are short (include/hgn_mp.h: seg_dz1)
         dP = torch.empty(N, 2 * LAT, device=dev)
         # One pass for data gradients AND weight gradients (include/hgn_mp.h: hgn_edge_bwd_fused): dz3 / dz2 never reach memory.
-        fused = (_FUSED_EDGE_BWD and pk_t is not None and E > 0 and _WGRAD_STREAM is None and accs[2] == accs[4]
-                 and bool(L.hgn_edge_bwd_fused_eligible(C.byref(b))))      # (dW3 / dW2 share one accumulate flag in hgn_wfuse_t)
+        may_fuse = _FUSED_EDGE_BWD and pk_t is not None and E > 0 and _WGRAD_STREAM is None and accs[2] == accs[4]
+        fused = may_fuse and bool(L.hgn_edge_bwd_fused_eligible(C.byref(b)))      # (dW3 / dW2 share one accumulate flag in hgn_wfuse_t)
+        if may_fuse and not fused and d_agg is not None and (d_out is None or _ld(d_out) == LAT):
+            # Several aggregates (pna) or arg-routed ones: the fused kernel gathers ONE `sum` row per edge.  The gradient that reaches e'
+            # -- d(e') + the aggregation backward scattered back to the edge rows -- is formed once by the streaming kernel
+            # (hgn_segment_reduce_bwd with `base`: the same values added in the same order as hgn_mlp_bwd's in-register d_out_eff)
+            # and handed over as d_out: 1 KB per edge row more traffic, against the two-launch backward's 2.4 KB.
+            b2 = _lib.MlpBwd.from_buffer_copy(b)
+            b2.agg_dout = None; b2.n_agg_ops = 0; b2.agg_seg = None; b2.agg_rowptr = None; b2.agg_argmax = None; b2.agg_argmin = None
+            b2.d_out = dz1.data_ptr(); b2.ld_dout = LAT                # (any aligned address: eligibility looks at shapes, not at the data)
+            if L.hgn_edge_bwd_fused_eligible(C.byref(b2)):
+                g_eff = torch.empty(E, LAT, device=dev)
+                arr, codes = _ops_array(agg_ops)
+                _lib.check(L.hgn_segment_reduce_bwd(d_agg.data_ptr(), _ld(d_agg), LAT, None, topo.rcv.data_ptr(), topo.r.rowptr.data_ptr(), E,
+                                                    arr, len(codes), amax.data_ptr() if amax is not None else None,
+                                                    amin.data_ptr() if amin is not None else None,
+                                                    d_out.data_ptr() if d_out is not None else None, g_eff.data_ptr(), LAT, st),
+                           'hgn_segment_reduce_bwd')
+                b2.d_out = g_eff.data_ptr()
+                b, fused = b2, True
         fuse_seg = (not fused and pk_t is not None and E > 0 and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
                     and L.hgn_mlp_bwd6_eligible(C.byref(b)))
         if fuse_seg:

@@ -1012,7 +1012,8 @@ def test_config4_shape_cylinder_hyper_L25_balance_vs_oracle(steps):
 def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
     """hgn_edge_bwd_fused (data gradients + weight gradients of an edge block in one persistent kernel, dz3 / dz2 never written)
     against the two-launch path it replaces (hgn_mlp_bwd + hgn_mlp_wgrad) on the same inputs: same products, other summation
-    order over rows -> 2e-6, and the fused path against the fp64 oracle at the usual tolerances.
+    order over rows -> 2e-6, and the fused path against the fp64 oracle at the usual tolerances.  `pna` / `max` blocks reach the
+    fused kernel through a streaming pre-pass that forms d(e') + the scattered aggregation backward (ops.EdgeBlockFn.backward).
     Sizes: fewer tiles than workgroups, the 146-tile benchmark graph, 1 100 tiles (several per persistent workgroup: the
     loop-carried prefetch), a ragged last tile."""
     import hgn_amd
@@ -1034,8 +1035,10 @@ def test_fused_edge_backward_equals_two_launch_backward(agg, nx, ny):
         finally:
             ops.prof_enable(False)
             ops.set_fused_edge_backward(None)
-        took_fused = fused and agg == 'sum'                  # several aggregates per edge set (pna) / arg-routing: two launches
-        assert ('edge_bwd_fused' in k) == took_fused and ('mlp_bwd_edge' in k) == (not took_fused), sorted(k)
+        # several aggregates per edge set (pna) / arg-routed ones (max): the gradient reaching e' is formed by hgn_segment_reduce_bwd
+        # (d(e') as `base`) and handed to the fused kernel as its d_out -- the same values the two-launch kernel adds in registers
+        assert ('edge_bwd_fused' in k) == fused and ('mlp_bwd_edge' in k) == (not fused), sorted(k)
+        assert ('seg_bwd' in k) == (fused and agg != 'sum'), sorted(k)
     (out_f, loss_f, g_f, ig_f), (out_u, loss_u, g_u, ig_u) = res[True], res[False]
     assert torch.equal(out_f, out_u)
     for kname in g_u:
