@@ -14,6 +14,7 @@ from typing import Dict, Optional, Sequence
 
 import torch
 
+from . import ops
 from .util import EdgeSet, MultiGraph
 
 
@@ -32,22 +33,47 @@ def _copy_in(static: MultiGraph, node_features: Sequence[torch.Tensor], edge_fea
 
 
 class GraphedForward:
-    """model(graph) for a fixed topology, replayed from a HIP graph (inference / rollout)."""
+    """model(graph) for a fixed topology, replayed from a HIP graph (inference / rollout).
+    The packed operand images of the weights (ops.packs_of: one small launch per MLP) are NOT part of the captured graph: between two
+    rollout steps the weights do not change, and at one graph per step those launches were a sixth of the replay.  Every call
+    compares the parameters' version counters and the pack epoch with what the images were made from and re-packs eagerly, into
+    the same buffers, when they have moved (an optimiser step between two rollouts)."""
 
     def __init__(self, model: torch.nn.Module, example: MultiGraph, warmup: int = 2):
         self.model = model
         self.static = _static_copy(example)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        rec = []
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):
-                model(self.static)
+            for i in range(max(1, warmup)):
+                if i == max(1, warmup) - 1:
+                    ops._pack_recorder = rec
+                try:
+                    model(self.static)
+                finally:
+                    ops._pack_recorder = None
         torch.cuda.current_stream().wait_stream(side)
+        seen, self._packs = set(), []
+        for w, t in rec:
+            if (id(w.w1), t) not in seen:
+                seen.add((id(w.w1), t))
+                self._packs.append((w, t))
+        self._sig = ops.pack_signature(self._packs)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.out = model(self.static)
+        ops._pack_in_capture = False
+        try:
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.out = model(self.static)
+        finally:
+            ops._pack_in_capture = True
 
     def __call__(self, node_features: Sequence[torch.Tensor], edge_features: Dict[str, torch.Tensor]) -> torch.Tensor:
+        sig = ops.pack_signature(self._packs)
+        if sig != self._sig:                        # the weights were updated since the images were made: same buffers, new contents
+            for w, t in self._packs:
+                ops.packs_of(w, t)
+            self._sig = ops.pack_signature(self._packs)
         _copy_in(self.static, node_features, edge_features)
         self.graph.replay()
         return self.out

@@ -128,6 +128,18 @@ def invalidate_packs() -> None:
     _pack_epoch += 1
 
 
+# graphs.GraphedForward (inference: the weights do not change between replays) keeps the pack kernels OUT of its captured graph and
+# re-packs eagerly when a version counter or the pack epoch has moved; a captured TRAINING step packs inside the graph (its own Adam
+# kernel rewrites the weights every replay).  `_pack_recorder`: list that collects the (weights, form) pairs a forward pass packs.
+_pack_in_capture = True
+_pack_recorder = None
+
+
+def pack_signature(pairs) -> tuple:
+    """What packs_of keys its cache on, for a list of (MLPWeights, transposed) pairs."""
+    return (_pack_epoch,) + tuple(v for w, _ in pairs for v in (w.w1._version, w.w2._version, w.w3._version))
+
+
 def packs_of(w: MLPWeights, transposed: bool = False):
     """-> uint8 tensor holding the packed blocks [W1 block 0 .. nb1-1, W2, W3] of this MLP (forward or transposed form; a
     first-layer width that is not a multiple of 128 gives a zero-padded last block), or None for a narrow output (decoder)."""
@@ -137,7 +149,9 @@ def packs_of(w: MLPWeights, transposed: bool = False):
     attr = '_hgn_pk_t' if transposed else '_hgn_pk'
     key = (_pack_epoch, w.w1._version, w.w2._version, w.w3._version, w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr())
     st = getattr(w.w1, attr, None)
-    capturing = torch.cuda.is_current_stream_capturing()
+    if _pack_recorder is not None:
+        _pack_recorder.append((w, transposed))
+    capturing = torch.cuda.is_current_stream_capturing() and _pack_in_capture
     if st is not None and st[0] == key and not capturing:
         return st[1]
     buf = st[1] if st is not None and st[1].numel() == (nb1 + 2) * _lib.PACK_BLOCK_BYTES else \

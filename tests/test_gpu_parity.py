@@ -616,6 +616,22 @@ def test_hip_graph_forward_and_train_step_replay():
     out0 = gf(G0.node_features, {'mesh_edges': G0.edge_sets[0].features}).clone()
     out1 = gf(G1.node_features, {'mesh_edges': G1.edge_sets[0].features}).clone()
     assert torch.equal(out0, ref0) and torch.equal(out1, ref1)
+    # The packed weight images are not part of the captured forward: weights updated between two rollouts (in-place torch update ->
+    # version counter; our Adam kernels -> pack epoch) must reach the next replay.
+    from hgn_amd import ops as _ops
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.03)
+        ref2 = model(G1).clone()
+    out2 = gf(G1.node_features, {'mesh_edges': G1.edge_sets[0].features}).clone()
+    assert torch.equal(out2, ref2) and not torch.equal(out2, ref1)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data.copy_(p.data / 1.03)             # behind the version counters, as a fused optimiser kernel would ...
+        _ops.invalidate_packs()                      # ... which then announces it
+        ref3 = model(G1).clone()
+    out3 = gf(G1.node_features, {'mesh_edges': G1.edge_sets[0].features}).clone()
+    assert torch.equal(out3, ref3)
     # training step
     N = 120
     target = torch.randn(N, 3, generator=torch.Generator().manual_seed(0)).cuda()
