@@ -204,3 +204,46 @@ class GraphedStepCache:
             return gs()
         self.entries.move_to_end(key)
         return hit[0](graph.node_features, {e.name: e.features for e in graph.edge_sets}, target, mask)
+
+
+class GraphedForwardCache:
+    """GraphedForward for the reference's rollout loops (FlagModel.rollout / _step_fn, flag.py:192-246): every step hands over a freshly
+    built graph -- new feature tensors, often new index tensors -- of ONE mesh.  The topology cache maps the index tensors to the
+    EdgeTopology objects of the first step; this class maps that tuple to a GraphedForward captured once, copies the features
+    into its static buffers and replays.  A step with a topology not seen before (plate: the world edges move with the obstacle)
+    runs eagerly; the SECOND sight of a topology captures it (a capture costs tens of milliseconds: a trajectory whose topology never
+    repeats stays eager), later ones replay.  At most `max_entries` graphs are kept (least recently used first out)."""
+
+    def __init__(self, model: torch.nn.Module, max_entries: int = 4):
+        import collections
+        self.model = model
+        self.entries = collections.OrderedDict()
+        self.seen = collections.OrderedDict()
+        self.max_entries = max_entries
+        self.captures = 0
+
+    def __call__(self, graph: MultiGraph) -> torch.Tensor:
+        from . import topology
+        n_tot = sum(x.shape[0] for x in graph.node_features)
+        dev = graph.node_features[0].device
+        topos = [topology.edge_topology(e.senders, e.receivers, n_tot, dev) for e in graph.edge_sets]
+        key = tuple((e.name, id(t), tuple(e.features.shape)) for e, t in zip(graph.edge_sets, topos)) + \
+            tuple(tuple(x.shape) for x in graph.node_features)
+        hit = self.entries.get(key)
+        if hit is None and key not in self.seen:
+            self.seen[key] = topos
+            while len(self.seen) > 4 * self.max_entries:
+                self.seen.popitem(last=False)
+            with torch.no_grad():
+                return self.model(graph)
+        if hit is None:
+            gf = GraphedForward(self.model, MultiGraph(list(graph.node_features), list(graph.edge_sets)))
+            self.entries[key] = (gf, topos)                   # the topologies stay alive with the graph that uses them
+            self.captures += 1
+            while len(self.entries) > self.max_entries:
+                self.entries.popitem(last=False)
+            hit = self.entries[key]
+        else:
+            self.entries.move_to_end(key)
+        # (a clone: the caller keeps the result across steps, the static output buffer is overwritten by the next replay)
+        return hit[0](graph.node_features, {e.name: e.features for e in graph.edge_sets}).clone()

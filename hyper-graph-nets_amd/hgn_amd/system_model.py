@@ -60,6 +60,8 @@ class AbstractSystemModel(nn.Module):
         self.message_passing_steps = params.get('message_passing_steps')
         self.message_passing_aggregator = params.get('aggregation')
         self._visualized = False
+        self.replay_rollout = True          # forward() without gradients replays a captured HIP graph per topology (graphs.GraphedForwardCache)
+        self._fwd_cache = None
         self._edge_sets = list(edge_sets)
         if self._balancer:
             from . import graph_balancer as _gb
@@ -112,6 +114,15 @@ class AbstractSystemModel(nn.Module):
         return graph
 
     def forward(self, graph):
+        # Rollout / evaluation (no gradients, on the GPU): the network is replayed from a HIP graph captured per topology, from the
+        # second time a topology is seen (graphs.GraphedForwardCache: bit-identical to the eager launches, half their time at one
+        # graph per step).  `model.replay_rollout = False` keeps every launch eager.
+        if (self.replay_rollout and not torch.is_grad_enabled() and graph.node_features[0].is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
+            if self._fwd_cache is None:
+                from . import graphs
+                self._fwd_cache = graphs.GraphedForwardCache(self.learned_model)
+            return self._fwd_cache(graph)
         return self.learned_model(graph)
 
     def evaluate(self) -> None:

@@ -292,6 +292,12 @@ def test_flag_rollout_runs_and_keeps_handles_fixed():
     assert torch.equal(ops_['pred_pos'][0], traj['world_pos'][0])
     handles = frames[0]['node_type'][:, 0] != 0
     assert torch.equal(ops_['pred_pos'][:, handles], traj['world_pos'][0][handles].expand(T, -1, -1))
+    # the steps above ran eager (step 0), captured (step 1: second sight of the topology) and replayed (steps 2, 3): the same
+    # trajectory with every launch eager is bit-identical
+    assert model._fwd_cache is not None and model._fwd_cache.captures == 1
+    model.replay_rollout = False
+    eager_ops, eager_mse = model.rollout(traj, T)
+    assert torch.equal(eager_ops['pred_pos'], ops_['pred_pos']) and torch.equal(eager_mse, mse)
 
 
 # ----------------------------------------------------------------------------------------------------------------
