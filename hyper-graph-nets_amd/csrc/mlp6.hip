@@ -235,6 +235,196 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
   HGN_STAMP();                                      // segment sums done
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// Column-split latency form (inference launches of at most 16 x LAT_MAX_TILES rows: the node MLP of a rollout step is 25 tiles of
+// 64 rows -- 25 CUs busy, each compute wave running the whole 3-layer chain of its 16 rows one product after the other).  Here a
+// workgroup takes 16 rows and its four compute waves SHARE them: wave w owns output blocks 2 w, 2 w + 1 (32 of the 128 features)
+// of every layer -- a quarter of the products per wave, four times the workgroups.  In the operand layout of the packed
+// weights contraction block c of a layer's input is exactly what lane (n, kq) holds of output blocks 2 c, 2 c + 1 of the
+// layer before, so wave w PRODUCES the split operand vectors of contraction block w from its own registers, the four waves
+// exchange them through 12 KB of LDS at the barrier that also opens the next weight half (lat_loader), and every wave reads
+// all four.  LayerNorm needs whole rows in the summation order of the other kernels: the pre-LayerNorm tile is gathered
+// through LDS and every wave normalises it (redundantly), then stores its own 32 columns.  Same products in the same order
+// per accumulator, same row sums: bit-identical to the other forms.  No saved activations, no in-kernel segment sums: launches
+// that need either take mlp6_fwd_kernel<1, NP, 4 + LAT_LOADERS>.
+template <int NP>
+__device__ __forceinline__ void cs_split8(const f32x4& v0, const f32x4& v1, bf16x8 (&o)[3]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = j < 4 ? v0[j & 3] : v1[j & 3];
+    if constexpr (NP == 2) {
+      o[0][j] = __builtin_bit_cast(__bf16, (_Float16)v);
+    } else {
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 m = (__bf16)r1;
+      const float r2 = r1 - (float)m;
+      o[0][j] = h; o[1][j] = m; o[2][j] = (__bf16)r2;
+    }
+  }
+}
+
+constexpr int CS_LOADERS = 4;
+template <int NP>
+__global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(const hgn_mlp_fwd_t a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * HALF_BF16];
+  __shared__ __attribute__((aligned(16))) bf16x8 xch[4][3][64];         // [contraction block][split][lane]
+  static_assert(sizeof(bf16x8) * 4 * 3 * 64 >= 16 * 132 * 4, "the pre-LayerNorm tile reuses the exchange buffer");
+  float* tile = reinterpret_cast<float*>(&xch[0][0][0]);                 // row stride 132 floats; free after the last block's second barrier
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= 4) {                                    // loader waves: the blocks in the order of the code below
+    int si = 0, k0 = 0, tail = 0;
+    lat_loader<NP, CS_LOADERS>(lds, (unsigned)wave - 4u, [&]() -> const __bf16* {
+      if (si < a.n_src) {
+        const __bf16* p = reinterpret_cast<const __bf16*>(a.src[si].Wpk) + (long)(k0 >> 7) * BLOCK_BF16;
+        k0 += 128;
+        if (k0 >= a.src[si].K) { ++si; k0 = 0; }
+        return p;
+      }
+      ++tail;
+      return tail == 1 ? reinterpret_cast<const __bf16*>(a.W2pk) : tail == 2 ? reinterpret_cast<const __bf16*>(a.W3pk) : nullptr;
+    });
+    return;
+  }
+  const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+  const long row = (long)blockIdx.x * 16 + n;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  const int col0 = 16 * (2 * wave) + 4 * kq, col1 = col0 + 16;          // this lane's two 4-float chunks of a 128-wide row
+  int add_row[HGN_MAX_ADD];
+#pragma unroll
+  for (int i = 0; i < HGN_MAX_ADD; ++i) add_row[i] = i < a.n_add ? a.add[i].idx[rc] : 0;
+  auto chunk = [](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+
+  f32x4 acc[2];
+  bf16x8 xs[3][4];
+  int slot = 0;
+  constexpr int NSP = NP != 6 ? 1 : 3;
+  auto produce = [&](const f32x4& v0, const f32x4& v1) {
+    bf16x8 o[3];
+    cs_split8<NP>(v0, v1, o);
+#pragma unroll
+    for (int sp = 0; sp < NSP; ++sp) xch[wave][sp][lane] = o[sp];
+  };
+  auto consume = [&] {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int sp = 0; sp < NSP; ++sp) xs[sp][c] = xch[c][sp][lane];
+  };
+  auto sweep = [&](auto HALF_) {                      // this wave's two output blocks against one weight half
+    constexpr int HALF = decltype(HALF_)::value;
+    const __bf16* lp = lds + slot * HALF_BF16 + lane * 8 + (2 * wave) * TILE_BF16;
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const int c = 2 * HALF + cl;
+      bf16x8 fr[2][3];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int sp = 0; sp < NSP; ++sp) fr[k][sp] = *reinterpret_cast<const bf16x8*>(lp + ((sp * 2 + cl) * 8 + k) * TILE_BF16);
+      f32x4 t0 = acc[0], t1 = acc[1];
+      if constexpr (NP != 6) {
+        t0 = mfma_one<NP>(fr[0][0], xs[0][c], t0);
+        t1 = mfma_one<NP>(fr[1][0], xs[0][c], t1);
+      } else {
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][2], xs[0][c], t0, 0, 0, 0);      // smallest terms first
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][2], xs[0][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[2][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[2][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][1], xs[1][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][1], xs[1][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][1], xs[0][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][1], xs[0][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[1][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[1][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[0][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[0][c], t1, 0, 0, 0);
+      }
+      acc[0] = t0; acc[1] = t1;
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  };
+  auto block = [&] {                                  // xch holds the operand vectors of this block's input
+    wg_barrier_lds();                                 // ... visible to every wave; the block's first weight half has landed
+    consume();
+    sweep(std::integral_constant<int, 0>{});
+    wg_barrier_lds();                                 // second half landed; every wave has read xch
+    sweep(std::integral_constant<int, 1>{});
+  };
+
+  bool first = true;
+  for (int si = 0; si < a.n_src; ++si) {
+    const hgn_src_t s = a.src[si];
+    const bool vec = ((s.ld & 3) == 0) && ((s.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
+    for (int k0 = 0; k0 < s.K; k0 += 128) {
+      const int kw = min(128, s.K - k0);
+      const long srow = s.idx ? (long)s.idx[rc] : rc;
+      const float* xr = s.x + srow * s.ld + k0;
+      f32x4 v[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {                   // zero beyond the source's width (the pack is zero padded there)
+        const int col = k ? col1 : col0;
+        if (vec) v[k] = col < kw ? chunk(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[k][u] = col + u < kw ? xr[col + u] : 0.f;
+        }
+      }
+      if (first) {                                    // acc = b1 + P0[row] + P1[row], in the order of the other kernels
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int col = k ? col1 : col0;
+          if (a.n_add == 0) acc[k] = chunk(a.b1 + col);
+          else {
+            f32x4 t = chunk(a.add[0].P + (long)add_row[0] * a.add[0].ld + col);
+            t = chunk(a.b1 + col) + t;
+            if (a.n_add > 1) t += chunk(a.add[1].P + (long)add_row[1] * a.add[1].ld + col);
+            acc[k] = t;
+          }
+        }
+        first = false;
+      }
+      produce(v[0], v[1]);
+      block();
+    }
+  }
+  const float* bias[2] = {a.b2, a.b3};
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[k][u] = fmaxf(acc[k][u], 0.f);
+    produce(acc[0], acc[1]);
+    acc[0] = chunk(bias[l] + col0);
+    acc[1] = chunk(bias[l] + col1);
+    block();
+  }
+  // ---- the whole pre-LayerNorm tile to every wave (row sums in the order of the other kernels) -----------------------------
+  *reinterpret_cast<f32x4*>(tile + n * 132 + col0) = acc[0];
+  *reinterpret_cast<f32x4*>(tile + n * 132 + col1) = acc[1];
+  wg_barrier_lds();                                   // (the loader waves have left: the barrier counts the compute waves)
+  Act y;
+  HGN_FOR_B(fb) y.v[fb] = *reinterpret_cast<const f32x4*>(tile + n * 132 + 16 * fb + 4 * kq);
+  if (a.ln_g) {
+    const float mean = row_sum(y) * (1.f / LAT);
+    HGN_FOR_B(fb) y.v[fb] -= mean;
+    const float var = row_sum_sq(y) * (1.f / LAT);
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    HGN_FOR_B(fb) y.v[fb] *= rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int fb = 2 * wave + k, col = k ? col1 : col0;
+    f32x4 o = y.v[0];
+    HGN_FOR_B(q) if (q == fb) o = y.v[q];             // (wave-uniform select: y is a register array)
+    if (a.ln_g) o = o * chunk(a.ln_g + col) + chunk(a.ln_b + col);
+    if (a.res) o += chunk(a.res + rc * a.ld_res + col);
+    if (valid) *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + col) = o;
+  }
+}
+
 // single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
 struct Lin6Args { const float* x; long ldx; long M; const __bf16* pk[4]; int n_blocks; float* out; long ld_out; };
 
@@ -449,8 +639,10 @@ static int g_big_tiles = getenv("HGN_BIG_TILES") ? 1 : 0;
 static long big_min_rows() { static const long v = getenv("HGN_BIG_MIN_ROWS") ? atol(getenv("HGN_BIG_MIN_ROWS")) : FWD128_MIN_ROWS; return v; }
 static bool tile128_fwd() { static const bool v = getenv("HGN_NO_TILE128_FWD") == nullptr; return v; }
 static long lat_max_tiles() { static const long v = getenv("HGN_LAT_MAX_TILES") ? atol(getenv("HGN_LAT_MAX_TILES")) : LAT_MAX_TILES; return v; }
+static bool cs_enabled() { static const bool v = getenv("HGN_NO_COLSPLIT") == nullptr; return v; }
 #else
 static constexpr long lat_max_tiles() { return LAT_MAX_TILES; }
+static constexpr bool cs_enabled() { return true; }
 static constexpr bool tile128() { return false; }
 static constexpr unsigned lds_pad() { return 0u; }
 static constexpr long big_min_rows() { return FWD128_MIN_ROWS; }
@@ -472,6 +664,14 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
   }
 #endif
+  if (a->M <= 16 * lat_max_tiles() && !a->seg_out && !a->z1 && !a->z2 && !a->xhat && !a->rstd && !a->relu_bits && cs_enabled()) {
+    const long wgs = (a->M + 15) / 16;               // inference on at most 16 rows per CU: the column-split latency form
+    constexpr int T = 64 * (4 + CS_LOADERS);
+    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+    else if (matmul_products() == 2) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<2>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_fwd_cs_kernel<6>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+    return hgn_check_launch("hgn_mlp_fwd (split-bf16, column-split latency form)");
+  }
   if ((a->M + TILE_ROWS - 1) / TILE_ROWS <= lat_max_tiles()) {     // a tile per CU at most: nothing to hide a weight DMA behind but loader waves
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
 #if HGN_LAB

@@ -164,6 +164,41 @@ def test_latency_form_forward_equals_the_throughput_kernels_bit_for_bit(widths):
             assert ka == kb and torch.equal(a[:small * ka], b[:small * kb]), (M, a.shape)
 
 
+@pytest.mark.parametrize('M', [1, 17, 333, 1600, 4096, 4100])
+@pytest.mark.parametrize('case', ['encoder7', 'encoder_idx', 'node2src', 'node_pna', 'latent_res'])
+def test_inference_forward_column_split_form_equals_training_forward_bit_for_bit(M, case):
+    """Without gradients nothing is saved for a backward pass, and launches of at most 4 096 rows take the column-split latency form
+    (csrc/mlp6.hip: mlp6_fwd_cs_kernel -- four waves share 16 rows, each owning 32 output columns, operand vectors exchanged
+    through LDS, LayerNorm on the gathered tile); with gradients the same call saves its activations and runs the row-per-wave
+    kernels.  Same products in the same order per accumulator and the same row sums: the outputs must be equal bit for bit
+    (4 100 rows: both sides run the row-per-wave form)."""
+    from hgn_amd import ops
+    gen = torch.Generator().manual_seed(M * 3 + len(case))
+    residual, idx = -1, None
+    if case == 'encoder7':
+        widths = [7]
+    elif case == 'encoder_idx':
+        widths = [128]
+        idx = torch.randint(0, 50, (M,), generator=gen)
+    elif case == 'node2src':
+        widths, residual = [128, 128], 0
+    elif case == 'node_pna':
+        widths, residual = [128, 512], 0
+    else:
+        widths, residual = [128], 0
+    sd = _mlp_sd(sum(widths), 128, True, seed=3)
+    w, _ = _weights(sd, True)
+    rows0 = 50 if idx is not None else M
+    srcs = [torch.randn(rows0 if i == 0 else M, wd, generator=gen).cuda() for i, wd in enumerate(widths)]
+    idxs = [idx.cuda().int() if idx is not None else None] + [None] * (len(srcs) - 1)
+    if idx is not None:
+        residual = -1
+    y_train = ops.fused_mlp([x.clone().requires_grad_(True) for x in srcs], w, idxs, residual).detach()
+    with torch.no_grad():
+        y_inf = ops.fused_mlp(srcs, w, idxs, residual)
+    assert torch.equal(y_inf, y_train)
+
+
 @pytest.mark.parametrize('M', [1, 31, 128, 333])
 @pytest.mark.parametrize('case', ['encoder7', 'encoder_idx', 'node2src', 'node_pna', 'decoder3', 'latent_res'])
 def test_fused_mlp_vs_oracle(M, case):
