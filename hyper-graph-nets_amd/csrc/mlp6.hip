@@ -698,6 +698,83 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
 }
 }  // namespace hgn
 
+namespace hgn {
+// Column-split latency form of the pre-projection (see mlp6_fwd_cs_kernel): 16 rows per workgroup, wave w produces the operand
+// vectors of contraction block w of the input rows and owns output blocks 2 w, 2 w + 1 of every 128-wide output block.
+template <int NP>
+__global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_fwd_cs_kernel(const Lin6Args a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * HALF_BF16];
+  __shared__ __attribute__((aligned(16))) bf16x8 xch[4][3][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= 4) {
+    int blk = 0;
+    lat_loader<NP, CS_LOADERS>(lds, (unsigned)wave - 4u, [&]() -> const __bf16* { return blk < a.n_blocks ? a.pk[blk++] : nullptr; });
+    return;
+  }
+  const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+  const long row = (long)blockIdx.x * 16 + n;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  const int col0 = 16 * (2 * wave) + 4 * kq, col1 = col0 + 16;
+  constexpr int NSP = NP != 6 ? 1 : 3;
+  {
+    const float* xr = a.x + rc * a.ldx;
+    bf16x8 o[3];
+    cs_split8<NP>(*reinterpret_cast<const f32x4*>(xr + col0), *reinterpret_cast<const f32x4*>(xr + col1), o);
+#pragma unroll
+    for (int sp = 0; sp < NSP; ++sp) xch[wave][sp][lane] = o[sp];
+  }
+  bf16x8 xs[3][4];
+  int slot = 0;
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      wg_barrier_lds();                               // this half has landed (and, the first time, the operand vectors are visible)
+      if (blk == 0 && half == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int sp = 0; sp < NSP; ++sp) xs[sp][c] = xch[c][sp][lane];
+      }
+      const __bf16* lp = lds + slot * HALF_BF16 + lane * 8 + (2 * wave) * TILE_BF16;
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        bf16x8 fr[2][3];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int sp = 0; sp < NSP; ++sp) fr[k][sp] = *reinterpret_cast<const bf16x8*>(lp + ((sp * 2 + cl) * 8 + k) * TILE_BF16);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          f32x4 t = acc[k];
+#pragma unroll
+          for (int hsel = 0; hsel < 2; ++hsel) {
+            if (hsel != half) continue;               // (xs is a register array: the contraction block is selected at compile time)
+            const int c = 2 * hsel + cl;
+            if constexpr (NP != 6) t = mfma_one<NP>(fr[k][0], xs[0][c], t);
+            else {
+              t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[k][2], xs[0][c], t, 0, 0, 0);      // smallest terms first
+              t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[k][0], xs[2][c], t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[k][1], xs[1][c], t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[k][1], xs[0][c], t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[k][0], xs[1][c], t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[k][0], xs[0][c], t, 0, 0, 0);
+            }
+          }
+          acc[k] = t;
+        }
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (valid) {
+      *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + 128 * blk + col0) = acc[0];
+      *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + 128 * blk + col1) = acc[1];
+    }
+  }
+}
+}  // namespace hgn
+
 extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
                                int64_t ld_out, void* stream) {
   if (M == 0) return HGN_OK;
@@ -710,6 +787,14 @@ extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const voi
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(7, (double)M, (hipStream_t)stream);
+  if (M <= 16 * hgn::lat_max_tiles() && hgn::cs_enabled()) {
+    constexpr int T = 64 * (4 + hgn::CS_LOADERS);
+    const long wgs = (M + 15) / 16;
+    if (matmul_products() == 1) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    else if (matmul_products() == 2) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<2>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<6>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    return hgn_check_launch("hgn_linear_fwd6 (column-split latency form)");
+  }
   if (tiles <= hgn::lat_max_tiles()) {
     constexpr int T = 64 * (4 + hgn::LAT_LOADERS);
     if (matmul_products() == 1) hipLaunchKernelGGL((linear6_fwd_kernel<1, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);

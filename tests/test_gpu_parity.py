@@ -164,6 +164,29 @@ def test_latency_form_forward_equals_the_throughput_kernels_bit_for_bit(widths):
             assert ka == kb and torch.equal(a[:small * ka], b[:small * kb]), (M, a.shape)
 
 
+def test_pre_projection_forms_agree_bit_for_bit():
+    """hgn_linear_fwd6 (h -> [h W1s^T | h W1r^T], the node-level half of the split first edge layer) has three forms by row count:
+    column-split latency form (<= 4 096 rows), row-per-wave latency form (<= 256 tiles), staged weights.  Same products, same
+    order: the first rows of a bigger launch equal a smaller launch on those rows bit for bit."""
+    import ctypes as C
+    from hgn_amd import ops, _lib
+    sd = _mlp_sd(384, 128, True, seed=9)
+    w, _ = _weights(sd, True)
+    pk = ops.packs_of(w)
+    L = _lib.lib()
+    pb = (C.c_void_p * 2)(pk.data_ptr(), pk.data_ptr() + _lib.PACK_BLOCK_BYTES)
+    h = torch.randn(20000, 128, generator=torch.Generator().manual_seed(4)).cuda()
+    outs = {}
+    for N in (1000, 4096, 9000, 20000):
+        P = torch.empty(N, 256, device='cuda')
+        _lib.check(L.hgn_linear_fwd6(h.data_ptr(), 128, N, pb, 2, P.data_ptr(), 256, _lib.stream_ptr()), 'hgn_linear_fwd6')
+        outs[N] = P
+    for N in (4096, 9000, 20000):
+        assert torch.equal(outs[N][:1000], outs[1000]), N
+    want = h.double() @ sd['m.0.layers.linear_0.weight'].double().cuda()[:, :128].t()
+    assert H.rel_err(outs[20000][:, :128], want) <= 2e-6
+
+
 @pytest.mark.parametrize('M', [1, 17, 333, 1600, 4096, 4100])
 @pytest.mark.parametrize('case', ['encoder7', 'encoder_idx', 'node2src', 'node_pna', 'latent_res'])
 def test_inference_forward_column_split_form_equals_training_forward_bit_for_bit(M, case):
