@@ -11,7 +11,7 @@ cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/d
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cold --no-secondary > $O/pmc_f.json 2> $O/pmc_f.err; echo "pmc fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cold --no-secondary > $O/pmc_w.json 2> $O/pmc_w.err; echo "pmc write rc=$?"
 python tools/make_traffic_json.py $O/pmc_f $O/pmc_w 1188096 204800 $COMMIT > $O/pmc_traffic.json; echo "traffic json rc=$?"
-for cfg in "pna --agg pna" "hyper --arch hyper --agg pna --layers 5 --clusters 16" "plate --workload plate --arch hetero --agg pna --layers 5 --clusters 31" "cylinder_fp16 --workload cylinder --arch hyper --agg pna --layers 25 --clusters 16 --precision fp16" "b1 --batch 1" "b8 --batch 8" "b21 --batch 21" "b64 --batch 64" "b256 --batch 256" "eager --eager" "bf16 --precision bf16" "fp16 --precision fp16"; do
+for cfg in "pna --agg pna" "hyper --arch hyper --agg pna --layers 5 --clusters 16" "plate --workload plate --arch hetero --agg pna --layers 5 --clusters 31" "cylinder_fp16 --workload cylinder --arch hyper --agg pna --layers 25 --clusters 16 --precision fp16 --no-prof" "b1 --batch 1" "b8 --batch 8" "b21 --batch 21" "b64 --batch 64" "b256 --batch 256" "eager --eager" "bf16 --precision bf16" "fp16 --precision fp16"; do
   set -- $cfg; n=$1; shift
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 "$@" > $O/bench_$n.json 2> $O/bench_$n.err || echo "config $n failed"
   python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true

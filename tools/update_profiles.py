@@ -20,6 +20,8 @@ out = {}
 for n in ('pna', 'hyper', 'plate', 'cylinder_fp16', 'b1', 'b8', 'b21', 'b64', 'b256', 'eager', 'bf16', 'fp16', 'two_launch_bwd'):
     if os.path.exists(f'{O}/bench_{n}.json'):
         d = last_json(f'{O}/bench_{n}.json')
+        if d is None:
+            continue
         out[n] = {'ms_per_step': d['ms_per_step'], 'edges_per_s': d['value'], 'edges_per_step': d['config'].get('edges_per_step'),
                   'steps': d['steps'], 'workload': d['config']['workload'], 'graphs_per_gpu': d['config'].get('graphs_per_gpu')}
 for tag, f in (('gpus2_gloo_one_gpu_rehearsal', 'bench_gpus2_gloo.json'), ('gpus2_gloo_one_gpu_rehearsal_strong_1_graph_per_rank', 'bench_gpus2_gloo_strong.json'),
