@@ -426,7 +426,8 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
 }
 
 // single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
-struct Lin6Args { const float* x; long ldx; long M; const __bf16* pk[4]; int n_blocks; float* out; long ld_out; };
+struct Lin6Args { const float* x; long ldx; long M; const __bf16* pk[4]; int n_blocks; float* out; long ld_out;
+                  float* zero; long ld_zero; };      // zero (optional): rows [0, M) x 128 floats set to 0 in the same pass
 
 // LATF: the latency form (see mlp6_fwd_kernel<1, NP, 6>): 4 compute waves + LAT_LOADERS loader waves, ring of three 48 KB slots
 template <int NP, bool LATF = false>
@@ -453,6 +454,7 @@ __global__ __launch_bounds__(LATF ? 64 * (4 + LAT_LOADERS) : WG, LATF ? 1 : 3) v
     else gemm6<1, NP>(acc, b, lds, a.pk[blk], between);
     if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out + 128 * blk, kq);
   }
+  if (a.zero && R.valid[0]) { t_zero(acc[0]); t_store(acc[0], a.zero + R.row[0] * a.ld_zero, kq); }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -772,16 +774,27 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_fwd_cs_kerne
       *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + 128 * blk + col1) = acc[1];
     }
   }
+  if (a.zero && valid) {
+    *reinterpret_cast<f32x4*>(a.zero + row * a.ld_zero + col0) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(a.zero + row * a.ld_zero + col1) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 }  // namespace hgn
 
+extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
+                                int64_t ld_out, float* zero_rows, int64_t ld_zero, void* stream);
 extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
                                int64_t ld_out, void* stream) {
+  return hgn_linear_fwd6z(x, ldx, M, pk_blocks, nb, out, ld_out, nullptr, 0, stream);
+}
+extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
+                                int64_t ld_out, float* zero_rows, int64_t ld_zero, void* stream) {
   if (M == 0) return HGN_OK;
-  if (!x || !pk_blocks || !out || M < 0 || nb < 1 || nb > 4 || (ldx & 3) || (ld_out & 3) || !aligned16(x) || !aligned16(out))
+  if (!x || !pk_blocks || !out || M < 0 || nb < 1 || nb > 4 || (ldx & 3) || (ld_out & 3) || !aligned16(x) || !aligned16(out) ||
+      (zero_rows && ((ld_zero & 3) || ld_zero < 128 || !aligned16(zero_rows))))
     return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: bad argument");
   Lin6Args a;
-  a.x = x; a.ldx = ldx; a.M = M; a.n_blocks = nb; a.out = out; a.ld_out = ld_out;
+  a.x = x; a.ldx = ldx; a.M = M; a.n_blocks = nb; a.out = out; a.ld_out = ld_out; a.zero = zero_rows; a.ld_zero = ld_zero;
   for (int i = 0; i < 4; ++i) a.pk[i] = i < nb ? reinterpret_cast<const __bf16*>(pk_blocks[i]) : nullptr;
   for (int i = 0; i < nb; ++i)
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: null packed block");
@@ -845,7 +858,7 @@ extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const voi
   if (!g || !pk_blocks || !dx || M < 0 || nb < 1 || nb > 4 || (ldg & 3) || (ld_dx & 3) || !aligned16(g) || !aligned16(dx))
     return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: bad argument");
   Lin6Args a;
-  a.x = g; a.ldx = ldg; a.M = M; a.n_blocks = nb; a.out = dx; a.ld_out = ld_dx;
+  a.x = g; a.ldx = ldg; a.M = M; a.n_blocks = nb; a.out = dx; a.ld_out = ld_dx; a.zero = nullptr; a.ld_zero = 0;
   for (int i = 0; i < 4; ++i) a.pk[i] = i < nb ? reinterpret_cast<const __bf16*>(pk_blocks[i]) : nullptr;
   for (int i = 0; i < nb; ++i)
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: null packed block");

@@ -95,6 +95,8 @@ _SIGS = {
     'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
     'hgn_linear_fwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
+    'hgn_linear_fwd6z': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
+                                   C.c_void_p, C.c_int64, C.c_void_p]),
     'hgn_mlp_bwd6_eligible': (C.c_int, [C.POINTER(MlpBwd)]),
     'hgn_linear_bwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_void_p]),

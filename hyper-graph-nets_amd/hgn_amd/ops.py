@@ -517,9 +517,15 @@ class EdgeBlockFn(torch.autograd.Function):
             raise _lib.HgnError(f'edge block: got {e.shape[0]} edge rows / {h_all.shape[0]} node rows, topology has {E} / {N}')
         P = torch.empty(N, 2 * LAT, device=dev)
         pk = packs_of(w) if (_ld(h_all) % 4 == 0 and h_all.data_ptr() % 16 == 0 and not _FP32_ONLY) else None
+        # the `sum` aggregate formed inside the edge kernel needs a zero-filled [N, 128] buffer: filled by the pre-projection launch,
+        # which passes over the same node rows anyway (hgn_linear_fwd6z), instead of a launch of its own
+        agg_zeroed = None
         if pk is not None:
             pb = (C.c_void_p * 2)(pk.data_ptr(), pk.data_ptr() + _lib.PACK_BLOCK_BYTES)
-            _lib.check(L.hgn_linear_fwd6(h_all.data_ptr(), _ld(h_all), N, pb, 2, P.data_ptr(), 2 * LAT, st), 'hgn_linear_fwd6')
+            if agg_ops == ('sum',) and 0 < E and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS:
+                agg_zeroed = torch.empty(N, LAT, device=dev)
+            _lib.check(L.hgn_linear_fwd6z(h_all.data_ptr(), _ld(h_all), N, pb, 2, P.data_ptr(), 2 * LAT,
+                                          agg_zeroed.data_ptr() if agg_zeroed is not None else None, LAT, st), 'hgn_linear_fwd6z')
         else:
             wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
             _lib.check(L.hgn_linear_fwd(h_all.data_ptr(), _ld(h_all), N, wb, 2, 3 * LAT, P.data_ptr(), 2 * LAT, st), 'hgn_linear_fwd')
@@ -544,7 +550,7 @@ class EdgeBlockFn(torch.autograd.Function):
         fuse_agg = (agg_ops == ('sum',) and pk is not None and 0 < E and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
                     and L.hgn_mlp_fwd6_eligible(C.byref(a)))
         if fuse_agg:
-            agg = torch.zeros(N, LAT, device=dev)
+            agg = agg_zeroed if agg_zeroed is not None else torch.zeros(N, LAT, device=dev)
             a.seg_out = agg.data_ptr(); a.ld_seg_out = LAT; a.seg_ids = topo.rcv.data_ptr()
         if E > 0:
             _lib.check(L.hgn_mlp_fwd(C.byref(a), st), 'hgn_mlp_fwd')

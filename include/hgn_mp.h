@@ -166,6 +166,11 @@ int hgn_get_matmul_products(void);
 int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd will take the split-bf16 kernel */
 int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
                     float* out, int64_t ld_out, void* stream);
+/* The same launch, which also sets zero_rows[i][0..128) = 0 for i < M (nullable; leading dimension ld_zero >= 128, a multiple of
+ * 4; 16-byte aligned): an edge block needs its node-level pre-projection AND a zero-filled aggregate buffer over the same node
+ * rows (hgn_mlp_fwd_t.seg_out) -- one pass over the rows instead of a launch of its own for the fill. */
+int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
+                     float* out, int64_t ld_out, float* zero_rows, int64_t ld_zero, void* stream);
 
 /* Backward data-gradient chain of the same MLP (LayerNorm bwd -> W3^T -> relu' -> W2^T -> relu' -> W1^T).
  * Writes dz3, dz2, dz1 ([M,128], consumed by hgn_mlp_wgrad and, for the pre-projected addends, by the
