@@ -271,7 +271,7 @@ int launch_ln_reduce(const float* ws, long n_slabs, float* part, float* d_gamma,
 
 }  // namespace hgn
 
-namespace hgn { int launch_ws_fwd(const hgn_mlp_fwd_t* a, void* stream); int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream); int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs); }
+namespace hgn { bool cs_eligible(const hgn_mlp_fwd_t* a); int launch_ws_fwd(const hgn_mlp_fwd_t* a, void* stream); int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream); int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs); }
 using namespace hgn;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -290,6 +290,15 @@ extern "C" int hgn_debug_set_stamps(void* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(hgn::g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -2;
 }
 #endif
+
+extern "C" int hgn_mlp_fwd_post_eligible(const hgn_mlp_fwd_t* a) {
+  if (!a || a->n_post < 1 || a->n_post > 4 || !a->post_out || (a->ld_post & 3) || a->ld_post < 128L * a->n_post || !aligned16(a->post_out))
+    return 0;
+  for (int i = 0; i < a->n_post; ++i)
+    if (!a->post_pk[i]) return 0;
+  if (a->post_zero && ((a->ld_post_zero & 3) || a->ld_post_zero < 128 || !aligned16(a->post_zero))) return 0;
+  return a->out_w == 128 && hgn_mlp_fwd6_eligible(a) && hgn::cs_eligible(a) ? 1 : 0;
+}
 
 extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   if (!a) return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: null args");
@@ -310,6 +319,8 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   const int kid = a->n_add ? 0 : 1;
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
+  if (a->n_post != 0 && !hgn_mlp_fwd_post_eligible(a))
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: post_* needs the column-split inference form (hgn_mlp_fwd_post_eligible)");
   if (a->seg_out && (!a->seg_ids || a->out_w != 128 || a->ld_seg_out < 128 || !hgn_mlp_fwd6_eligible(a)))
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: seg_out needs seg_ids, a 128-wide output and the split-bf16 kernel");
 #if HGN_LAB

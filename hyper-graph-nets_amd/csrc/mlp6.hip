@@ -273,7 +273,8 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
   float* tile = reinterpret_cast<float*>(&xch[0][0][0]);                 // row stride 132 floats; free after the last block's second barrier
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave >= 4) {                                    // loader waves: the blocks in the order of the code below
-    int si = 0, k0 = 0, tail = 0;
+    int si = 0, k0 = 0, tail = 0, main_halves = 4;
+    for (int i = 0; i < a.n_src; ++i) main_halves += 2 * ((a.src[i].K + 127) >> 7);
     lat_loader<NP, CS_LOADERS>(lds, (unsigned)wave - 4u, [&]() -> const __bf16* {
       if (si < a.n_src) {
         const __bf16* p = reinterpret_cast<const __bf16*>(a.src[si].Wpk) + (long)(k0 >> 7) * BLOCK_BF16;
@@ -282,8 +283,10 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
         return p;
       }
       ++tail;
-      return tail == 1 ? reinterpret_cast<const __bf16*>(a.W2pk) : tail == 2 ? reinterpret_cast<const __bf16*>(a.W3pk) : nullptr;
-    });
+      if (tail == 1) return reinterpret_cast<const __bf16*>(a.W2pk);
+      if (tail == 2) return reinterpret_cast<const __bf16*>(a.W3pk);
+      return tail - 3 < a.n_post ? reinterpret_cast<const __bf16*>(a.post_pk[tail - 3]) : nullptr;
+    }, a.n_post > 0 ? main_halves : -1);
     return;
   }
   const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
@@ -345,8 +348,8 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     }
     slot = slot == 2 ? 0 : slot + 1;
   };
-  auto block = [&] {                                  // xch holds the operand vectors of this block's input
-    wg_barrier_lds();                                 // ... visible to every wave; the block's first weight half has landed
+  auto block = [&](bool opened = false) {             // xch holds the operand vectors of this block's input
+    if (!opened) wg_barrier_lds();                    // ... visible to every wave; the block's first weight half has landed
     consume();
     sweep(std::integral_constant<int, 0>{});
     wg_barrier_lds();                                 // second half landed; every wave has read xch
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
   // ---- the whole pre-LayerNorm tile to every wave (row sums in the order of the other kernels) -----------------------------
   *reinterpret_cast<f32x4*>(tile + n * 132 + col0) = acc[0];
   *reinterpret_cast<f32x4*>(tile + n * 132 + col1) = acc[1];
-  wg_barrier_lds();                                   // (the loader waves have left: the barrier counts the compute waves)
+  wg_barrier_lds();                                   // (no post blocks: the loader waves have left; with them: the barrier that opens the first post half)
   Act y;
   HGN_FOR_B(fb) y.v[fb] = *reinterpret_cast<const f32x4*>(tile + n * 132 + 16 * fb + 4 * kq);
   if (a.ln_g) {
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     const float rstd = 1.f / sqrtf(var + 1e-5f);
     HGN_FOR_B(fb) y.v[fb] *= rstd;
   }
+  f32x4 o2[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int fb = 2 * wave + k, col = k ? col1 : col0;
@@ -422,6 +426,29 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     if (a.ln_g) o = o * chunk(a.ln_g + col) + chunk(a.ln_b + col);
     if (a.res) o += chunk(a.res + rc * a.ld_res + col);
     if (valid) *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + col) = o;
+    o2[k] = o;
+  }
+  // ---- post-projection blocks: the output rows are the next edge block's node operand (hgn_mlp_fwd_t.post_*) -------------------
+  // The barrier in front of the tile gather was the one that opens the first post half (the loader waves are still streaming);
+  // two more, which the loaders join (lat_loader: extra_after), separate the tile reads from the operand vectors that replace
+  // the tile in LDS, and those from their readers.
+  if (a.n_post > 0) {
+    wg_barrier_lds();                                 // every wave has read the tile
+    produce(o2[0], o2[1]);
+    wg_barrier_lds();                                 // the operand vectors of the output rows are visible
+    for (int pb = 0; pb < a.n_post; ++pb) {
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      block(pb == 0);                                 // (xs is re-read per block: 12 LDS reads against 48 products)
+      if (valid) {
+        *reinterpret_cast<f32x4*>(a.post_out + row * a.ld_post + 128 * pb + col0) = acc[0];
+        *reinterpret_cast<f32x4*>(a.post_out + row * a.ld_post + 128 * pb + col1) = acc[1];
+      }
+    }
+    if (a.post_zero && valid) {
+      *reinterpret_cast<f32x4*>(a.post_zero + row * a.ld_post_zero + col0) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(a.post_zero + row * a.ld_post_zero + col1) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 }
 
@@ -656,6 +683,11 @@ extern "C" int hgn_set_big_tiles(int on) { hgn::g_big_tiles = on ? 1 : 0; return
 #endif
 namespace hgn {
 
+// inference on at most 16 rows per CU, nothing saved for a backward pass, no in-kernel segment sums: the column-split latency form
+bool cs_eligible(const hgn_mlp_fwd_t* a) {
+  return a->M <= 16 * lat_max_tiles() && !a->seg_out && !a->z1 && !a->z2 && !a->xhat && !a->rstd && !a->relu_bits && cs_enabled();
+}
+
 int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
 #if HGN_LAB
   if (g_big_tiles && !tile128() && a->M >= big_min_rows()) {
@@ -666,7 +698,7 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
   }
 #endif
-  if (a->M <= 16 * lat_max_tiles() && !a->seg_out && !a->z1 && !a->z2 && !a->xhat && !a->rstd && !a->relu_bits && cs_enabled()) {
+  if (cs_eligible(a)) {
     const long wgs = (a->M + 15) / 16;               // inference on at most 16 rows per CU: the column-split latency form
     constexpr int T = 64 * (4 + CS_LOADERS);
     if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);

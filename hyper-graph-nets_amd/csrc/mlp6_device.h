@@ -296,27 +296,29 @@ template <int N> __device__ __forceinline__ void lat_wait_keep() {
 }
 
 // A loader wave (l of NL): `next()` yields the packed blocks in the order the compute waves multiply them (nullptr = no more).
+// `extra_after` (optional): the compute waves run two barriers of their own right after the barrier that opens half
+// `extra_after` (mlp6_fwd_cs_kernel: between the LayerNorm epilogue and the post-projection blocks); the loader joins them.
 template <int NP, int NL, class Next>
-__device__ __forceinline__ void lat_loader(__bf16* __restrict__ lds, unsigned l, Next&& next) {
+__device__ __forceinline__ void lat_loader(__bf16* __restrict__ lds, unsigned l, Next&& next, int extra_after = -1) {
   static_assert(LatRing<NP>::PER % NL == 0, "whole tiles per loader wave");
   constexpr int MINE = LatRing<NP>::PER / NL;
   int j = 0, slot = 0;
+  auto open = [&](int h, bool last) {               // half h has landed (a younger one may still fly); then its barrier
+    if (last) lat_wait_keep<0>(); else lat_wait_keep<MINE>();
+    __builtin_amdgcn_s_barrier();
+    if (h == extra_after) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+  };
   for (const __bf16* pk = next(); pk != nullptr; pk = next()) {
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-      if (j >= 2) {                                 // half j - 2 has landed (half j - 1 may still fly); then its barrier
-        lat_wait_keep<MINE>();
-        __builtin_amdgcn_s_barrier();
-      }
+      if (j >= 2) open(j - 2, false);
       lat_issue_half<NP, NL>(lds + slot * HALF_BF16, pk + half * HALF_BF16, l);
       slot = slot == 2 ? 0 : slot + 1;
       ++j;
     }
   }
-  lat_wait_keep<MINE>();
-  __builtin_amdgcn_s_barrier();                     // barrier H - 2
-  lat_wait_keep<0>();
-  __builtin_amdgcn_s_barrier();                     // barrier H - 1
+  open(j - 2, false);                               // barrier H - 2
+  open(j - 1, true);                                // barrier H - 1
 }
 
 // A compute wave's block: the same products in the same order as gemm6 (identical bits); `slot` is the ring position of the

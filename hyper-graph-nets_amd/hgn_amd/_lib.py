@@ -38,7 +38,9 @@ class MlpFwd(C.Structure):
                 ('W3', c_f32p), ('b3', c_f32p), ('out_w', C.c_int32), ('ln_g', c_f32p), ('ln_b', c_f32p),
                 ('res', c_f32p), ('ld_res', C.c_int64), ('out', c_f32p), ('ld_out', C.c_int64), ('z1', c_f32p),
                 ('z2', c_f32p), ('xhat', c_f32p), ('rstd', c_f32p), ('W2pk', C.c_void_p), ('W3pk', C.c_void_p),
-                ('relu_bits', C.c_void_p), ('seg_out', c_f32p), ('ld_seg_out', C.c_int64), ('seg_ids', c_i32p)]
+                ('relu_bits', C.c_void_p), ('seg_out', c_f32p), ('ld_seg_out', C.c_int64), ('seg_ids', c_i32p),
+                ('post_pk', C.c_void_p * 4), ('n_post', C.c_int32), ('post_out', c_f32p), ('ld_post', C.c_int64),
+                ('post_zero', c_f32p), ('ld_post_zero', C.c_int64)]
 
 
 class Dx(C.Structure):
@@ -93,6 +95,7 @@ _SIGS = {
     'hgn_set_matmul_products': (C.c_int, [C.c_int]),
     'hgn_get_matmul_products': (C.c_int, []),
     'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
+    'hgn_mlp_fwd_post_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
     'hgn_linear_fwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
     'hgn_linear_fwd6z': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,

@@ -81,9 +81,9 @@ def weights_of(module: nn.Module, in_features: int) -> ops.MLPWeights:
     return w
 
 
-def fused_apply(module: nn.Module, srcs: Sequence[Tensor], idxs=None, residual: int = -1) -> Tensor:
+def fused_apply(module: nn.Module, srcs: Sequence[Tensor], idxs=None, residual: int = -1, post=None):
     width = sum(s.shape[1] for s in srcs)
-    return ops.fused_mlp(srcs, weights_of(module, width), idxs, residual)
+    return ops.fused_mlp(srcs, weights_of(module, width), idxs, residual, post)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -116,11 +116,12 @@ class _SplitRows(torch.autograd.Function):
 
 
 class _Latent:
-    __slots__ = ('nodes', 'edges', 'topo', 'splits')
+    __slots__ = ('nodes', 'edges', 'topo', 'splits', 'pre')
 
     def __init__(self, nodes: List[Tensor], edges: 'OrderedDict[str, Tensor]', topo: Dict[str, topology.EdgeTopology]):
         self.nodes, self.edges, self.topo = nodes, edges, topo
         self.splits = {}
+        self.pre = {}       # edge-set name -> (P, zero-filled aggregate buffer) formed by the node kernel of the block before (inference)
 
     def split_rows(self, a: Tensor):
         """(mesh rows, hyper rows) of an [N_tot, .] tensor; one autograd node per tensor however often it is consumed."""
@@ -185,7 +186,8 @@ class GraphNet(nn.Module):
     def _edge(self, lat: _Latent, feats: Tensor, name: str, h_all: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """-> (updated edge latents, their aggregates over receivers [N_tot, k*128]); one autograd node for both."""
         h_all = lat.h_all() if h_all is None else h_all
-        return ops.edge_block(h_all, feats, lat.topo[name], weights_of(self.edge_models[name], 3 * ops.LAT), self._ops())
+        return ops.edge_block(h_all, feats, lat.topo[name], weights_of(self.edge_models[name], 3 * ops.LAT), self._ops(),
+                              pre=lat.pre.get(name))
 
     def _node(self, lat: _Latent, aggs: Sequence[Tensor], model: nn.Module, which: int):
         """nodes[which] += LN(MLP([h ; agg_1 ; agg_2 ...][rows of `which`]))   (graphnet.py:47-48,107-108,123-124).
@@ -196,7 +198,7 @@ class GraphNet(nn.Module):
         lat.nodes[which] = fused_apply(model, srcs, residual=0)
 
     # -- GraphNet.forward (graphnet.py:72-84) --------------------------------------------------------------------
-    def _forward_latent(self, lat: _Latent) -> _Latent:
+    def _forward_latent(self, lat: _Latent, nxt: Optional['GraphNet'] = None) -> _Latent:
         h_all = lat.h_all()
         new_edges, aggs = OrderedDict(), OrderedDict()
         for name, feats in lat.edges.items():
@@ -204,11 +206,29 @@ class GraphNet(nn.Module):
                 raise KeyError(name)                                           # graphnet.py:32
             new_edges[name], aggs[name] = self._edge(lat, feats, name, h_all)
         out = _Latent(list(lat.nodes), new_edges, lat.topo)
-        self._update_nodes(out, aggs)
+        if nxt is not None:                                                     # (plain blocks only: Processor.forward)
+            self._update_nodes(out, aggs, nxt)
+        else:
+            self._update_nodes(out, aggs)                                       # subclasses override this two-argument form
         return out
 
-    def _update_nodes(self, lat: _Latent, aggs):
-        self._node(lat, list(aggs.values()), self.node_model_cross, 0)       # graph order (graphnet.py:43)
+    def _update_nodes(self, lat: _Latent, aggs, nxt: Optional['GraphNet'] = None):
+        # Inference through a plain stack of blocks with ONE edge set (Processor.forward): the node kernel also forms the NEXT block's
+        # node-level pre-projection P = [h W1s^T | h W1r^T] and the zero fill of its aggregate buffer while the rows are in registers
+        post = None
+        if nxt is not None and len(lat.edges) == 1:
+            name = next(iter(lat.edges))
+            if name in nxt.edge_models:
+                pk = ops.packs_of(weights_of(nxt.edge_models[name], 3 * ops.LAT))
+                if pk is not None:
+                    post = (pk, nxt.message_passing_aggregator == 'sum')
+        if post is None:
+            self._node(lat, list(aggs.values()), self.node_model_cross, 0)   # graph order (graphnet.py:43)
+            return
+        srcs = [lat.nodes[0]] + list(aggs.values())
+        lat.nodes[0], got = fused_apply(self.node_model_cross, srcs, residual=0, post=post)
+        if got is not None:
+            lat.pre = {next(iter(lat.edges)): got}
 
     def forward(self, graph, mask=None):
         if isinstance(graph, _Latent):
@@ -358,6 +378,14 @@ class Processor(nn.Module):
         self.graphnet_blocks = nn.Sequential(*blocks)
 
     def forward(self, latent_graph):
+        blocks = list(self.graphnet_blocks)
+        # inference through plain GraphNet blocks on one node type: block i hands block i + 1 its pre-projection (GraphNet._update_nodes)
+        if (not torch.is_grad_enabled() and isinstance(latent_graph, _Latent) and len(latent_graph.nodes) == 1
+                and all(type(b) in (GraphNet, MultiGraphNet) for b in blocks)):
+            lat = latent_graph
+            for i, b in enumerate(blocks):
+                lat = b._forward_latent(lat, blocks[i + 1] if i + 1 < len(blocks) else None)
+            return lat
         return self.graphnet_blocks(latent_graph)
 
 

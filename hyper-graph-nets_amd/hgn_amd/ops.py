@@ -359,7 +359,8 @@ class MLPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, *tensors):
-        n_src, idxs, residual, has_ln, train = meta
+        n_src, idxs, residual, has_ln, train = meta[:5]
+        post = meta[5] if len(meta) > 5 else None          # (packed next-block weights, zero-fill wanted): inference only, see fused_mlp
         srcs = [_rowmajor(t) for t in tensors[:n_src]]
         wt = tensors[n_src:]
         w = MLPWeights(*wt)
@@ -395,6 +396,20 @@ class MLPFn(torch.autograd.Function):
         saves = _alloc_saves(M, has_ln, dev) if train else None
         res = srcs[residual] if residual >= 0 else None
         _fill_common_fwd(a, w, out, res, saves)
+        if post is not None and not train:
+            global _post_result
+            pk_next, want_zero = post
+            P = torch.empty(M, 2 * LAT, device=dev)
+            zero = torch.empty(M, LAT, device=dev) if want_zero else None
+            a.n_post = 2; a.post_out = P.data_ptr(); a.ld_post = 2 * LAT
+            a.post_pk[0] = pk_next.data_ptr(); a.post_pk[1] = pk_next.data_ptr() + _lib.PACK_BLOCK_BYTES
+            if zero is not None:
+                a.post_zero = zero.data_ptr(); a.ld_post_zero = LAT
+            if M > 0 and _lib.lib().hgn_mlp_fwd_post_eligible(C.byref(a)):
+                _post_result = (P, zero)
+            else:                                            # bigger launches: the pre-projection stays a launch of its own
+                a.n_post = 0; a.post_out = None; a.post_zero = None
+                _post_result = None
         if M > 0:
             _lib.check(_lib.lib().hgn_mlp_fwd(C.byref(a), _lib.stream_ptr()), 'hgn_mlp_fwd')
         if train and _GATE_LOG is not None:
@@ -483,13 +498,25 @@ class MLPFn(torch.autograd.Function):
         return (None, *dxs, *grads_w)
 
 
+_post_result = None
+
+
 def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequence[Optional[torch.Tensor]]] = None,
-              residual: int = -1) -> torch.Tensor:
+              residual: int = -1, post=None):
+    """`post` (inference only): (packs_of(weights of the NEXT edge block), zero-fill wanted) -- when the launch is small enough for
+    the column-split form the node-level pre-projection of that block (its P = [h W1s^T | h W1r^T]) and the zero fill of its
+    aggregate buffer come out of the same launch: -> (out, (P, zeros) or None)."""
     idxs = tuple(idxs) if idxs is not None else (None,) * len(srcs)
     wt = w.tensors()
     train = torch.is_grad_enabled() and any(t.requires_grad for t in list(srcs) + wt)
-    meta = (len(srcs), idxs, residual, w.ln_w is not None, train)
-    return MLPFn.apply(meta, *srcs, *wt)
+    if post is None or train:
+        out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train), *srcs, *wt)
+        return out if post is None else (out, None)
+    global _post_result
+    _post_result = None
+    out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, post), *srcs, *wt)
+    got, _post_result = _post_result, None
+    return out, got
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -501,7 +528,7 @@ class EdgeBlockFn(torch.autograd.Function):
     inside the segment-reduce kernel instead of in a separate pass)."""
 
     @staticmethod
-    def forward(ctx, topo, train, agg_ops, h_all, e, *wt):
+    def forward(ctx, topo, train, agg_ops, pre, h_all, e, *wt):
         w = MLPWeights(*wt)
         w.check()
         if w.w1.shape[1] != 3 * LAT or w.ln_w is None:
@@ -520,7 +547,9 @@ class EdgeBlockFn(torch.autograd.Function):
         # the `sum` aggregate formed inside the edge kernel needs a zero-filled [N, 128] buffer: filled by the pre-projection launch,
         # which passes over the same node rows anyway (hgn_linear_fwd6z), instead of a launch of its own
         agg_zeroed = None
-        if pk is not None:
+        if pre is not None and not train and pk is not None and tuple(pre[0].shape) == (N, 2 * LAT):
+            P, agg_zeroed = pre                              # formed by the node kernel of the block before (fused_mlp: post)
+        elif pk is not None:
             pb = (C.c_void_p * 2)(pk.data_ptr(), pk.data_ptr() + _lib.PACK_BLOCK_BYTES)
             if agg_ops == ('sum',) and 0 < E and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS:
                 agg_zeroed = torch.empty(N, LAT, device=dev)
@@ -590,7 +619,7 @@ class EdgeBlockFn(torch.autograd.Function):
         E, N = topo.num_edges, topo.num_nodes
         st = _lib.stream_ptr()
         if d_out is None and d_agg is None:
-            return (None,) * (5 + len(wt))
+            return (None,) * (6 + len(wt))
         dev = (d_out if d_out is not None else d_agg).device
         dz3 = dz2 = None              # [E,128] each, only on the two-launch path (the fused kernel keeps them on chip)
         dz1 = torch.empty((E + 63) // 64 * 64, LAT, device=dev)[:E]      # whole 64-row tiles: hgn_edge_bwd_fused stores the padding rows too
@@ -695,7 +724,7 @@ class EdgeBlockFn(torch.autograd.Function):
                         dw1.data_ptr() + 4 * LAT, 3 * LAT, None, accs[0])]
         _run_wgrad(tasks, N, dev, keep=[h_all, dP], defer=True)
         dh = None
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[4]:                      # h_all (inputs: topo, train, agg_ops, pre, h_all, e, *weights)
             dh = torch.empty(N, LAT, device=dev)
             if pk_t is not None:
                 pb = (C.c_void_p * 2)(pk_t.data_ptr(), pk_t.data_ptr() + _lib.PACK_BLOCK_BYTES)
@@ -703,14 +732,14 @@ class EdgeBlockFn(torch.autograd.Function):
             else:
                 wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
                 _lib.check(L.hgn_linear_bwd(dP.data_ptr(), 2 * LAT, N, wb, 2, 3 * LAT, dh.data_ptr(), LAT, st), 'hgn_linear_bwd')
-        return (None, None, None, dh, de, *grads_w)
+        return (None, None, None, None, dh, de, *grads_w)
 
 
-def edge_block(h_all: torch.Tensor, e_sorted: torch.Tensor, topo, w: MLPWeights, agg_ops=None):
+def edge_block(h_all: torch.Tensor, e_sorted: torch.Tensor, topo, w: MLPWeights, agg_ops=None, pre=None):
     """-> e'   or, with ``agg_ops`` (e.g. ('sum',) or the four PNA ops),  (e', agg[N, len(ops)*128])."""
     wt = w.tensors()
     train = torch.is_grad_enabled() and any(t.requires_grad for t in [h_all, e_sorted] + wt)
-    return EdgeBlockFn.apply(topo, train, tuple(agg_ops) if agg_ops is not None else None, h_all, e_sorted, *wt)
+    return EdgeBlockFn.apply(topo, train, tuple(agg_ops) if agg_ops is not None else None, None if train else pre, h_all, e_sorted, *wt)
 
 
 # ------------------------------------------------------------------------------------------------------------

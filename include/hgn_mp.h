@@ -133,6 +133,13 @@ typedef struct {
    * atomically: bit-reproducible as long as no segment spans more than two tiles (always true for <= 65 rows per segment;
    * callers with larger segments use hgn_segment_reduce_fwd). */
   float* seg_out; int64_t ld_seg_out; const int32_t* seg_ids;
+  /* optional, inference launches of the column-split form only (hgn_mlp_fwd_post_eligible): n_post (1..4) further packed 128 x 128
+   * blocks applied to the OUTPUT rows in the same launch,
+   *   post_out[i][128 b .. 128 b + 128) = out[i] . post_pk[b]^T        (b < n_post; leading dimension ld_post),
+   * bit-identical to hgn_linear_fwd6 on `out` -- the node-level pre-projection of the NEXT edge block (graphnet.py:22-32: the
+   * sender / receiver column blocks of its first Linear), formed while the rows are still in registers --, and, when
+   * post_zero is given, post_zero[i][0..128) = 0 (that block's aggregate buffer, see seg_out). */
+  const void* post_pk[4]; int32_t n_post; float* post_out; int64_t ld_post; float* post_zero; int64_t ld_post_zero;
 } hgn_mlp_fwd_t;
 
 int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
@@ -164,6 +171,7 @@ int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* strea
 int hgn_set_matmul_products(int n /* 6, 1 or 2 */);
 int hgn_get_matmul_products(void);
 int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd will take the split-bf16 kernel */
+int hgn_mlp_fwd_post_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd accepts these args WITH their post_* fields */
 int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
                     float* out, int64_t ld_out, void* stream);
 /* The same launch, which also sets zero_rows[i][0..128) = 0 for i < M (nullable; leading dimension ld_zero >= 128, a multiple of

@@ -164,6 +164,27 @@ def test_latency_form_forward_equals_the_throughput_kernels_bit_for_bit(widths):
             assert ka == kb and torch.equal(a[:small * ka], b[:small * kb]), (M, a.shape)
 
 
+@pytest.mark.parametrize('agg', ['sum', 'pna'])
+def test_inference_forward_of_the_whole_model_equals_the_training_forward_bit_for_bit(agg):
+    """Without gradients a stack of plain GraphNet blocks runs its small launches in the column-split form, and every node kernel also
+    forms the NEXT block's pre-projection (and zero-fills its aggregate buffer) in the same launch (hgn_mlp_fwd_t.post_*,
+    modules.Processor.forward); with gradients every block launches its own pre-projection and saves activations.  Same
+    arithmetic in the same order: the network outputs are equal bit for bit."""
+    import hgn_amd
+    graph = synth.grid_graph(seed=5, nx=13, ny=9)
+    shapes = O.param_shapes('none', agg, 4, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=21)
+    model = H.hip_model('none', agg, 4, ['mesh_edges'], sd)
+    G = hgn_amd.MultiGraph([x.cuda() for x in graph.node_features],
+                           [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in graph.edge_sets])
+    y_train = model(G).detach()
+    with torch.no_grad():
+        y_inf = model(G)
+    assert torch.equal(y_inf, y_train)
+    out_o, _, _, _ = H.oracle_run(sd, graph, 'none', agg, torch.zeros(13 * 9, 3), torch.ones(13 * 9, dtype=torch.bool))
+    assert H.rel_err(y_inf, out_o) <= TOL_OUT
+
+
 def test_pre_projection_forms_agree_bit_for_bit():
     """hgn_linear_fwd6 (h -> [h W1s^T | h W1r^T], the node-level half of the split first edge layer) has three forms by row count:
     column-split latency form (<= 4 096 rows), row-per-wave latency form (<= 256 tiles), staged weights.  Same products, same

@@ -35,7 +35,7 @@ def test_abi_struct_sizes_match_header_layout():
     from hgn_amd import _lib
     assert C.sizeof(_lib.Src) == 48 and C.sizeof(_lib.Add) == 24 and C.sizeof(_lib.Dx) == 48
     assert C.sizeof(_lib.WTask) == 96
-    assert C.sizeof(_lib.MlpFwd) == 8 + 8 + 8 * 48 + 8 + 2 * 24 + 8 * 6 + 8 + 8 * 2 + 8 * 2 + 8 * 2 + 8 * 4 + 8 * 2 + 8 + 24
+    assert C.sizeof(_lib.MlpFwd) == 8 + 8 + 8 * 48 + 8 + 2 * 24 + 8 * 6 + 8 + 8 * 2 + 8 * 2 + 8 * 2 + 8 * 4 + 8 * 2 + 8 + 24 + (4 * 8 + 8 + 8 + 8 + 8 + 8)
     assert C.sizeof(_lib.Pack) == 40
     assert C.sizeof(_lib.MlpBwd) == 8 + 8 + 8 + 8 + 8 * 7 + 8 + 8 * 3 + 8 + 8 * 48 + (8 + 8 + 4 + 16 + 4) + 8 * 4 + 8 * 3 + 8 + 8 * 2 + 8 + 24
 
