@@ -496,12 +496,23 @@ def main():
             cache.step(fresh(), target, mask)
         torch.cuda.synchronize()
         t_hit = (time.perf_counter() - t0) / n_cold * 1e3
+        # (capturing a HIP graph empties the allocator's cache -- torch.cuda.graph.__enter__ --, so the first eager step after the
+        # capture above pays for ~45 GB of device mallocs: 0.1 s on some boxes, 2 s on others; one untimed step takes that out
+        # of a figure that is about the topology cache)
+        topo_mod.clear_cache()
+        trainer.step(fresh(), target, mask)
+        torch.cuda.synchronize()
+        ms0 = torch.cuda.memory_stats()
         t0 = time.perf_counter()
         for _ in range(3):
             topo_mod.clear_cache()
             trainer.step(fresh(), target, mask)
         torch.cuda.synchronize()
         t_miss = (time.perf_counter() - t0) / 3 * 1e3
+        ms1 = torch.cuda.memory_stats()
+        log('cold eager steps: reserved %.1f -> %.1f GB, device mallocs %d, allocator retries %d' % (
+            ms0['reserved_bytes.all.current'] / 2**30, ms1['reserved_bytes.all.current'] / 2**30,
+            ms1['segment.all.allocated'] - ms0['segment.all.allocated'], ms1['num_alloc_retries'] - ms0['num_alloc_retries']))
         cold = {'fresh_index_tensors_topology_found_by_content_ms': t_hit, 'captures': cache.captures,
                 'fresh_index_tensors_topology_rebuilt_eager_ms': t_miss,
                 'note': 'per step, 128-graph batch; replayed step with warm tensors = ms_per_step above',
