@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Build-time check of csrc/fused_bwd.hip's counted waits, run by the Makefile on the assembly of the very object it links
+(hipcc -save-temps) and by tests/test_host_cpu.py.
+
+The weight-gradient waves retire their weight-ring LDS-DMA with `s_waitcnt vmcnt(N)` in front of every phase barrier; N is the number
+of vector-memory instructions the wave issues AFTER the DMA of the piece the phase reads: the next piece's DMA and the operand fetches
+of the two phases in between (fused_bwd.hip: Keep<>).  The fetches are ordinary loads emitted by the compiler: if a toolchain merges,
+splits, duplicates or spills anything in that loop the counts are wrong and the chain reads weights that have not landed -- silently
+wrong gradients.  Checked per phase of the weight-gradient loop: DMA instructions, loads in the fetch phases only, no store, no scratch
+access, and every wait immediate against the Keep table.   usage: check_fused_counts.py <listing.s>   (exit status 0 = ok)"""
+import re
+import sys
+
+KERNEL = '_ZN3hgn21edge_bwd_fused_kernelILi6EEEvNS_9FusedArgsE'
+PHASES = 12
+DMA_PER_PHASE = 6            # Ring<6>::DPW
+LOADS_PER_FETCH = 8
+FETCH_PHASES = {1, 4, 6, 11}  # wg_fetches()
+
+
+def check(text: str) -> None:
+    at = text.index(KERNEL + ':')
+    body = text[at:text.index('.Lfunc_end', at)]
+    if 'scratch_' in body:
+        raise AssertionError('register spills in the fused backward: their memory traffic breaks the counted waits')
+    lines = [l.strip() for l in body.splitlines()]
+    total = PHASES * DMA_PER_PHASE
+    heads = [i for i, l in enumerate(lines) if 'Loop Header' in l]
+    dma_lines = [i for i, l in enumerate(lines) if l.startswith('global_load_lds_dwordx4')]
+    # the weight-gradient loop: the innermost loop that holds a whole tile's LDS-DMA instructions (the prologue's lie before it)
+    start = max(h for h in heads if sum(1 for d in dma_lines if d > h) >= total)
+    end = next(i for i in range(start, len(lines))
+               if lines[i].startswith('s_cbranch') and sum(1 for d in dma_lines if start < d < i) >= total)
+    loop = lines[start:end]
+    phases, cur = [], None
+    for l in loop:
+        if l.startswith('s_barrier'):
+            cur = {'dma': 0, 'loads': 0, 'stores': 0}
+            phases.append(cur)
+        elif cur is not None:
+            if l.startswith('global_load_lds'):
+                cur['dma'] += 1
+            elif l.startswith(('global_load', 'buffer_load', 'flat_load')):
+                cur['loads'] += 1
+            elif l.startswith(('global_store', 'buffer_store', 'flat_store', 'global_atomic')):
+                cur['stores'] += 1
+    waits = [int(re.search(r'vmcnt\((\d+)\)', l).group(1)) for l in loop if l.startswith('s_waitcnt vmcnt(') and 'lgkmcnt(0)' in l]
+    if len(phases) != PHASES or len(waits) != PHASES:
+        raise AssertionError(f'expected {PHASES} phases / waits in the weight-gradient loop, found {len(phases)} / {len(waits)}')
+    for p, ph in enumerate(phases):
+        want_loads = LOADS_PER_FETCH if p in FETCH_PHASES else 0
+        if ph['dma'] != DMA_PER_PHASE or ph['stores'] != 0 or ph['loads'] != want_loads:
+            raise AssertionError(f'phase {p}: {ph}, expected {DMA_PER_PHASE} DMA, {want_loads} loads, 0 stores')
+        keep = DMA_PER_PHASE + LOADS_PER_FETCH * (((p - 2) % PHASES) in FETCH_PHASES) + LOADS_PER_FETCH * (((p - 1) % PHASES) in FETCH_PHASES)
+        if waits[p] != keep:
+            raise AssertionError(f'phase {p}: s_waitcnt vmcnt({waits[p]}), Keep<> says {keep}')
+
+
+if __name__ == '__main__':
+    try:
+        check(open(sys.argv[1]).read())
+    except (AssertionError, ValueError, StopIteration) as e:
+        print('check_fused_counts: FAILED:', e, file=sys.stderr)
+        sys.exit(1)
+    print('check_fused_counts: ok (12 phases, counted waits match the emitted instructions)')

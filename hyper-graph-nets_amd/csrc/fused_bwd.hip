@@ -103,7 +103,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {      // one per-lane ba
 // (the compiler would drain it at its next wait) and costs three instructions per KiB.  Wave ww of the four copies operand tiles
 // i = ww + 4 k, k = 0..5, i.e. split k / 2, output block ww + 4 (k & 1): in the packed block those lie (16 (k / 2) + 4 (k & 1)) KiB
 // behind tile (split 0, output block ww), in the ring slot 4 k KiB.  M0 (the DMA's LDS base) is compiler-reserved and not assumed
-// to survive an asm statement; it is written in the statement that reads it.  s_add_u32 writes SCC: declared, or the compiler keeps
+// to survive an asm statement; it is written in the statement that reads it and declared clobbered.  s_add_u32 writes SCC: declared, or the compiler keeps
 // a scalar compare result live across the statement (it did: one clamped row index per fetch came out wrong).  Completion: a
 // counted vmcnt of the issuing wave, then a barrier.
 template <int NP>
@@ -113,7 +113,7 @@ __device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: sou
   if (NP == 1)
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
                  "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
-                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc", "m0");
   else
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
                  "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
@@ -121,7 +121,7 @@ __device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: sou
                  "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x5000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
                  "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x8000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
                  "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x9000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
-                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc", "m0");
 }
 
 __device__ __forceinline__ void split3v8(const float (&v)[8], bf16x8 (&s)[3]) {

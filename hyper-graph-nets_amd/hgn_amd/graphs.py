@@ -42,12 +42,18 @@ class GraphedForward:
     def __init__(self, model: torch.nn.Module, example: MultiGraph, warmup: int = 2):
         self.model = model
         self.static = _static_copy(example)
+        self.warmup = max(1, warmup)
+        self.captures = 0
+        self._capture()
+
+    def _capture(self):
+        model = self.model
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         rec = []
         with torch.cuda.stream(side), torch.no_grad():
-            for i in range(max(1, warmup)):
-                if i == max(1, warmup) - 1:
+            for i in range(self.warmup):
+                if i == self.warmup - 1:
                     ops._pack_recorder = rec
                 try:
                     model(self.static)
@@ -60,6 +66,7 @@ class GraphedForward:
                 seen.add((id(w.w1), t))
                 self._packs.append((w, t))
         self._sig = ops.pack_signature(self._packs)
+        self._where = ops.storage_signature(self._packs)
         self.graph = torch.cuda.CUDAGraph()
         ops._pack_in_capture = False
         try:
@@ -67,8 +74,13 @@ class GraphedForward:
                 self.out = model(self.static)
         finally:
             ops._pack_in_capture = True
+        self.captures += 1
 
     def __call__(self, node_features: Sequence[torch.Tensor], edge_features: Dict[str, torch.Tensor]) -> torch.Tensor:
+        if ops.storage_signature(self._packs) != self._where:
+            # parameter storage was re-homed since the capture (FlatParams, model.to(): the old addresses are baked into the
+            # graph and may be freed memory by now): capture again on the same static inputs
+            self._capture()
         sig = ops.pack_signature(self._packs)
         if sig != self._sig:                        # the weights were updated since the images were made: same buffers, new contents
             for w, t in self._packs:
@@ -142,6 +154,7 @@ class GraphedShardStep:
     def _fwd_bwd(self) -> torch.Tensor:
         from . import ops
         tr = self.trainer
+        ops.discard_stale_wgrad()        # tasks a failed backward pass left queued belong to no step
         tr.fp.zero_grad()
         tr._pending, tr._done_upto = [], None
         if tr.side is not None:

@@ -429,11 +429,16 @@ class MeshGraphNet(nn.Module):
         return self.decoder(MultiGraph(lat.nodes[0], None))
 
     def _make_mlp(self, output_size: int, layer_norm=True) -> nn.Module:
-        widths = [self._latent_size] * self._num_layers + [output_size]
-        network = LazyMLP(widths)
-        if layer_norm:
-            network = nn.Sequential(network, nn.LayerNorm(normalized_shape=widths[-1]))
-        return network
+        """`num_layers` hidden Linear+ReLU stages of the latent width, one output Linear; the LayerNorm'd variant is a Sequential
+        whose positions 0 / 1 are what the state_dict keys name (`...0.layers.linear_k`, `...1.weight`; meshgraphnet.py:53-60)."""
+        hidden = (self._latent_size,) * self._num_layers
+        mlp = LazyMLP([*hidden, output_size])
+        return nn.Sequential(mlp, nn.LayerNorm(output_size)) if layer_norm else mlp
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .float() / .cuda() give every parameter new storage: captured forward graphs hold the old addresses
+        ops.storage_moved()
+        return super()._apply(fn, *args, **kwargs)
 
     @staticmethod
     def get_architecture(architecture: str) -> Tuple[Type[GraphNet], bool]:

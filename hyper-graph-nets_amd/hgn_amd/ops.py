@@ -140,6 +140,21 @@ def pack_signature(pairs) -> tuple:
     return (_pack_epoch,) + tuple(v for w, _ in pairs for v in (w.w1._version, w.w2._version, w.w3._version))
 
 
+# A captured graph has the ADDRESSES of biases, LayerNorm vectors, the decoder's weights and the packed images baked in.  Whatever
+# re-homes parameter storage (parallel.FlatParams, Module.to / .float / .cuda through modules.MeshGraphNet._apply) bumps this epoch;
+# graphs.GraphedForward compares it -- and the addresses of the first-layer weights it packed -- on every call and captures again.
+_storage_epoch = 0
+
+
+def storage_moved() -> None:
+    global _storage_epoch
+    _storage_epoch += 1
+
+
+def storage_signature(pairs) -> tuple:
+    return (_storage_epoch,) + tuple(w.w1.data_ptr() for w, _ in pairs)
+
+
 def packs_of(w: MLPWeights, transposed: bool = False):
     """-> uint8 tensor holding the packed blocks [W1 block 0 .. nb1-1, W2, W3] of this MLP (forward or transposed form; a
     first-layer width that is not a multiple of 128 gives a zero-padded last block), or None for a narrow output (decoder)."""
@@ -327,8 +342,15 @@ def _ln_workspace(M: int, dev) -> torch.Tensor:
 def _grad_targets(wt):
     """Flat-gradient mode (parallel.FlatParams): a parameter tagged with ``_hgn_grad`` receives its gradient by
     ACCUMULATION straight into that buffer (zeroed once per step) and autograd gets None for it -- no per-parameter
-    add kernels.  Untagged parameters get a fresh tensor returned to autograd."""
-    return [getattr(t, '_hgn_grad', None) for t in wt]
+    add kernels.  Untagged parameters get a fresh tensor returned to autograd.  The tag only counts while it IS the parameter's
+    .grad storage: a pickled / reloaded parameter carries a copy of the attribute that belongs to no trainer."""
+    out = []
+    for t in wt:
+        tg = getattr(t, '_hgn_grad', None)
+        if tg is not None and (t.grad is None or t.grad.data_ptr() != tg.data_ptr()):
+            tg = None
+        out.append(tg)
+    return out
 
 
 def _grad_bufs(wt, targets):

@@ -40,6 +40,14 @@ class FlatParams:
         # hypergraphnet.py:54 keeps only its five sets).  They have no gradient and no storage: left alone.
         params = [p for p in params if not isinstance(p, nn.parameter.UninitializedParameter)]
         self.params = params
+        self.left_lazy = [n for n, p in module.named_parameters() if isinstance(p, nn.parameter.UninitializedParameter)]
+        if self.left_lazy:
+            import warnings
+            warnings.warn('FlatParams: %d parameter(s) still lazy after the warm-up forward are NOT part of the flat buffer '
+                          '(never broadcast, reduced or updated): %s' % (len(self.left_lazy), ', '.join(self.left_lazy[:8]) +
+                                                                          (' ...' if len(self.left_lazy) > 8 else '')))
+        self._module = module
+        self._member = {id(p) for p in params}
         # every parameter starts on a 16-byte boundary: the kernels read biases / LayerNorm affine vectors as float4
         self.offsets = []
         total = 0
@@ -60,6 +68,18 @@ class FlatParams:
             p.grad = self.grad[off:off + n].view(p.shape)
             p._hgn_grad = p.grad          # the kernels accumulate straight into this view (ops._grad_targets)
         self.numel = total
+        from . import ops
+        ops.storage_moved()               # every parameter has a new address: captured forward graphs (graphs.GraphedForward) re-capture
+
+    def check_outsiders(self):
+        """A module that was lazy when the buffer was laid out and has been exercised since (a batch with an edge set the warm-up
+        graph lacked) owns parameters that no collective and no optimiser step sees: the replicas would diverge silently."""
+        if not self.left_lazy:
+            return
+        bad = [n for n, p in self._module.named_parameters()
+               if id(p) not in self._member and p.requires_grad and not isinstance(p, nn.parameter.UninitializedParameter)]
+        if bad:
+            raise RuntimeError('parameters materialised after FlatParams was built are outside the flat buffer: ' + ', '.join(bad[:8]))
 
     def zero_grad(self):
         self.grad_ext.zero_()
@@ -111,6 +131,39 @@ class _BucketMark(torch.autograd.Function):
     def backward(ctx, *gs):
         ctx.on_backward()
         return (None, *gs)
+
+
+class _DetachedHook:
+    """What a bucket-boundary hook becomes in a pickle / deep copy of the model: the copy belongs to no trainer."""
+
+    def __call__(self, module, inputs, output):
+        return None
+
+
+class _BucketHook:
+    """Forward hook at a bucket boundary (DataParallelTrainer._plan_buckets): threads a _BucketMark through the tensors that cross
+    it.  A class instead of a closure so that a model with hooks installed still pickles (the reference checkpoints by
+    `pickle.dump` of the object that holds the network, MeshSimulator.py:492-493): the hook itself is left out of the pickle."""
+
+    def __init__(self, trainer, start: int):
+        self.trainer, self.start = trainer, start
+
+    def __reduce__(self):
+        return (_DetachedHook, ())
+
+    def _on_backward(self):
+        self.trainer._reduce_from(self.start)
+
+    def __call__(self, module, inputs, output):
+        if not (self.trainer.overlap and torch.is_grad_enabled()):
+            return None
+        tensors = []
+        _map_tensors(output, lambda x: tensors.append(x) or x)
+        live = [x for x in tensors if x.requires_grad]
+        if not live:
+            return None
+        marked = iter(_BucketMark.apply(self._on_backward, *live))
+        return _map_tensors(output, lambda x: next(marked) if x.requires_grad else x)
 
 
 class DataParallelTrainer:
@@ -185,20 +238,7 @@ class DataParallelTrainer:
         return starts
 
     def _make_hook(self, start: int):
-        def on_backward():
-            self._reduce_from(start)
-
-        def hook(module, inputs, output):
-            if not (self.overlap and torch.is_grad_enabled()):
-                return None
-            tensors = []
-            _map_tensors(output, lambda x: tensors.append(x) or x)
-            live = [x for x in tensors if x.requires_grad]
-            if not live:
-                return None
-            marked = iter(_BucketMark.apply(on_backward, *live))
-            return _map_tensors(output, lambda x: next(marked) if x.requires_grad else x)
-        return hook
+        return _BucketHook(self, start)
 
     def _reduce_from(self, start: int):
         """All-reduce grad_ext[start : the range already under way), asynchronously."""
@@ -214,8 +254,12 @@ class DataParallelTrainer:
         self._done_upto = start
 
     def step(self, graph, target: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        self.fp.check_outsiders()
         self.fp.zero_grad()
         self._pending, self._done_upto = [], None
+        if self.fp.flat.is_cuda:
+            from . import ops
+            ops.discard_stale_wgrad()                                # tasks a failed backward pass left queued belong to no step
         if self.side is not None:
             from . import ops
             self.side.wait_stream(torch.cuda.current_stream())      # the zeroed gradient buffer is visible to the side stream

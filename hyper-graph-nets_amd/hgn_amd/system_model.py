@@ -79,6 +79,16 @@ class AbstractSystemModel(nn.Module):
         self._cells_key = None
         self._cells_edges = None
 
+    def __getstate__(self):
+        """The reference pickles the whole system model at every checkpoint (MeshSimulator.py:492-493 `pickle.dump(self)`, with
+        `_network` inside) and deep-copies it for evaluation.  Captured HIP graphs (the rollout replay cache) and the per-mesh
+        edge cache are run-time state, not model state: a copy starts without them and captures again on its own device."""
+        state = super().__getstate__()
+        state['_fwd_cache'] = None
+        state['_cells_key'] = None
+        state['_cells_edges'] = None
+        return state
+
     def _select_architecture(self, connector):
         return connector if self._rmp else 'none'                     # flag.py:36, cylinder.py:36
 

@@ -300,6 +300,66 @@ def test_flag_rollout_runs_and_keeps_handles_fixed():
     assert torch.equal(eager_ops['pred_pos'], ops_['pred_pos']) and torch.equal(eager_mse, mse)
 
 
+def test_system_model_pickles_and_deep_copies_after_a_replayed_rollout():
+    """The reference's loop rolls out (no-grad forwards: captured at the second sight of a topology) and then checkpoints with
+    `pickle.dump` of the object that holds the network (MeshSimulator.py:492-493, MeshTask.py:100-110).  A captured HIP graph cannot
+    be pickled: the replay cache is run-time state and must stay out of the pickle; the copy predicts the same trajectory."""
+    import copy
+    import io
+    import pickle
+    from hgn_amd import system_model
+    T = 4
+    frames = [synth.flag_frame(seed=40 + i, nx=8, ny=6) for i in range(T)]
+    traj = {k: torch.stack([f[k] for f in frames]).cuda() for k in frames[0]}
+    model = system_model.FlagModel(flag_params('hyper', 4, False, True))
+    model.build_graph(cuda_frame(frames[0]), True)
+    model.get_target(cuda_frame(frames[0]), True)
+    ops_, mse = model.rollout(traj, T)
+    assert model._fwd_cache is not None and model._fwd_cache.captures == 1
+    blob = pickle.dumps(model)
+    twin = pickle.loads(blob)
+    assert twin._fwd_cache is None and model._fwd_cache is not None      # the live model keeps its replay cache
+    t_ops, t_mse = twin.rollout(traj, T)
+    assert torch.equal(t_ops['pred_pos'], ops_['pred_pos']) and torch.equal(t_mse, mse)
+    clone = copy.deepcopy(model)
+    c_ops, _ = clone.rollout(traj, T)
+    assert torch.equal(c_ops['pred_pos'], ops_['pred_pos'])
+    buf = io.BytesIO()
+    torch.save(model, buf)                                                # torch.save pickles the module the same way
+    assert buf.tell() > 0
+
+
+def test_replayed_rollout_follows_parameters_that_were_re_homed():
+    """A captured forward has parameter ADDRESSES baked in (biases, LayerNorm vectors, the decoder).  parallel.FlatParams moves every
+    parameter into one flat buffer, model.float() / .to() give them new storage: the old addresses are freed memory afterwards.  The
+    replay must notice and capture again -- rollout after building a trainer on the same network equals the eager rollout."""
+    from hgn_amd import parallel, system_model
+    T = 4
+    frames = [synth.flag_frame(seed=60 + i, nx=8, ny=6) for i in range(T)]
+    traj = {k: torch.stack([f[k] for f in frames]).cuda() for k in frames[0]}
+    model = system_model.FlagModel(flag_params('hyper', 4, False, True))
+    model.build_graph(cuda_frame(frames[0]), True)
+    model.get_target(cuda_frame(frames[0]), True)
+    model.rollout(traj, T)
+    cache = model._fwd_cache
+    assert cache.captures == 1
+    gf = next(iter(cache.entries.values()))[0]
+    assert gf.captures == 1
+    trainer = parallel.DataParallelTrainer(model.learned_model, lr=1e-3)          # re-homes every parameter
+    junk = [torch.full((1 << 20,), float('nan'), device='cuda') for _ in range(8)]  # whatever reuses the freed storage is poison
+    g = model.expand_graph(model.build_graph(cuda_frame(frames[0]), True), 0, T, True)
+    target = model.get_target(cuda_frame(frames[0]), True)
+    mask = torch.ones(target.shape[0], dtype=torch.bool, device='cuda')
+    trainer.step(g, target, mask)                                                   # and the weights move
+    got, got_mse = model.rollout(traj, T)
+    assert gf.captures == 2, 'the forward graph was not captured again after the parameters moved'
+    model.replay_rollout = False
+    want, want_mse = model.rollout(traj, T)
+    assert torch.isfinite(got['pred_pos']).all()
+    assert torch.equal(got['pred_pos'], want['pred_pos']) and torch.equal(got_mse, want_mse)
+    del junk
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # PlateModel: world edges by radius, 4-vertex cells, obstacle removal before clustering, hetero expansion
 # ----------------------------------------------------------------------------------------------------------------

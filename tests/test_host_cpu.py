@@ -487,34 +487,60 @@ def test_fused_backward_ring_counts_match_the_emitted_instructions(tmp_path):
     r = subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
                         '--cuda-device-only', '-S', src, '-o', out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    # the same checker the Makefile runs on the assembly of the object it links (csrc/check_fused_counts.py)
+    sys.path.insert(0, os.path.join(ROOT, 'hyper-graph-nets_amd', 'csrc'))
+    try:
+        import check_fused_counts
+    finally:
+        sys.path.pop(0)
+    check_fused_counts.check(open(out).read())
+    # ... and it does reject a stream whose counts are off: one fetch load more in phase 1
     text = open(out).read()
-    name = '_ZN3hgn21edge_bwd_fused_kernelILi6EEEvNS_9FusedArgsE'
-    body = text[text.index(name + ':'):text.index('.Lfunc_end', text.index(name + ':'))]
-    assert 'scratch_' not in body, 'register spills in the fused backward: their memory traffic breaks the counted waits'
-    lines = [l.strip() for l in body.splitlines()]
-    # the weight-gradient loop: the innermost loop that holds LDS-DMA instructions
-    heads = [i for i, l in enumerate(lines) if 'Loop Header' in l]
-    dma_lines = [i for i, l in enumerate(lines) if l.startswith('global_load_lds_dwordx4')]
-    start = max(h for h in heads if sum(1 for d in dma_lines if d > h) >= 72)      # (the prologue's 12 DMAs lie before it)
-    end = next(i for i in range(start, len(lines)) if lines[i].startswith('s_cbranch') and sum(1 for d in dma_lines if start < d < i) >= 72)
-    loop = lines[start:end]
-    phases, cur = [], None
-    for l in loop:
-        if l.startswith('s_barrier'):
-            cur = {'dma': 0, 'loads': 0, 'stores': 0, 'wait': None}
-            phases.append(cur)
-        elif cur is not None:
-            if l.startswith('global_load_lds'):
-                cur['dma'] += 1
-            elif l.startswith(('global_load', 'buffer_load', 'flat_load')):
-                cur['loads'] += 1
-            elif l.startswith(('global_store', 'buffer_store', 'flat_store', 'global_atomic')):
-                cur['stores'] += 1
-    waits = [int(re.search(r'vmcnt\((\d+)\)', l).group(1)) for l in loop if l.startswith('s_waitcnt vmcnt(') and 'lgkmcnt(0)' in l]
-    assert len(phases) == 12 and len(waits) == 12, (len(phases), len(waits))
-    fetch = {1, 4, 6, 11}
-    for p, ph in enumerate(phases):
-        assert ph['dma'] == 6 and ph['stores'] == 0, (p, ph)
-        assert ph['loads'] == (8 if p in fetch else 0), (p, ph)
-        keep = 6 + 8 * (((p - 2) % 12) in fetch) + 8 * (((p - 1) % 12) in fetch)
-        assert waits[p] == keep, (p, waits[p], keep)
+    name = check_fused_counts.KERNEL
+    end = text.index('.Lfunc_end', text.index(name + ':'))
+    at = text.rindex('global_load_dwordx2', 0, end)            # the last fetch load of the weight-gradient loop
+    broken = text[:at] + 'global_load_dwordx2 v[0:1], v0, s[0:1]\n\t' + text[at:]
+    with pytest.raises(AssertionError):
+        check_fused_counts.check(broken)
+
+
+def test_bucket_hooks_and_trainer_state_stay_out_of_model_pickles():
+    """A model under DataParallelTrainer carries forward hooks at its bucket boundaries; the reference checkpoints with pickle.dump of
+    the object that holds the network (MeshSimulator.py:492-493).  The hook object pickles as a detached no-op (it references the
+    trainer: process group, streams), and a `_hgn_grad` tag that a reloaded parameter still carries is ignored by the kernels' gradient
+    routing because it is no longer that parameter's .grad storage."""
+    import pickle
+    from hgn_amd import ops, parallel
+
+    class Holder:
+        overlap = True
+
+        def _reduce_from(self, start):
+            raise AssertionError('a detached hook must never reach a trainer')
+
+    lin = torch.nn.Linear(4, 4)
+    lin.register_forward_hook(parallel._BucketHook(Holder(), 128))
+    twin = pickle.loads(pickle.dumps(lin))
+    hooks = list(twin._forward_hooks.values())
+    assert len(hooks) == 1 and isinstance(hooks[0], parallel._DetachedHook)
+    x = torch.randn(2, 4, requires_grad=True)
+    twin(x).sum().backward()                                   # the detached hook leaves the output alone
+    # flat-gradient tags: valid while they ARE the .grad storage, ignored on a reloaded copy
+    fp = parallel.FlatParams(lin)
+    assert [t is not None for t in ops._grad_targets(list(lin.parameters()))] == [True, True]
+    reloaded = pickle.loads(pickle.dumps(lin))
+    assert all(hasattr(p, '_hgn_grad') for p in reloaded.parameters())          # the attribute does travel ...
+    assert ops._grad_targets(list(reloaded.parameters())) == [None, None]        # ... and is not trusted
+    assert fp.left_lazy == []
+
+
+def test_flat_params_reports_parameters_left_lazy_and_refuses_late_materialisation():
+    from hgn_amd import parallel
+    net = torch.nn.Sequential(torch.nn.Linear(3, 3), torch.nn.LazyLinear(2))
+    with pytest.warns(UserWarning, match='still lazy'):
+        fp = parallel.FlatParams(net)
+    assert fp.left_lazy == ['1.weight', '1.bias']
+    fp.check_outsiders()                                       # still lazy: nothing to complain about
+    net(torch.randn(1, 3))                                     # the lazy layer materialises OUTSIDE the flat buffer
+    with pytest.raises(RuntimeError, match='outside the flat buffer'):
+        fp.check_outsiders()
