@@ -287,16 +287,7 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], 
   }
 }
 
-// Row access with a UNIFORM base pointer and a 32-bit per-lane byte offset (eligibility bounds these arrays to 4 GiB): the
-// address stays one VGPR next to a scalar base instead of a hoisted 64-bit pointer per array that the allocator then spills.
-__device__ __forceinline__ void t_load32(Act& a, const float* __restrict__ base, unsigned byte_off) {
-  const char* p = reinterpret_cast<const char*>(base);
-  HGN_FOR_B(fb) a.v[fb] = *reinterpret_cast<const f32x4*>(p + (byte_off + 64u * fb));
-}
-__device__ __forceinline__ void t_store32(const Act& a, float* __restrict__ base, unsigned byte_off) {
-  char* p = reinterpret_cast<char*>(base);
-  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + (byte_off + 64u * fb)) = a.v[fb];
-}
+// (t_load32 / t_store32: hgn_device.h -- a uniform base pointer + a 32-bit per-lane byte offset; eligibility bounds these arrays to 4 GiB)
 
 #if HGN_FEXP & (16 | 256)
 // timing experiments only (WRONG rows): the same bytes with every instruction covering two whole rows (8 cache lines) instead of

@@ -247,6 +247,41 @@ __device__ __forceinline__ void t_store_rows(const Act& a, float* __restrict__ b
       if (row0 + r + 4 * q < M) *reinterpret_cast<f32x4*>(base + (row0 + r + 4 * q) * ld + 64 * h + 4 * c) = v[q];
   }
 }
+// Row access with a UNIFORM base pointer and a 32-bit per-lane byte offset (the caller bounds the array to 4 GiB): the address is one
+// VGPR next to a scalar register pair (global_load / global_store with saddr) -- no 64-bit vector arithmetic per access and no 64-bit
+// pointer per array for the allocator to keep alive.
+__device__ __forceinline__ void t_load32(Act& a, const float* __restrict__ base, unsigned byte_off) {
+  const char* p = reinterpret_cast<const char*>(base);
+  HGN_FOR_B(fb) a.v[fb] = *reinterpret_cast<const f32x4*>(p + (byte_off + 64u * fb));
+}
+__device__ __forceinline__ void t_store32(const Act& a, float* __restrict__ base, unsigned byte_off) {
+  char* p = reinterpret_cast<char*>(base);
+  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + (byte_off + 64u * fb)) = a.v[fb];
+}
+// t_store_rows for a 128-float row stride with 32-bit offsets.  `row0`: first of the wave's 16 rows; `full` (uniform): all 16 rows exist
+// -- every tile of a launch but the last: no per-row tests at all.
+__device__ __forceinline__ void t_store_rows32(const Act& a, float* __restrict__ base, unsigned row0, bool full, unsigned M, float* st) {
+  const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+  const unsigned r = lane >> 4, c = lane & 15;
+  char* p = reinterpret_cast<char*>(base);
+  const unsigned off = (row0 + r) * 512u + 16u * c;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(st + n * 64 + 4 * ((4 * q + kq) ^ n)) = a.v[4 * h + q];
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(st + (r + 4 * q) * 64 + 4 * (c ^ (r + 4 * q)));
+    if (full) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p + (off + 2048u * q + 256u * h)) = v[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (row0 + r + 4 * q < M) *reinterpret_cast<f32x4*>(p + (off + 2048u * q + 256u * h)) = v[q];
+    }
+  }
+}
 __device__ __forceinline__ void t_store_masked(const Act& a, float* __restrict__ row, int kq, int w) {
   HGN_FOR_B(fb) {
 #pragma unroll

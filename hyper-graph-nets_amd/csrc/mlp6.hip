@@ -177,9 +177,10 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
   }
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
-    relu6(acc[u]);
+    unsigned m1 = 0;
+    if (a.relu_bits) m1 = relu_with_bits(acc[u]); else relu_int(acc[u]);
     if (!(HGN_ABL & 4) && a.z1) HGN_TSTORE(acc[u], a.z1, LAT, u);
-    if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + kq] = relu_bits_of(acc[u]);
+    if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + kq] = m1;
   }
   block(b, acc, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
 #pragma unroll
@@ -187,9 +188,10 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
   }, nothing);
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
-    relu6(b[u]);
+    unsigned m2 = 0;
+    if (a.relu_bits) m2 = relu_with_bits(b[u]); else relu_int(b[u]);
     if (!(HGN_ABL & 4) && a.z2) HGN_TSTORE(b[u], a.z2, LAT, u);
-    if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + 4 + kq] = relu_bits_of(b[u]);
+    if (!(HGN_ABL & 4) && a.relu_bits && R.valid[u]) a.relu_bits[R.row[u] * 8 + 4 + kq] = m2;
   }
   block(acc, b, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
 #pragma unroll
@@ -233,6 +235,129 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
     }
   }
   HGN_STAMP();                                      // segment sums done
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// The TRAINING EDGE BLOCK as a kernel of its own (graphnet.py:22-32 on >= FWD128_MIN_ROWS receiver-sorted edge rows: 15 of these
+// launches are a quarter of a training step).  Same tiles (128 rows, two 16-row sub-tiles per wave), same products in the same order
+// and the same row sums as mlp6_fwd_kernel<2, NP> -- bit-identical results -- with everything the general kernel decides at run time
+// decided at launch (launch_mlp6_fwd checks): ONE 128-wide ungathered source, two gathered pre-projections, LayerNorm, residual, all
+// saves present, every row array 128 floats wide and below 4 GiB.  What that buys is the instruction stream: row addresses are one
+// 32-bit VGPR next to a scalar base (no 64-bit vector arithmetic, no per-source loop, no width / alignment cases), the stores of all
+// tiles but the launch's last carry no per-row test, ReLU + sign word cost three instructions per value instead of four and a half.
+// ----------------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(WG, 2) void mlp6_fwd_edge_kernel(const hgn_mlp_fwd_t a) {
+  constexpr int NS = 2;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+  __shared__ int seg_ids_lds[NS][SEG_PRE_INTS];
+  __shared__ __attribute__((aligned(16))) float stage_lds[WG / 64][1024];
+  const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned M = (unsigned)a.M;
+  const unsigned tile_row0 = (unsigned)xcd_tile() * (NS * TILE_ROWS);
+  const bool full = tile_row0 + NS * TILE_ROWS <= M;                 // uniform: every tile but the launch's last
+  unsigned row0[NS], rc[NS];                                          // the wave's first row of sub-tile u; the lane's row, clamped
+  bool valid[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    row0[u] = tile_row0 + u * TILE_ROWS + wave * WAVE_ROWS;
+    valid[u] = row0[u] + n < M;
+    rc[u] = valid[u] ? row0[u] + n : M - 1;
+  }
+  // gather indices first: the dependent row loads then cost one memory round trip, not two
+  int add_row[NS][2];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    add_row[u][0] = a.add[0].idx[rc[u]];
+    add_row[u][1] = a.add[1].idx[rc[u]];
+  }
+  SegPre seg_pre[NS];
+  if (a.seg_out) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) seg_pre[u].load(a.seg_ids, (long)tile_row0 + u * TILE_ROWS, a.M);
+  }
+  float* st = stage_lds[wave];
+  auto nothing = [](Act (&)[NS]) {};
+  Act acc[NS], b[NS];
+  const __bf16* pk1 = reinterpret_cast<const __bf16*>(a.src[0].Wpk);
+  gemm6<NS, NP>(acc, b, lds, pk1, [&] {
+    // acc = (b1 + P0[snd]) + P1[rcv] per sub-tile.  Both e tiles (HBM) go out first, then the gathered pre-projection rows (cache
+    // resident) one sub-tile at a time: with all six tiles in flight plus the bias vectors the allocator spills, and scratch traffic
+    // in this kernel would sit in the same in-order queue as every store.
+    Act p1;
+    t_load32(b[0], a.src[0].x, rc[0] * 512u + 16u * kq);
+    t_load32(b[1], a.src[0].x, rc[1] * 512u + 16u * kq);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      t_load(acc[u], a.add[0].P + (long)add_row[u][0] * a.add[0].ld, kq);
+      t_load(p1, a.add[1].P + (long)add_row[u][1] * a.add[1].ld, kq);
+      __builtin_amdgcn_sched_barrier(0);
+      HGN_FOR_B(fb) acc[u].v[fb] = *reinterpret_cast<const f32x4*>(a.b1 + 16 * fb + 4 * kq) + acc[u].v[fb];
+      HGN_FOR_B(fb) acc[u].v[fb] += p1.v[fb];
+      if (u + 1 < NS) {
+        // the next sub-tile's gather addresses "depend" on these sums: its loads cannot be issued (into yet another 64 registers)
+        // before this sub-tile's temporaries are dead -- scheduling barriers alone do not hold the adds in place
+        int i0 = add_row[u + 1][0], i1 = add_row[u + 1][1];
+        asm volatile("" : "+v"(i0), "+v"(i1)
+                     : "v"(acc[u].v[0][0]), "v"(acc[u].v[0][2]), "v"(acc[u].v[1][0]), "v"(acc[u].v[1][2]), "v"(acc[u].v[2][0]), "v"(acc[u].v[2][2]),
+                       "v"(acc[u].v[3][0]), "v"(acc[u].v[3][2]), "v"(acc[u].v[4][0]), "v"(acc[u].v[4][2]), "v"(acc[u].v[5][0]), "v"(acc[u].v[5][2]),
+                       "v"(acc[u].v[6][0]), "v"(acc[u].v[6][2]), "v"(acc[u].v[7][0]), "v"(acc[u].v[7][2]));
+        add_row[u + 1][0] = i0; add_row[u + 1][1] = i1;
+      }
+    }
+    if (a.seg_out) {
+      seg_pre[0].stash(seg_ids_lds[0]);
+      seg_pre[1].stash(seg_ids_lds[1]);
+    }
+  }, nothing);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const unsigned m = relu_with_bits(acc[u]);
+    t_store_rows32(acc[u], a.z1, row0[u], full, M, st);
+    if (valid[u]) a.relu_bits[rc[u] * 8u + kq] = m;
+  }
+  gemm6<NS, NP>(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) t_load(b[u], a.b2, kq);
+  }, nothing);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const unsigned m = relu_with_bits(b[u]);
+    t_store_rows32(b[u], a.z2, row0[u], full, M, st);
+    if (valid[u]) a.relu_bits[rc[u] * 8u + 4u + kq] = m;
+  }
+  gemm6<NS, NP>(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) t_load(acc[u], a.b3, kq);
+  }, [&](Act (&free_b)[NS]) {                       // the residual rows arrive while the last block multiplies
+#pragma unroll
+    for (int u = 0; u < NS; ++u) t_load32(free_b[u], a.res, rc[u] * 512u + 16u * kq);
+  });
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const float mean = row_sum(acc[u]) * (1.f / LAT);
+    HGN_FOR_B(fb) acc[u].v[fb] -= mean;
+    const float var = row_sum_sq(acc[u]) * (1.f / LAT);
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    HGN_FOR_B(fb) acc[u].v[fb] *= rstd;
+    t_store_rows32(acc[u], a.xhat, row0[u], full, M, st);
+    if (valid[u] && kq == 0) a.rstd[rc[u]] = rstd;
+    HGN_FOR_B(fb) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 16 * fb + 4 * kq);
+      acc[u].v[fb] = acc[u].v[fb] * gm + bt;
+    }
+    HGN_FOR_B(fb) acc[u].v[fb] += b[u].v[fb];
+    t_store_rows32(acc[u], a.out, row0[u], full, M, st);
+  }
+  if (a.seg_out) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+      if (tile_row0 + u * TILE_ROWS < M)              // uniform over the workgroup
+        tile_segment_sum(acc[u], reinterpret_cast<float*>(lds), a.seg_ids, a.seg_out, a.ld_seg_out, (long)tile_row0 + u * TILE_ROWS, a.M,
+                         seg_ids_lds[u]);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -688,6 +813,19 @@ bool cs_eligible(const hgn_mlp_fwd_t* a) {
   return a->M <= 16 * lat_max_tiles() && !a->seg_out && !a->z1 && !a->z2 && !a->xhat && !a->rstd && !a->relu_bits && cs_enabled();
 }
 
+// the arguments of a training edge block as mlp6_fwd_edge_kernel assumes them (everything else: the general kernel)
+static bool edge_block_shape(const hgn_mlp_fwd_t* a) {
+  if (getenv("HGN_NO_EDGE_FWD") || a->n_src != 1 || a->n_add != 2 || a->n_post != 0) return false;
+  const hgn_src_t& s = a->src[0];
+  if (s.K != 128 || s.idx || s.ld != 128 || !aligned16(s.x)) return false;
+  if (!a->z1 || !a->z2 || !a->xhat || !a->rstd || !a->relu_bits || !a->ln_g || !a->ln_b || !a->res) return false;
+  if (a->ld_out != 128 || a->ld_res != 128 || a->out_w != 128) return false;
+  if (!aligned16(a->z1) || !aligned16(a->z2) || !aligned16(a->xhat) || !aligned16(a->out) || !aligned16(a->res)) return false;
+  for (int i = 0; i < 2; ++i)
+    if (!a->add[i].P || !a->add[i].idx || (a->add[i].ld & 3) || !aligned16(a->add[i].P)) return false;
+  return (a->M + 2 * TILE_ROWS) * 512 < ((int64_t)1 << 32);      // 32-bit byte offsets into the [M, 128] row arrays
+}
+
 int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
 #if HGN_LAB
   if (g_big_tiles && !tile128() && a->M >= big_min_rows()) {
@@ -721,7 +859,8 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   }
   if ((tile128() || (tile128_fwd() && a->M >= big_min_rows())) && matmul_products() == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
-    hipLaunchKernelGGL((mlp6_fwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    if (edge_block_shape(a)) hipLaunchKernelGGL((mlp6_fwd_edge_kernel<6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((mlp6_fwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   } else {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
     if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);

@@ -22,10 +22,34 @@ __device__ __forceinline__ unsigned relu_bits_of(const Act& a) {
   return m;
 }
 
+// g *= relu'(z) from the sign word: bit -> all-ones / zero by a sign-extending field extract, then one AND (2 instructions per value)
 __device__ __forceinline__ void relu_mask_bits(Act& g, unsigned m) {
   HGN_FOR_B(fb)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) g.v[fb][u] = (m >> (4 * fb + u)) & 1u ? g.v[fb][u] : 0.f;
+    for (int u = 0; u < 4; ++u)
+      g.v[fb][u] = __uint_as_float(__float_as_uint(g.v[fb][u]) & (unsigned)__builtin_amdgcn_sbfe((int)m, 4 * fb + u, 1));
+}
+
+// a = relu(a) in place and its sign word (relu_bits_of), three instructions per value: the maximum of the BIT PATTERN and 0 as signed
+// integers is relu for every finite float (negative floats are negative integers, -0.0 included; fmaxf costs two instructions: the
+// compiler canonicalises its operand first), "z > 0" is "bit pattern of z != 0", i.e. the sign of 0 - bits, shifted into the word
+// from the top bit index down.
+__device__ __forceinline__ unsigned relu_with_bits(Act& a) {
+  unsigned m = 0;
+#pragma unroll
+  for (int fb = NB - 1; fb >= 0; --fb)
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+      const int z = max(__float_as_int(a.v[fb][u]), 0);
+      a.v[fb][u] = __int_as_float(z);
+      m = __builtin_amdgcn_alignbit(m, 0u - (unsigned)z, 31);
+    }
+  return m;
+}
+__device__ __forceinline__ void relu_int(Act& a) {
+  HGN_FOR_B(fb)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a.v[fb][u] = __int_as_float(max(__float_as_int(a.v[fb][u]), 0));
 }
 
 // Segment sums of the workgroup's 64 x 128 tile `v` (rows sorted by segment id) into out[seg][0..128): the tile goes through

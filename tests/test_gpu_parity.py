@@ -164,6 +164,49 @@ def test_latency_form_forward_equals_the_throughput_kernels_bit_for_bit(widths):
             assert ka == kb and torch.equal(a[:small * ka], b[:small * kb]), (M, a.shape)
 
 
+@pytest.mark.parametrize('agg', [('sum',), ('sum', 'mean', 'max', 'min'), None], ids=['sum_in_kernel', 'pna', 'no_aggregate'])
+def test_training_edge_forward_kernel_equals_the_general_kernel_bit_for_bit(agg, monkeypatch):
+    """Training edge blocks of >= 98 304 rows run mlp6_fwd_edge_kernel (csrc/mlp6.hip): the general 128-row kernel with everything it
+    decides at run time decided at launch (32-bit row offsets from scalar bases, no per-row store tests except in the launch's last
+    tile, three-instruction ReLU + sign words).  Same products, same order, same row sums: outputs, in-kernel segment sums, every
+    saved tensor the backward reads (z1, z2, x-hat, 1/sigma, sign words) and therefore every gradient must equal the general
+    kernel's BIT FOR BIT -- on a row count that is not a multiple of the tile (the last workgroup takes the tested store path)."""
+    from hgn_amd import ops, topology, modules
+    import hgn_amd
+    g = synth.batch([synth.grid_graph(seed=i % 3, nx=40, ny=40) for i in range(11)])
+    es = g.edge_sets[0]
+    N, E = g.node_features[0].shape[0], es.senders.shape[0]
+    assert E >= 98304 and E % 128 != 0
+    topo = topology.EdgeTopology(es.senders, es.receivers, N, torch.device('cuda'))
+    torch.manual_seed(3)
+    m = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges']).cuda()
+    m(hgn_amd.MultiGraph([x.cuda() for x in g.node_features], [hgn_amd.EdgeSet(es.name, es.features.cuda(), es.senders, es.receivers)]))
+    w = modules.weights_of(m.processor.graphnet_blocks[0].edge_models['mesh_edges'], 384)
+    h0, e0 = torch.randn(N, 128, device='cuda'), torch.randn(E, 128, device='cuda')
+    wsum = torch.randn(E, 128, device='cuda')
+
+    def run():
+        h, e = h0.clone().requires_grad_(True), e0.clone().requires_grad_(True)
+        for p_ in w.tensors():
+            p_.grad = None
+        out = ops.edge_block(h, e, topo, w, agg)
+        y, a_ = out if agg is not None else (out, None)
+        saves = [t.clone() for t in y.grad_fn.saves if torch.is_tensor(t)]
+        loss = (y * wsum).sum() + (a_.sum() if a_ is not None else 0.0)
+        loss.backward()
+        return [y.detach(), a_.detach() if a_ is not None else None] + saves + [h.grad, e.grad] + [p_.grad.clone() for p_ in w.tensors()]
+
+    fast = run()
+    monkeypatch.setenv('HGN_NO_EDGE_FWD', '1')
+    general = run()
+    monkeypatch.delenv('HGN_NO_EDGE_FWD')
+    assert len(fast) == len(general) and len(fast) >= 2 + 5 + 2 + 8
+    for i, (a_, b_) in enumerate(zip(fast, general)):
+        assert (a_ is None) == (b_ is None), i
+        if a_ is not None:
+            assert a_.shape == b_.shape and torch.equal(a_, b_), (i, a_.shape)
+
+
 @pytest.mark.parametrize('agg', ['sum', 'pna'])
 def test_inference_forward_of_the_whole_model_equals_the_training_forward_bit_for_bit(agg):
     """Without gradients a stack of plain GraphNet blocks runs its small launches in the column-split form, and every node kernel also

@@ -12,6 +12,8 @@ import hgn_amd
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=128)
 ap.add_argument('--iters', type=int, default=6)
+ap.add_argument('--reps', type=int, default=1)
+ap.add_argument('--ab-edge-fwd', action='store_true')
 a = ap.parse_args()
 g = synthetic.batch([synthetic.grid_graph(seed=i % 4) for i in range(a.batch)])
 es = g.edge_sets[0]
@@ -24,12 +26,21 @@ blk = m.processor.graphnet_blocks[0]
 w = modules.weights_of(blk.edge_models['mesh_edges'], 384)
 h = torch.randn(N, 128, device=dev, requires_grad=True)
 e = torch.randn(E, 128, device=dev, requires_grad=True)
-for it in range(a.iters + 2):
-    if it == 2:
-        torch.cuda.synchronize(); ops.prof_reset(); ops.prof_enable(True)
-    y, agg = ops.edge_block(h, e, topo, w, ('sum',))
-    (y.sum() + agg.sum()).backward()
-torch.cuda.synchronize()
-k = ops.prof_collect()
-ops.prof_enable(False)
-print('rows', E, 'dbg', os.environ.get('HGN_FUSED_DBG', '0'), ' '.join(f"{n}={v['ms'] / v['count']:.4f}ms" for n, v in k.items()))
+def run(tag):
+    for it in range(a.iters + 2):
+        if it == 2:
+            torch.cuda.synchronize(); ops.prof_reset(); ops.prof_enable(True)
+        y, agg = ops.edge_block(h, e, topo, w, ('sum',))
+        (y.sum() + agg.sum()).backward()
+    torch.cuda.synchronize()
+    k = ops.prof_collect()
+    ops.prof_enable(False)
+    print('rows', E, tag, ' '.join(f"{n}={v['ms'] / v['count']:.4f}ms" for n, v in k.items()), flush=True)
+
+
+for rep in range(a.reps):
+    run('dbg ' + os.environ.get('HGN_FUSED_DBG', '0'))
+    if a.ab_edge_fwd:                    # the general forward kernel on the same box, same process (csrc/mlp6.hip: edge_block_shape)
+        os.environ['HGN_NO_EDGE_FWD'] = '1'
+        run('general-forward-kernel')
+        del os.environ['HGN_NO_EDGE_FWD']
