@@ -56,10 +56,53 @@ def check(text: str) -> None:
             raise AssertionError(f'phase {p}: s_waitcnt vmcnt({waits[p]}), Keep<> says {keep}')
 
 
+# ---- csrc/mlp6.hip: mlp6_fwd_edge_kernel (quarter-pipelined weight ring, mlp6_device.h: gemm6q) -------------------------------------
+# Its waits `s_waitcnt vmcnt(N) lgkmcnt(0)` with N > 0 leave the N youngest vector-memory operations of the wave in flight while the
+# LDS-DMA of a ring piece -- issued BEFORE them -- must have landed.  Safe exactly when, walking back from the wait, the first N
+# vector-memory instructions are reached without passing a label (another path could join with a different count), are not LDS-DMA,
+# and the kernel has no scratch access (a spill reload is a vector-memory operation nobody counted).
+EDGE_KERNEL = '_ZN3hgn20mlp6_fwd_edge_kernelILi6EEEv13hgn_mlp_fwd_t'
+_VMEM = ('global_load', 'global_store', 'global_atomic', 'buffer_', 'flat_', 'scratch_')
+
+
+def check_edge_forward(text: str) -> int:
+    at = text.index(EDGE_KERNEL + ':')
+    body = text[at:text.index('.Lfunc_end', at)]
+    if 'scratch_' in body:
+        raise AssertionError('register spills in mlp6_fwd_edge_kernel: their reloads break the counted waits')
+    lines = [l.strip() for l in body.splitlines()]
+    n_checked = 0
+    for i, l in enumerate(lines):
+        m = re.match(r's_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)', l)
+        if not m or int(m.group(1)) == 0:
+            continue
+        keep, seen, j = int(m.group(1)), 0, i - 1
+        while seen < keep:
+            if j < 0:
+                raise AssertionError(f'wait at line {i}: ran out of instructions after {seen} of {keep}')
+            x = lines[j]
+            if re.match(r'^\.?L?BB\d+_\d+:', x) or x.startswith('s_cbranch') or x.startswith('s_branch'):
+                raise AssertionError(f'wait vmcnt({keep}) at line {i}: control flow joins / leaves within its {keep} youngest operations')
+            if x.startswith('global_load_lds'):
+                raise AssertionError(f'wait vmcnt({keep}) at line {i}: an LDS-DMA is among the {keep} operations it leaves in flight')
+            if x.startswith(_VMEM):
+                seen += 1
+            j -= 1
+        n_checked += 1
+    if n_checked < 3:
+        raise AssertionError(f'expected at least 3 counted waits in mlp6_fwd_edge_kernel, found {n_checked}')
+    return n_checked
+
+
 if __name__ == '__main__':
     try:
-        check(open(sys.argv[1]).read())
+        text = open(sys.argv[1]).read()
+        if KERNEL + ':' in text:
+            check(text)
+            print('check_fused_counts: ok (fused backward: 12 phases, counted waits match the emitted instructions)')
+        if EDGE_KERNEL + ':' in text:
+            n = check_edge_forward(text)
+            print(f'check_fused_counts: ok (edge forward: {n} counted waits leave only younger, unconditional operations in flight; no scratch)')
     except (AssertionError, ValueError, StopIteration) as e:
         print('check_fused_counts: FAILED:', e, file=sys.stderr)
         sys.exit(1)
-    print('check_fused_counts: ok (12 phases, counted waits match the emitted instructions)')

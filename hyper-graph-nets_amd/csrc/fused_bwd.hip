@@ -93,36 +93,10 @@ __device__ __forceinline__ void wait_keep() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
 }
 
-__device__ __forceinline__ unsigned opaque(unsigned v) {      // one per-lane base register + immediates, never a register per address
-  asm volatile("" : "+v"(v));
-  return v;
-}
+__device__ __forceinline__ unsigned opaque(unsigned v) { return opaque_u(v); }
 
-// The LDS-DMA of one ring piece by one wgrad wave (global_load_lds_dwordx4: lane l copies 16 bytes from sbase + voff(l) to M0 + 16 l;
-// 1 KiB per instruction), issued from ONE inline-assembly statement so that it stays outside the compiler's s_waitcnt bookkeeping
-// (the compiler would drain it at its next wait) and costs three instructions per KiB.  Wave ww of the four copies operand tiles
-// i = ww + 4 k, k = 0..5, i.e. split k / 2, output block ww + 4 (k & 1): in the packed block those lie (16 (k / 2) + 4 (k & 1)) KiB
-// behind tile (split 0, output block ww), in the ring slot 4 k KiB.  M0 (the DMA's LDS base) is compiler-reserved and not assumed
-// to survive an asm statement; it is written in the statement that reads it and declared clobbered.  s_add_u32 writes SCC: declared, or the compiler keeps
-// a scalar compare result live across the statement (it did: one clamped row index per fetch came out wrong).  Completion: a
-// counted vmcnt of the issuing wave, then a barrier.
-template <int NP>
-__device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: source of tile (0, ww)*/, unsigned voff /*16 * lane*/,
-                                           unsigned lds_dst /*wave-uniform: LDS byte address of tile (0, ww) in the slot*/) {
-  unsigned t;
-  if (NP == 1)
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
-                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc", "m0");
-  else
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x4000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x5000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x8000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x9000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
-                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc", "m0");
-}
+// (glds_piece<NP>: csrc/mlp6_device.h -- the LDS-DMA of one ring piece by one of the four waves that share it, one inline-assembly
+// statement outside the compiler's s_waitcnt bookkeeping; completion: a counted vmcnt of the issuing wave, then a barrier)
 
 __device__ __forceinline__ void split3v8(const float (&v)[8], bf16x8 (&s)[3]) {
 #pragma unroll
@@ -335,8 +309,6 @@ constexpr bool wg_fetches(int p) { const int q = ((p % 12) + 12) % 12; return q 
 // the DMA of piece P + 1 (phase P - 1) and the fetch of phase P - 1
 template <int P, int NP>
 struct Keep { static constexpr int value = Ring<NP>::DPW + 8 * (wg_fetches(P - 2) ? 1 : 0) + 8 * (wg_fetches(P - 1) ? 1 : 0); };
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- the weight-gradient waves (4-7) of edge_bwd_fused_kernel -----------------------------------------------------------------
 template <int NP>

@@ -258,9 +258,10 @@ __device__ __forceinline__ void t_store32(const Act& a, float* __restrict__ base
   char* p = reinterpret_cast<char*>(base);
   HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + (byte_off + 64u * fb)) = a.v[fb];
 }
-// t_store_rows for a 128-float row stride with 32-bit offsets.  `row0`: first of the wave's 16 rows; `full` (uniform): all 16 rows exist
-// -- every tile of a launch but the last: no per-row tests at all.
-__device__ __forceinline__ void t_store_rows32(const Act& a, float* __restrict__ base, unsigned row0, bool full, unsigned M, float* st) {
+// t_store_rows for a 128-float row stride with 32-bit offsets.  `row0`: first of the wave's 16 rows; FULL: all 16 rows exist (every
+// tile of a launch but the last): no per-row tests, and a STATIC number of store instructions (8) for counted waits.
+template <bool FULL>
+__device__ __forceinline__ void t_store_rows32(const Act& a, float* __restrict__ base, unsigned row0, unsigned M, float* st) {
   const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
   const unsigned r = lane >> 4, c = lane & 15;
   char* p = reinterpret_cast<char*>(base);
@@ -272,14 +273,9 @@ __device__ __forceinline__ void t_store_rows32(const Act& a, float* __restrict__
     f32x4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(st + (r + 4 * q) * 64 + 4 * (c ^ (r + 4 * q)));
-    if (full) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p + (off + 2048u * q + 256u * h)) = v[q];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (row0 + r + 4 * q < M) *reinterpret_cast<f32x4*>(p + (off + 2048u * q + 256u * h)) = v[q];
-    }
+    for (int q = 0; q < 4; ++q)
+      if (FULL || row0 + r + 4 * q < M) *reinterpret_cast<f32x4*>(p + (off + 2048u * q + 256u * h)) = v[q];
   }
 }
 __device__ __forceinline__ void t_store_masked(const Act& a, float* __restrict__ row, int kq, int w) {

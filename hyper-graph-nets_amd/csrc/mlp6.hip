@@ -11,6 +11,7 @@
 // tiles of 16 x 32 bf16 stored in lane order, so staging is a straight LDS-DMA copy and every ds_read_b128 is linear.
 // LDS: half a block (two contraction blocks x three splits x eight output blocks = 48 KB) at a time, 3 workgroups per CU.
 #include <cstdlib>
+#include <type_traits>
 #include "hgn_device.h"
 #include "hgn_host.h"
 #include "mlp_common.h"
@@ -257,14 +258,18 @@ __global__ __launch_bounds__(WG, 2) void mlp6_fwd_edge_kernel(const hgn_mlp_fwd_
   const unsigned M = (unsigned)a.M;
   const unsigned tile_row0 = (unsigned)xcd_tile() * (NS * TILE_ROWS);
   const bool full = tile_row0 + NS * TILE_ROWS <= M;                 // uniform: every tile but the launch's last
-  unsigned row0[NS], rc[NS];                                          // the wave's first row of sub-tile u; the lane's row, clamped
-  bool valid[NS];
+  unsigned row0[NS];                                                  // the wave's first row of sub-tile u (uniform)
 #pragma unroll
-  for (int u = 0; u < NS; ++u) {
-    row0[u] = tile_row0 + u * TILE_ROWS + wave * WAVE_ROWS;
-    valid[u] = row0[u] + n < M;
-    rc[u] = valid[u] ? row0[u] + n : M - 1;
-  }
+  for (int u = 0; u < NS; ++u) row0[u] = tile_row0 + u * TILE_ROWS + wave * WAVE_ROWS;
+  // Per-lane row numbers are RE-DERIVED from an opaque lane id wherever they are needed (three instructions) instead of living in
+  // registers from kernel entry to the epilogue: at this kernel's budget every long-lived per-lane value is a spill, and a spill's
+  // reload is a vector-memory operation in the middle of the counted waits.
+  auto lane_now = [&] { return opaque_u(threadIdx.x & 63); };
+  auto row_clamped = [&](int u, unsigned ln) { const unsigned r = row0[u] + (ln & 15u); return r < M ? r : M - 1; };
+  auto row_valid = [&](int u, unsigned ln) { return row0[u] + (ln & 15u) < M; };
+  unsigned rc[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) rc[u] = row_clamped(u, lane);
   // gather indices first: the dependent row loads then cost one memory round trip, not two
   int add_row[NS][2];
 #pragma unroll
@@ -278,10 +283,12 @@ __global__ __launch_bounds__(WG, 2) void mlp6_fwd_edge_kernel(const hgn_mlp_fwd_
     for (int u = 0; u < NS; ++u) seg_pre[u].load(a.seg_ids, (long)tile_row0 + u * TILE_ROWS, a.M);
   }
   float* st = stage_lds[wave];
-  auto nothing = [](Act (&)[NS]) {};
+  auto nothing = [](int, Act (&)[NS]) {};
   Act acc[NS], b[NS];
   const __bf16* pk1 = reinterpret_cast<const __bf16*>(a.src[0].Wpk);
-  gemm6<NS, NP>(acc, b, lds, pk1, [&] {
+  const __bf16* pk2 = reinterpret_cast<const __bf16*>(a.W2pk);
+  const __bf16* pk3 = reinterpret_cast<const __bf16*>(a.W3pk);
+  gemm6q<NS, NP, false, 0, 0, 0>(acc, b, lds, pk1, pk2, true, [&] {
     // acc = (b1 + P0[snd]) + P1[rcv] per sub-tile.  Both e tiles (HBM) go out first, then the gathered pre-projection rows (cache
     // resident) one sub-tile at a time: with all six tiles in flight plus the bias vectors the allocator spills, and scratch traffic
     // in this kernel would sit in the same in-order queue as every store.
@@ -310,29 +317,39 @@ __global__ __launch_bounds__(WG, 2) void mlp6_fwd_edge_kernel(const hgn_mlp_fwd_
       seg_pre[0].stash(seg_ids_lds[0]);
       seg_pre[1].stash(seg_ids_lds[1]);
     }
-  }, nothing);
+  }, [&](int q, Act (&free_b)[NS]) {                // the next block's accumulators start from its bias: loaded during the last piece
+    if (q == 3) {                                   // (three quarters of the operand vectors are dead by then), into the registers of
+#pragma unroll                                      // the operand rows this block has split: nothing is loaded between two blocks
+      for (int u = 0; u < NS; ++u) t_load(free_b[u], a.b2, kq);
+    }
+  });
+  // Between two blocks: ReLU, sign words, the saved activation rows -- and the wait for the next block's first piece, whose DMA was
+  // issued BEFORE these stores.  In a full tile their number is static (per sub-tile 8 row stores + 1 sign-word store): the wait
+  // leaves them in flight.  Path by path (no join in between: the compiler's own bookkeeping takes the smaller count at a join).
+  constexpr int SAVE_OPS = NS * (NB + 1);
+  auto save = [&](auto full_, Act (&z)[NS], Act (&next_acc)[NS], float* __restrict__ dst, unsigned word) {
+    constexpr bool FULL = decltype(full_)::value;
+    const unsigned ln = lane_now();
 #pragma unroll
-  for (int u = 0; u < NS; ++u) {
-    const unsigned m = relu_with_bits(acc[u]);
-    t_store_rows32(acc[u], a.z1, row0[u], full, M, st);
-    if (valid[u]) a.relu_bits[rc[u] * 8u + kq] = m;
-  }
-  gemm6<NS, NP>(b, acc, lds, reinterpret_cast<const __bf16*>(a.W2pk), [&] {
+    for (int u = 0; u < NS; ++u) {
+      const unsigned m = relu_with_bits(z[u]);
+      t_store_rows32<FULL>(z[u], dst, row0[u], M, st);
+      if (FULL || row_valid(u, ln)) a.relu_bits[row_clamped(u, ln) * 8u + word + (ln >> 4)] = m;
+    }
+    gemm6q_landed<NS, FULL ? SAVE_OPS : 0>(next_acc, z);
+  };
+  if (full) save(std::true_type{}, acc, b, a.z1, 0u); else save(std::false_type{}, acc, b, a.z1, 0u);
+  gemm6q<NS, NP, true, 0, 0, 0>(b, acc, lds, pk2, pk3, false, [] {}, [&](int q, Act (&free_a)[NS]) {
+    if (q == 3) {
 #pragma unroll
-    for (int u = 0; u < NS; ++u) t_load(b[u], a.b2, kq);
-  }, nothing);
-#pragma unroll
-  for (int u = 0; u < NS; ++u) {
-    const unsigned m = relu_with_bits(b[u]);
-    t_store_rows32(b[u], a.z2, row0[u], full, M, st);
-    if (valid[u]) a.relu_bits[rc[u] * 8u + 4u + kq] = m;
-  }
-  gemm6<NS, NP>(acc, b, lds, reinterpret_cast<const __bf16*>(a.W3pk), [&] {
-#pragma unroll
-    for (int u = 0; u < NS; ++u) t_load(acc[u], a.b3, kq);
-  }, [&](Act (&free_b)[NS]) {                       // the residual rows arrive while the last block multiplies
-#pragma unroll
-    for (int u = 0; u < NS; ++u) t_load32(free_b[u], a.res, rc[u] * 512u + 16u * kq);
+      for (int u = 0; u < NS; ++u) t_load(free_a[u], a.b3, kq);
+    }
+  });
+  if (full) save(std::true_type{}, b, acc, a.z2, 4u); else save(std::false_type{}, b, acc, a.z2, 4u);
+  gemm6q<NS, NP, true, 0, 0, NB>(acc, b, lds, pk3, nullptr, false, [] {
+  }, [&](int q, Act (&free_b)[NS]) {                // the residual rows arrive while pieces 2 and 3 multiply, in the registers of the
+    if (q == 2) { const unsigned ln = lane_now(); t_load32(free_b[0], a.res, row_clamped(0, ln) * 512u + 16u * (ln >> 4)); }      // operand vectors that
+    if (q == 3) { const unsigned ln = lane_now(); t_load32(free_b[1], a.res, row_clamped(1, ln) * 512u + 16u * (ln >> 4)); }      // pieces 0 and 1 consumed
   });
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
@@ -341,15 +358,15 @@ __global__ __launch_bounds__(WG, 2) void mlp6_fwd_edge_kernel(const hgn_mlp_fwd_
     const float var = row_sum_sq(acc[u]) * (1.f / LAT);
     const float rstd = 1.f / sqrtf(var + 1e-5f);
     HGN_FOR_B(fb) acc[u].v[fb] *= rstd;
-    t_store_rows32(acc[u], a.xhat, row0[u], full, M, st);
-    if (valid[u] && kq == 0) a.rstd[rc[u]] = rstd;
+    if (full) t_store_rows32<true>(acc[u], a.xhat, row0[u], M, st); else t_store_rows32<false>(acc[u], a.xhat, row0[u], M, st);
+    { const unsigned ln = lane_now(); if (row_valid(u, ln) && (ln >> 4) == 0) a.rstd[row_clamped(u, ln)] = rstd; }
     HGN_FOR_B(fb) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
       const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 16 * fb + 4 * kq);
       acc[u].v[fb] = acc[u].v[fb] * gm + bt;
     }
     HGN_FOR_B(fb) acc[u].v[fb] += b[u].v[fb];
-    t_store_rows32(acc[u], a.out, row0[u], full, M, st);
+    if (full) t_store_rows32<true>(acc[u], a.out, row0[u], M, st); else t_store_rows32<false>(acc[u], a.out, row0[u], M, st);
   }
   if (a.seg_out) {
 #pragma unroll

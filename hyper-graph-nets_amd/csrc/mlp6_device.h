@@ -272,6 +272,167 @@ __device__ __forceinline__ void gemm6(Act (&acc)[NS], const Act (&b)[NS], __bf16
   gemm6<NS, NP>(acc, const_cast<Act (&)[NS]>(b), lds, pk, between, [](Act (&)[NS]) {});
 }
 
+// ---- quarter-pipelined weight ring (throughput kernels: csrc/mlp6.hip mlp6_fwd_edge_kernel) ------------------------------------------
+// gemm6 stages half a packed block, WAITS for it, multiplies, and does so twice per block: a workgroup spends ~1 us per wait with
+// nothing to do, six times per tile (the ablation without weight DMA ran 22 % faster).  Here the 48 KB stage is a ring of two 24 KB
+// slots, one CONTRACTION BLOCK ("piece": [split][output block][lane][8 bf16], as in csrc/fused_bwd.hip) each: while piece q multiplies
+// out of slot q & 1 the LDS-DMA of piece q + 1 -- of the NEXT packed block when q = 3 -- is in flight into the other slot, which every
+// wave finished reading before the barrier that opened piece q.  One barrier per piece (four per block, as before) and no exposed DMA:
+//   wait (own DMA of piece q landed) ; barrier ; issue DMA of piece q + 1 ; [q = 0: split the operand] ; 48 NS products of piece q.
+// The DMA is issued from inline assembly (glds_piece): issued through the builtin the compiler orders every later LDS read of the
+// array behind it with a vmcnt(0), which is the wait this structure exists to remove.  Waits are explicit s_waitcnt vmcnt(KEEP):
+// KEEP = vector-memory operations the wave issued AFTER that DMA that may stay in flight (they retire in order).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int PIECE_BYTES6 = 3 * 8 * 1024;
+
+__device__ __forceinline__ unsigned opaque_u(unsigned v) {      // one per-lane base register + immediates, never a register per address
+  asm volatile("" : "+v"(v));
+  return v;
+}
+template <int KEEP>
+__device__ __forceinline__ void wait_vm_keep() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
+}
+
+// The LDS-DMA of one piece by one of the four waves that share it (global_load_lds_dwordx4: lane l copies 16 bytes from sbase + voff(l)
+// to M0 + 16 l; 1 KiB per instruction).  Wave ww copies operand tiles ww + 4 k, k = 0..5, i.e. split k / 2, output block ww + 4 (k & 1):
+// in the packed block those lie (16 (k / 2) + 4 (k & 1)) KiB behind tile (split 0, output block ww), in the slot 4 k KiB.  M0 is written
+// in the statement that reads it and declared clobbered, like SCC (s_add_u32).  NP != 6: only the leading split is staged.
+template <int NP>
+__device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: source of tile (0, ww)*/, unsigned voff /*16 * lane*/,
+                                           unsigned lds_dst /*wave-uniform: LDS byte address of tile (0, ww) in the slot*/) {
+  unsigned t;
+  if (NP != 6)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
+                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x4000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x5000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x8000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x9000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
+                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc", "m0");
+}
+// piece c (contraction block) of the packed block `blk` -> ring slot `slot` of the ring at LDS byte address lds_base
+template <int NP>
+__device__ __forceinline__ void dma_piece6(const __bf16* __restrict__ blk, int c, unsigned lds_base, int slot, unsigned ww, unsigned voff) {
+  const __bf16* src = blk + ((c >> 1) * HALF_BF16 + ((c & 1) * 8) * TILE_BF16) + ww * TILE_BF16;      // uniform: a scalar register pair
+  if (!(HGN_ABL & 1)) glds_piece<NP>(src, voff, lds_base + slot * PIECE_BYTES6 + ww * 1024);
+}
+
+// acc[u][ob] += (piece: contraction block C) * x[u], six products per output block and sub-tile in the order of mfma_half6 (the same
+// bits); the three fragments of output block ob + 1 are read while block ob multiplies (12 NS products: 192 NS matrix-pipe cycles).
+template <int C, int NS, int NP>
+__device__ __forceinline__ void sweep_piece6(Act (&acc)[NS], const bf16x8 (&xs)[NS][3][4], const unsigned char* __restrict__ lp /*slot + 16 lane*/) {
+  if (HGN_ABL & 2) return;
+  constexpr int NSP = NP != 6 ? 1 : 3;
+  bf16x8 fr[2][3];
+#pragma unroll
+  for (int s = 0; s < NSP; ++s) fr[0][s] = *reinterpret_cast<const bf16x8*>(lp + (s * 8) * 1024);
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+    if (ob + 1 < NB) {
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) fr[(ob + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(lp + (s * 8 + ob + 1) * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 (&a)[3] = fr[ob & 1];               // a[0] hi, a[1] mid, a[2] lo
+    if constexpr (NS == 2 && NP == 6) {             // two independent accumulation chains, interleaved
+      f32x4 t0 = acc[0].v[ob], t1 = acc[1].v[ob];
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[0][0][C], t0, 0, 0, 0);      // smallest terms first
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[1][0][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][2][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[1][2][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[0][1][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[1][1][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[0][0][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[1][0][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][1][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[1][1][C], t1, 0, 0, 0);
+      t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][0][C], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[1][0][C], t1, 0, 0, 0);
+      acc[0].v[ob] = t0; acc[1].v[ob] = t1;
+    } else {
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        f32x4 t = acc[u].v[ob];
+        if constexpr (NP != 6) {
+          t = mfma_one<NP>(a[0], xs[u][0][C], t);
+        } else {
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[u][0][C], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[u][2][C], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[u][1][C], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], xs[u][0][C], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[u][1][C], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[u][0][C], t, 0, 0, 0);
+        }
+        acc[u].v[ob] = t;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// One packed block through the two-slot ring.  On entry the DMA of the block's piece 0 is in flight into slot 0 (issued during the
+// block before: `pk_next` there) unless `first`, in which case it is issued here behind a barrier.  `between()`: the caller's loads
+// that must have LANDED before the products (operand rows, accumulator start values).  `at_piece(q, b)`: called at the start of piece
+// q = 0..3, right after the DMA of the following piece has been issued (q = 0: after `b` has been split -- its registers are free from
+// there on); KEEP1..3 = the vector-memory operations at_piece(0..2) issue: they stay in flight across the wait that follows them (a
+// later wait drains them: vector memory retires in order, and the next DMA is younger than they are).  `pk_next` (nullable): the block
+// whose piece 0 is fetched while this block's piece 3 multiplies.
+// The wait for piece 0 + the "use" of everything loaded so far (see below): a function of its own so that a caller whose path to
+// this point has a static operation count can run it INSIDE that path (KEEP > 0), before the path joins one whose count differs.
+template <int NS, int KEEP>
+__device__ __forceinline__ void gemm6q_landed(Act (&acc)[NS], Act (&b)[NS]) {
+  wait_vm_keep<KEEP>();
+  // The compiler does not see that wait (nor the DMAs): it would put its OWN counted waits in front of the first use of whatever
+  // was loaded -- somewhere inside the sweeps, where its count (its loads only) also drains the younger DMAs it knows nothing
+  // about.  Every such register is "used" here, before the next DMA is issued: the compiler's waits land here, already satisfied.
+#pragma unroll
+  for (int u = 0; u < NS; ++u)
+    HGN_FOR_B(fb) asm volatile("" : "+v"(acc[u].v[fb]), "+v"(b[u].v[fb]));
+}
+
+// PREWAITED: the caller has run gemm6q_landed itself (and between() is empty).
+template <int NS, int NP, bool PREWAITED, int KEEP1, int KEEP2, int KEEP3, class F, class G>
+__device__ __forceinline__ void gemm6q(Act (&acc)[NS], Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
+                                       const __bf16* __restrict__ pk_next, bool first, F&& between, G&& at_piece) {
+  bf16x8 xs[NS][3][4];
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned ww = (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(lds);
+  const unsigned char* ring = reinterpret_cast<const unsigned char*>(lds);
+  if (first) {
+    wg_barrier_lds();
+    dma_piece6<NP>(pk, 0, lds_base, 0, ww, opaque_u(lane * 16u));
+  }
+  between();
+  if constexpr (!PREWAITED) gemm6q_landed<NS, 0>(acc, b);
+  __builtin_amdgcn_s_barrier();                     // ---- piece 0 has landed for every wave; slot 1 is free
+  dma_piece6<NP>(pk, 1, lds_base, 1, ww, opaque_u(lane * 16u));
+#pragma unroll
+  for (int u = 0; u < NS; ++u) split_np<NP>(b[u], xs[u]);
+  at_piece(0, b);
+  sweep_piece6<0, NS, NP>(acc, xs, ring + opaque_u(lane * 16u));
+  wait_vm_keep<KEEP1>();
+  __builtin_amdgcn_s_barrier();                     // ---- piece 1 landed; every wave is done with slot 0
+  dma_piece6<NP>(pk, 2, lds_base, 0, ww, opaque_u(lane * 16u));
+  at_piece(1, b);
+  sweep_piece6<1, NS, NP>(acc, xs, ring + opaque_u(lane * 16u + PIECE_BYTES6));
+  wait_vm_keep<KEEP2>();
+  __builtin_amdgcn_s_barrier();                     // ---- piece 2 landed; slot 1 free
+  dma_piece6<NP>(pk, 3, lds_base, 1, ww, opaque_u(lane * 16u));
+  at_piece(2, b);
+  sweep_piece6<2, NS, NP>(acc, xs, ring + opaque_u(lane * 16u));
+  wait_vm_keep<KEEP3>();
+  __builtin_amdgcn_s_barrier();                     // ---- piece 3 landed; slot 0 free
+  if (pk_next) dma_piece6<NP>(pk_next, 0, lds_base, 0, ww, opaque_u(lane * 16u));
+  at_piece(3, b);
+  sweep_piece6<3, NS, NP>(acc, xs, ring + opaque_u(lane * 16u + PIECE_BYTES6));
+}
+
 // ---- latency form (small launches: at most a tile or two per CU, csrc/mlp6.hip: mlp6_fwd_kernel<1, NP, 5>) -----------------------
 // A workgroup that has its CU to itself (rollout: one 1 600-node graph = 146 edge tiles, 25 node tiles) spends most of a block
 // of gemm6 waiting for its own weight DMA: issue -> 2 us of L2 latency -> barrier -> products, twice per block.  Here NL extra
