@@ -167,8 +167,11 @@ __device__ __forceinline__ bf16x8 g_read(const unsigned char* __restrict__ smem,
 // of the first version and of csrc/mlp6_device.h (smallest terms first; per accumulator c = 0..3 in sequence): the same bits.
 // The fragments of output block ob + 1 are read while block ob multiplies (scheduling barriers keep the reads where they are
 // written: at this kernel's register budget the unconstrained scheduler hoists dozens of fragment reads and then spills).
-template <int C, int NP>
-__device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], const unsigned char* __restrict__ lp /*slot + 16 lane*/) {
+// START 0: acc += ...; 1: acc = 0 + ... (an inline constant as the first product's C operand: no zero fill); 2: acc = init + ... (the
+// first product reads its C operand from `init`'s registers and writes acc's: no copy)
+template <int C, int NP, int START = 0>
+__device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], const unsigned char* __restrict__ lp /*slot + 16 lane*/,
+                                            const Act* init = nullptr) {
   // two output blocks at a time (two independent accumulation chains), the SIX fragments of the next pair read before the
   // current pair's twelve products are issued: 192 matrix-pipe cycles between a ds_read_b128 and its use (one block ahead, 96
   // cycles, left an exposed LDS round trip of 100-300 cycles per block: the sweeps ran at half the matrix rate)
@@ -187,7 +190,10 @@ __device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], 
     if (g + 1 < 4) load_pair(g + 1, fr[(g + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8 (&a)[2][3] = fr[g & 1];               // a[k][0] hi, [1] mid, [2] lo of output block 2 g + k
-    f32x4 t0 = acc.v[2 * g], t1 = acc.v[2 * g + 1];
+    f32x4 t0, t1;
+    if constexpr (START == 1) { t0 = f32x4{0.f, 0.f, 0.f, 0.f}; t1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    else if constexpr (START == 2) { t0 = init->v[2 * g]; t1 = init->v[2 * g + 1]; }
+    else { t0 = acc.v[2 * g]; t1 = acc.v[2 * g + 1]; }
     if (NP == 1) {
       t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], xs[0][C], t0, 0, 0, 0);
       t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], xs[0][C], t1, 0, 0, 0);
@@ -214,7 +220,7 @@ __device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], 
 // G: rows 32 blk .. 32 blk + 31 of the row-major image (transposed reads), A: the 32-row vector image.  The A vectors of feature block nb + 1 are read while
 // block nb multiplies.
 template <int NP>
-__device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], const unsigned char* __restrict__ smem, const unsigned (&gr)[4],
+__device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], f32x4 (&cs)[2], const unsigned char* __restrict__ smem, const unsigned (&gr)[4],
                                             const bf16x8* __restrict__ ap /*lane base: A image*/, int blk) {
   constexpr int NS = NP == 1 ? 1 : 3;
   bf16x8 gs[2][3];
@@ -222,16 +228,23 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&cs)[2], 
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
     for (int s = 0; s < NS; ++s) gs[mb][s] = g_read(smem, gr[2 * mb], gr[2 * mb + 1], s * G_SPLIT_BYTES + blk * 32 * 256);
+  // bias gradient = column sums of G over the 32 rows: the same G^T fragments against an operand of ONES on the matrix pipe (the
+  // three split terms add up to the fp32 value exactly; every column of the 16 x 16 result holds the sums) -- three products per
+  // 16 features instead of 24 conversions + 24 additions per lane on the vector pipe, which this kernel is short of
+  {
+    bf16x8 ones;
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {                    // bias gradient: the three split terms add up to the fp32 value exactly
-    float t = 0.f;
+    for (int p = 0; p < 8; ++p) ones[p] = (__bf16)1.0f;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      float v = (float)gs[mb][0][p];
-      if (NP != 1) v += (float)gs[mb][1][p] + (float)gs[mb][2][p];
-      t += v;
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x4 c = cs[mb];
+      if (NP != 1) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][2], ones, c, 0, 0, 0);      // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][1], ones, c, 0, 0, 0);
+      }
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][0], ones, c, 0, 0, 0);
+      cs[mb] = c;
     }
-    cs[mb] += t;
   }
   bf16x8 as[2][3];
 #pragma unroll
@@ -329,12 +342,12 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
   const __bf16* pk2 = reinterpret_cast<const __bf16*>(a.W2pk_t);
   const __bf16* pk1 = reinterpret_cast<const __bf16*>(a.dx[0].Wpk_t);
   f32x4 acc[2][2][8];
-  float cs[2][2];
+  f32x4 cs[2][2];
 #pragma unroll
   for (int l = 0; l < 2; ++l)
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      cs[l][mb] = 0.f;
+      cs[l][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) acc[l][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -422,10 +435,10 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
       for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab[(32 * ww + 16 * mb + 4 * kg + r) * 128 + 16 * nb + m] = acc[l][mb][nb][r];
-      float v = cs[l][mb];                            // the four row groups of a feature live in four lanes
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      if (kg == 0) slab[128 * 128 + 32 * ww + 16 * mb + m] = v;
+      if (m == 0) {                                   // every column of the ones-product holds the sums: column 0 stores them
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[128 * 128 + 32 * ww + 16 * mb + 4 * kg + r] = cs[l][mb][r];
+      }
     }
   }
 }
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     int seg_next = 0;
     bf16x8 xs[3][4];
     int n = lane & 15, kq = lane >> 4;
-    float lnacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float lnacc_g[2] = {0.f, 0.f}, lnacc_b[2] = {0.f, 0.f};      // LayerNorm-affine gradient partials of the lane's 2 + 2 features, over all tiles
     const unsigned ld_dout4 = (unsigned)a.ld_dout * 4u;
     // rows of tile `tile`: x-hat -> g, d(e') -> gout, the receiver's d(agg) row -> ga, sign words, 1 / sigma
     auto prefetch = [&](long tile, int seg) {
@@ -484,7 +497,6 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       // invariant addresses out of the loop and spills them
       const int lane_i = (int)opaque((unsigned)lane);
       n = lane_i & 15; kq = lane_i >> 4;
-      float* lnw = reinterpret_cast<float*>(smem + opaque((unsigned)(LN_OFF + (wave * 256 + 4 * kq) * 4)));
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       const bool valid = row < M;
       FSTAMP(0, 0);
@@ -492,42 +504,43 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       const unsigned mb1 = pf_m1, mb2 = pf_m2;
       // ---- LayerNorm backward -> dz3 (g) ------------------------------------------------------------------------------------
       {
-        Act& xh = t;
-        xh = g;
+        const Act& xh = g;                            // x-hat of this tile (prefetched); dz3 replaces it element by element below
+        Act& gg = t;                                  // d_out_eff * gamma (t is free until layer 1)
         if (!has_dout) t_zero(gout);
         if (has_agg) HGN_FOR_B(fb) gout.v[fb] += ga.v[fb];
-        HGN_FOR_B(fb) {                               // LayerNorm-affine gradient partials of this wave's rows
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            float pb = valid ? gout.v[fb][w] : 0.f;
-            const float pg = row16_sum(pb * xh.v[fb][w]);
-            pb = row16_sum(pb);
-            if (n == 0) { lnw[16 * fb + w] = pg; lnw[128 + 16 * fb + w] = pb; }
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        // LayerNorm-affine gradient partials of this wave's 16 rows: column sums of d_out_eff * x-hat and of d_out_eff by the
+        // transposing butterfly (hgn_device.h: 90 instructions per array; the row16_sum form was ~640 for the two, a third of this
+        // role's vector instructions), accumulated in registers over the tiles -- no LDS, no exec-masked stores.
+        if (tile + 1 == t_end && (M & (TILE_ROWS - 1)) != 0)      // rows past the end (the launch's last tile only; uniform)
+          HGN_FOR_B(fb) gout.v[fb] = valid ? gout.v[fb] : f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+          HGN_FOR_B(fb) gg.v[fb] = gout.v[fb] * xh.v[fb];
+          float sg[2], sb[2];
+          row16_sums_transposed(gg, sg);
+          row16_sums_transposed(gout, sb);
+          lnacc_g[0] += sg[0]; lnacc_g[1] += sg[1];
+          lnacc_b[0] += sb[0]; lnacc_b[1] += sb[1];
         }
-        HGN_FOR_B(fb) g.v[fb] = gout.v[fb] * *reinterpret_cast<const f32x4*>(lng + 16 * fb + 4 * kq);
-        const float m1 = row_sum(g) * (1.f / LAT);
+        HGN_FOR_B(fb) gg.v[fb] = gout.v[fb] * *reinterpret_cast<const f32x4*>(lng + 16 * fb + 4 * kq);
+        const float m1 = row_sum(gg) * (1.f / LAT);
         float q0 = 0.f, q1 = 0.f;
         HGN_FOR_B(fb) {
-          q0 += g.v[fb][0] * xh.v[fb][0] + g.v[fb][1] * xh.v[fb][1];
-          q1 += g.v[fb][2] * xh.v[fb][2] + g.v[fb][3] * xh.v[fb][3];
+          q0 += gg.v[fb][0] * xh.v[fb][0] + gg.v[fb][1] * xh.v[fb][1];
+          q1 += gg.v[fb][2] * xh.v[fb][2] + gg.v[fb][3] * xh.v[fb][3];
         }
         float qs = q0 + q1;
         qs += __shfl_xor(qs, 16);
         qs += __shfl_xor(qs, 32);
         const float m2 = qs * (1.f / LAT);
         const float r = pf_rstd;
-        HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - xh.v[fb] * m2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lnacc[k] += lnl[wave * 256 + lane + 64 * k];      // this wave's own partials (same-wave LDS order)
+        HGN_FOR_B(fb) g.v[fb] = r * (gg.v[fb] - m1 - g.v[fb] * m2);
       }
-      t_zero(t);
       FSTAMP(0, 1);
       // ---- layers 3 and 2: ONE copy of the code (a run-time loop: fully unrolled the kernel is 63 KB of instructions; the
       // counters show no instruction-cache misses either way, the loop is kept for build time and register pressure).
-      // Entering layer `li`: g = the gradient to multiply (dz3, dz2), t = 0.
-      // li = 0: t = W3^T dz3; 1: t = W2^T dz2.  Ring slot of piece (li, c): (4 li + c) mod 3.
+      // Entering layer `li`: g = the gradient to multiply (dz3, dz2).  Once it is split into operand vectors its registers are free:
+      // the products accumulate INTO g (the first piece from an inline 0) -- no second tile, no zero fill, no copy per layer.
+      // li = 0: g <- W3^T dz3; 1: g <- W2^T dz2.  Ring slot of piece (li, c): (4 li + c) mod 3.
 #pragma unroll 1
       for (int li = 0; li < 2; ++li) {
         split3(g, xs);
@@ -539,19 +552,17 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
         bar_lds();                                              // ---- phase 4 li
         FSTAMP(0, 3 + 8 * li);
         if (wave >= 2) write_gops<NP>(smem, gw, xs);            // rows 32-63: free now (the previous layer's second block is done)
-        sweep_piece<0, NP>(t, xs, ring);
+        sweep_piece<0, NP, 1>(g, xs, ring);
         ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 2 : 1) * PIECE_BYTES));
         FSTAMP(0, 4 + 8 * li); bar_lds(); FSTAMP(0, 5 + 8 * li);
-        sweep_piece<1, NP>(t, xs, ring);                        // ---- phase 4 li + 1
+        sweep_piece<1, NP>(g, xs, ring);                        // ---- phase 4 li + 1
         ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 0 : 2) * PIECE_BYTES));
         FSTAMP(0, 6 + 8 * li); bar_lds(); FSTAMP(0, 7 + 8 * li);
-        sweep_piece<2, NP>(t, xs, ring);                        // ---- phase 4 li + 2
+        sweep_piece<2, NP>(g, xs, ring);                        // ---- phase 4 li + 2
         ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 1 : 0) * PIECE_BYTES));
         FSTAMP(0, 8 + 8 * li); bar_lds(); FSTAMP(0, 9 + 8 * li);
-        sweep_piece<3, NP>(t, xs, ring);                        // ---- phase 4 li + 3
-        relu_mask_bits(t, li == 0 ? mb2 : mb1);                 // dz2 / dz1
-        g = t;                                                  // the next layer's operand
-        t_zero(t);
+        sweep_piece<3, NP>(g, xs, ring);                        // ---- phase 4 li + 3
+        relu_mask_bits(g, li == 0 ? mb2 : mb1);                 // dz2 / dz1
       }
       // ---- layer 1: de = d_out_eff + dz1 W1e; the next tile's rows start their way, one array per phase (one burst of all of
       // them holds up every other memory instruction of the CU -- the ring's DMA among them -- for thousands of cycles) -------------
@@ -561,8 +572,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
 #else
       if (!(HGN_FEXP & 4)) t_store32(g, a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
 #endif
-      split3(g, xs);
-      t = gout;                                                 // the skip connection is the accumulator's start value
+      split3(g, xs);                                            // (t starts from gout, the skip connection: sweep_piece START = 2)
       const long nrow = (tile + 1) * TILE_ROWS + wave * WAVE_ROWS + n;
       const unsigned nrc = (unsigned)(nrow < M ? nrow : M - 1);
       const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16));
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
 #else
       if (!(HGN_FEXP & 8)) t_load32(g, a.xhat, nrc * (LAT * 4u) + 16u * kq);
 #endif
-      FSTAMP(0, 18); bar_lds(); FSTAMP(0, 19); sweep_piece<0, NP>(t, xs, ring + 2 * PIECE_BYTES);                // ---- phase 8
+      FSTAMP(0, 18); bar_lds(); FSTAMP(0, 19); sweep_piece<0, NP, 2>(t, xs, ring + 2 * PIECE_BYTES, &gout);                // ---- phase 8
 #if HGN_FEXP & 16
       if (has_dout) t_load32c(gout, a.d_out, nrcc * ld_dout4 + 16u * (lane_i & 31));
 #else
@@ -598,8 +608,11 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       if (valid && !(HGN_FEXP & 4)) t_store32(t, d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
 #endif
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) lnl[wave * 256 + lane + 64 * k] = lnacc[k];
+    {                                                 // lane (n, kq) holds features 16 (n >> 1) + 4 kq + 2 (n & 1) + {0, 1} (row16_sums_transposed)
+      const int f0 = 16 * (n >> 1) + 4 * kq + 2 * (n & 1);
+      lnl[wave * 256 + f0] = lnacc_g[0]; lnl[wave * 256 + f0 + 1] = lnacc_g[1];
+      lnl[wave * 256 + 128 + f0] = lnacc_b[0]; lnl[wave * 256 + 128 + f0 + 1] = lnacc_b[1];
+    }
     bar_lds();                                        // (E) every chain wave's LayerNorm partials are in LDS
     const float sum = (lnl[tid] + lnl[256 + tid]) + (lnl[512 + tid] + lnl[768 + tid]);
     a.ln_ws[(long)blockIdx.x * 256 + tid] = sum;

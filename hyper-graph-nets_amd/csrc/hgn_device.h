@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace hgn {
 
@@ -298,6 +299,44 @@ __device__ __forceinline__ float row16_sum(float x) {
   x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false));   // row_ror:2
   x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false));   // row_ror:1
   return x;
+}
+
+// Sums of the 32 values of an Act over the 16 lanes of a DPP row (= the 16 rows n of one k-quarter) by a TRANSPOSING butterfly: in each
+// of four steps a lane keeps half of its values, hands the other half to a partner lane and adds what the partner hands back, so that
+// afterwards lane n holds 2 of the 32 sums -- those of values j = 2 n, 2 n + 1 of the numbering j = 4 fb + w, i.e. of
+//   fb = n >> 1,  w = 2 (n & 1) + {0, 1}      (feature 16 fb + 4 kq + w).
+// 3 instructions per output (two selects by a lane-bit mask, one add with a DPP operand): 90 for the 32 sums, against 8 per VALUE
+// (row16_sum on every value, 256 + moves) for sums that every lane then holds sixteen-fold.  Partners: lane ^ 8 (row_ror:8), 7 - lane
+// within the half (row_half_mirror), lane ^ 2, lane ^ 1 (quad_perm) -- each flips the bit the step selects by and keeps the higher ones.
+__device__ __forceinline__ void row16_sums_transposed(const Act& a, float (&out)[2]) {
+  const int lane = threadIdx.x & 63;
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+  auto dpp = [](float x, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false)); };
+  float s16[4][4], s8[2][4], s4[4];
+#pragma unroll
+  for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float lo = a.v[fb][w], hi = a.v[fb + 4][w];
+      s16[fb][w] = (b3 ? hi : lo) + dpp(b3 ? lo : hi, std::integral_constant<int, 0x128>{});      // row_ror:8
+    }
+#pragma unroll
+  for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float lo = s16[fb][w], hi = s16[fb + 2][w];
+      s8[fb][w] = (b2 ? hi : lo) + dpp(b2 ? lo : hi, std::integral_constant<int, 0x141>{});        // row_half_mirror
+    }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float lo = s8[0][w], hi = s8[1][w];
+    s4[w] = (b1 ? hi : lo) + dpp(b1 ? lo : hi, std::integral_constant<int, 0x4E>{});               // quad_perm [2,3,0,1]
+  }
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const float lo = s4[w], hi = s4[w + 2];
+    out[w] = (b0 ? hi : lo) + dpp(b0 ? lo : hi, std::integral_constant<int, 0xB1>{});              // quad_perm [1,0,3,2]
+  }
 }
 
 // Sum over the 128 features of a row: 32 in-lane values, then the three partner lanes (same n, other kq).
