@@ -251,6 +251,49 @@ __global__ void seg_bwd_generic_kernel(const float* __restrict__ d_out, long ld_
   d_data[pos * ld + d] = g;
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// 'std' (src/util.py:129-130 -> torch_scatter.scatter_std, unbiased): thread per (segment, column), two sweeps over the segment's
+// rows -- the mean first, then the squared deviations (the second sweep is served by the caches).  Off the hot path.
+// ----------------------------------------------------------------------------------------------------------
+__global__ void seg_std_fwd_kernel(const float* __restrict__ data, long ld, int D, const int* __restrict__ perm,
+                                   const int* __restrict__ rowptr, long N, float* __restrict__ out, long ld_out,
+                                   float* __restrict__ mean_out) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= N * D) return;
+  const long n = gid / D;
+  const int d = (int)(gid - n * D);
+  const int beg = rowptr[n], end = rowptr[n + 1];
+  float sum = 0.f;
+  for (int j = beg; j < end; ++j) sum += data[(perm ? (long)perm[j] : (long)j) * ld + d];
+  const int cnt = end - beg;
+  const float mean = sum / (float)(cnt > 0 ? cnt : 1);
+  float ssq = 0.f;
+  for (int j = beg; j < end; ++j) {
+    const float dev = data[(perm ? (long)perm[j] : (long)j) * ld + d] - mean;
+    ssq += dev * dev;
+  }
+  const float cu = (float)(cnt > 2 ? cnt - 1 : 1);          // clamp(clamp(count, 1) - 1, 1)
+  out[n * ld_out + d] = sqrtf(ssq / (cu + 1e-6f));
+  if (mean_out) mean_out[n * ld_out + d] = mean;
+}
+
+// autograd of the composite: d std / d x = (x - mean) / (std (count_u + 1e-6)); 0 / 0 = NaN for a segment without variance, like the wheel
+__global__ void seg_std_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ out, const float* __restrict__ mean,
+                                   long ld_out, const float* __restrict__ data, long ld, int D, const int* __restrict__ perm,
+                                   const int* __restrict__ seg, const int* __restrict__ rowptr, long E,
+                                   float* __restrict__ d_data, long ld_d) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= E * D) return;
+  const long j = gid / D;
+  const int d = (int)(gid - j * D);
+  const long r = seg[j];
+  const long pos = perm ? perm[j] : j;
+  const int cnt = rowptr[r + 1] - rowptr[r];
+  const float cu = (float)(cnt > 2 ? cnt - 1 : 1);
+  const float x = data[pos * ld + d];
+  d_data[pos * ld_d + d] = d_out[r * ld_out + d] * (x - mean[r * ld_out + d]) / (out[r * ld_out + d] * (cu + 1e-6f));
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static int sort_bits(int64_t N) {
@@ -391,4 +434,26 @@ extern "C" int hgn_segment_reduce_bwd(const float* d_out, int64_t ld_out, int D,
                        (long)ld_out, D, perm, seg, rowptr, (long)E, o, argmax, argmin, base, d_data, (long)ld);
   }
   return hgn_check_launch("hgn_segment_reduce_bwd");
+}
+
+extern "C" int hgn_segment_std_fwd(const float* data, int64_t ld, int D, const int32_t* perm, const int32_t* rowptr, int64_t N,
+                                   float* out, int64_t ld_out, float* mean, void* stream) {
+  if (N == 0) return HGN_OK;
+  if (!data || !rowptr || !out || N < 0 || D < 1 || ld < D || ld_out < D) return hgn_fail(HGN_E_INVALID, "hgn_segment_std_fwd: bad argument");
+  ProfScope ps(5, (double)N, (hipStream_t)stream);
+  hipLaunchKernelGGL(seg_std_fwd_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, data, (long)ld, D,
+                     perm, rowptr, (long)N, out, (long)ld_out, mean);
+  return hgn_check_launch("hgn_segment_std_fwd");
+}
+
+extern "C" int hgn_segment_std_bwd(const float* d_out, const float* out, const float* mean, int64_t ld_out, const float* data,
+                                   int64_t ld, int D, const int32_t* perm, const int32_t* seg, const int32_t* rowptr, int64_t E,
+                                   float* d_data, int64_t ld_d, void* stream) {
+  if (E == 0) return HGN_OK;
+  if (!d_out || !out || !mean || !data || !seg || !rowptr || !d_data || E < 0 || D < 1 || ld < D || ld_d < D || ld_out < D)
+    return hgn_fail(HGN_E_INVALID, "hgn_segment_std_bwd: bad argument");
+  ProfScope ps(6, (double)E, (hipStream_t)stream);
+  hipLaunchKernelGGL(seg_std_bwd_kernel, dim3((unsigned)((E * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_out, out, mean,
+                     (long)ld_out, data, (long)ld, D, perm, seg, rowptr, (long)E, d_data, (long)ld_d);
+  return hgn_check_launch("hgn_segment_std_bwd");
 }

@@ -90,6 +90,10 @@ _SIGS = {
     'hgn_segment_reduce_bwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'hgn_segment_std_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p]),
+    'hgn_segment_std_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     'hgn_mlp_fwd': (C.c_int, [C.POINTER(MlpFwd), C.c_void_p]),
     'hgn_pack_bf16x3': (C.c_int, [C.POINTER(Pack), C.c_int, C.c_void_p]),
     'hgn_set_matmul_products': (C.c_int, [C.c_int]),

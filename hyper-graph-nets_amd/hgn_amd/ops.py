@@ -831,6 +831,42 @@ class AggregateFn(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+class SegmentStdFn(torch.autograd.Function):
+    """'std' of util.unsorted_segment_operation (src/util.py:129-130 -> torch_scatter.scatter_std, unbiased): include/hgn_mp.h
+    hgn_segment_std_fwd / _bwd.  csr = (perm or None, rowptr, seg)."""
+
+    @staticmethod
+    def forward(ctx, csr, data):
+        perm, rowptr, seg = csr
+        data = _rowmajor(data)
+        _lib.require_gpu(data)
+        N, D = rowptr.shape[0] - 1, data.shape[1]
+        out = torch.empty(N, D, device=data.device)
+        mean = torch.empty(N, D, device=data.device)
+        _lib.check(_lib.lib().hgn_segment_std_fwd(data.data_ptr(), _ld(data), D, perm.data_ptr() if perm is not None else None,
+                                                  rowptr.data_ptr(), N, out.data_ptr(), D, mean.data_ptr(), _lib.stream_ptr()),
+                   'hgn_segment_std_fwd')
+        ctx.csr = csr
+        ctx.save_for_backward(data, out, mean)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        perm, rowptr, seg = ctx.csr
+        data, out, mean = ctx.saved_tensors
+        d_out = _rowmajor(d_out).contiguous()
+        E, D = data.shape
+        g = torch.empty(E, D, device=data.device)
+        _lib.check(_lib.lib().hgn_segment_std_bwd(d_out.data_ptr(), out.data_ptr(), mean.data_ptr(), D, data.data_ptr(), _ld(data), D,
+                                                  perm.data_ptr() if perm is not None else None, seg.data_ptr(), rowptr.data_ptr(),
+                                                  E, g.data_ptr(), D, _lib.stream_ptr()), 'hgn_segment_std_bwd')
+        return None, g
+
+
+def segment_std(data: torch.Tensor, csr) -> torch.Tensor:
+    return SegmentStdFn.apply(tuple(csr), data)
+
+
 def aggregate(datas: Sequence[torch.Tensor], csrs: Sequence[Tuple], ops: Sequence[str]) -> torch.Tensor:
     """csrs[i] = (perm or None, rowptr, seg) for data i."""
     train = torch.is_grad_enabled() and any(d.requires_grad for d in datas)

@@ -149,6 +149,51 @@ class GaussianMixtureClustering(AbstractClusteringAlgorithm):
         return gm.predict(X)
 
 
+class HDBSCANClustering(AbstractClusteringAlgorithm):
+    """src/rmp/hdbscan.py:13-105 (`clustering: hdbscan`, get_rmp.py:68-69): density-based clusters of the standardised target
+    features; the number of clusters is the algorithm's outcome and nodes it calls noise (label -1) belong to no cluster (they get
+    no intra-cluster edges, abstract_clustering_algorithm.py:104-122 skips the label).
+
+    The reference calls the third-party `hdbscan` wheel (requirements.txt, absent from this image and from /root/reference); here
+    the same algorithm comes from scikit-learn's port, `sklearn.cluster.HDBSCAN`, with the reference's arguments (max / min cluster
+    size, min_samples; `core_dist_n_jobs` / `prediction_data` are wheel-only and affect no label).  Labels are therefore pinned to
+    scikit-learn (tests/golden/hdbscan_labels.json), not to the wheel.  Two things the reference leaves undone are done here,
+    because without them its own path raises: `neigboring_clusters` is set (the reference's `run` override never assigns it and
+    remote_message_passing.py:78 reads it), from the mesh edges between two different non-noise labels.  Intra-cluster sampling
+    (`spotter` / `exemplars` through the wheel's condensed tree and soft membership vectors, hdbscan.py:71-101, marked "TODO: Fix
+    sampling approach" there) needs internals scikit-learn does not expose: `intra_cluster_sampling.enabled` raises."""
+
+    def __init__(self, sampling, max_cluster_size, min_cluster_size, min_samples, spotter_threshold):
+        super().__init__(num_clusters=10, sampling=sampling, alpha=0.5, threshold=spotter_threshold)
+        self._max_cluster_size = max_cluster_size
+        self._min_cluster_size = min_cluster_size
+        self._min_samples = min_samples
+        self._spotter_threshold = spotter_threshold
+
+    def _cluster(self, graph):                           # hdbscan.py:53-68
+        import sklearn.cluster
+        from sklearn.preprocessing import StandardScaler
+        X = StandardScaler().fit_transform(graph.target_feature.detach().cpu().numpy())
+        fit = sklearn.cluster.HDBSCAN(min_cluster_size=self._min_cluster_size, min_samples=self._min_samples,
+                                      max_cluster_size=self._max_cluster_size, copy=True).fit(X)
+        return fit.labels_
+
+    def run(self, graph: MultiGraphWithPos, number=0, b4=True) -> List[Tensor]:
+        """hdbscan.py:29-51; `number` / `b4`: the obstacle rows removed in front of / behind the clustered nodes
+        (remote_message_passing.py:131), as in AbstractClusteringAlgorithm.run."""
+        if self._sampling:
+            raise NotImplementedError('hdbscan with intra_cluster_sampling: the reference samples through the hdbscan wheel\'s '
+                                      'condensed tree and membership vectors (src/rmp/hdbscan.py:71-101), which scikit-learn\'s '
+                                      'HDBSCAN does not expose')
+        labels = [int(x) for x in self._cluster(graph)]
+        self._labels = [-1] * number + labels if b4 else labels + [-1] * number
+        clusters = self._labels_to_indices(labels) if labels and max(labels) >= 0 else []
+        self._num_clusters = len(clusters)
+        keep = [p for p in self.get_neigbors(graph, labels) if int(p[0]) >= 0]        # noise joins nothing
+        self.neigboring_clusters = keep
+        return clusters
+
+
 class RandomClustering(AbstractClusteringAlgorithm):
     def _cluster(self, graph):                           # random_clustering.py:38-39
         return [int(x) for x in np.random.rand(graph.target_feature.shape[0]) * self._num_clusters]
@@ -382,7 +427,7 @@ def get_rmp(config) -> RemoteMessagePassing:
 
 
 def get_clustering_algorithm(name: str, config) -> Optional[AbstractClusteringAlgorithm]:
-    """get_rmp.py:29-81.  HDBSCAN (a third-party wheel in the reference, get_rmp.py:68-69) is not provided."""
+    """get_rmp.py:29-81."""
     rmp = config['rmp']
     samp = rmp.get('intra_cluster_sampling', {})
     args = (rmp['num_clusters'], samp.get('enabled', False), samp.get('alpha', 0.5), samp.get('spotter_threshold', 0))
@@ -390,6 +435,10 @@ def get_clustering_algorithm(name: str, config) -> Optional[AbstractClusteringAl
              'kmeans': KMeansClustering, 'k-means': KMeansClustering}
     if name == 'none':
         return None
+    if name == 'hdbscan':                                # get_rmp.py:47-69: its own block of the configuration
+        h = rmp['hdbscan']
+        return HDBSCANClustering(samp.get('enabled', False), h['max_cluster_size'], h['min_cluster_size'], h['min_samples'],
+                                 h['spotter_threshold'])
     if name in table:
         return table[name](*args)
     raise NotImplementedError('Implement your clustering algorithms here!')

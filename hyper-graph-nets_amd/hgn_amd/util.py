@@ -56,7 +56,7 @@ def unsorted_segment_operation(data, segment_ids, num_segments, operation):
     [0, num_segments); empty segments give 0; result has ``data``'s dtype."""
     from . import ops, topology
     assert all([i in data.shape for i in segment_ids.shape]), "segment_ids.shape should be a prefix of data.shape"
-    if operation not in ('sum', 'mean', 'max', 'min'):
+    if operation not in ('sum', 'mean', 'max', 'min', 'std'):
         raise Exception('Invalid operation type!')
     if segment_ids.dim() != 1:
         segment_ids = segment_ids.reshape(segment_ids.shape[0], -1)[:, 0]
@@ -67,5 +67,8 @@ def unsorted_segment_operation(data, segment_ids, num_segments, operation):
         inner *= int(d)
     flat = data.reshape(E, inner).float()
     csr = topology.segment_csr(segment_ids, int(num_segments), data.device)
-    out = ops.aggregate([flat], [(csr.perm, csr.rowptr, csr.seg)], (operation,))
+    if operation == 'std':                                  # util.py:129-130: torch_scatter.scatter_std (unbiased), its own kernels
+        out = ops.segment_std(flat, (csr.perm, csr.rowptr, csr.seg))
+    else:
+        out = ops.aggregate([flat], [(csr.perm, csr.rowptr, csr.seg)], (operation,))
     return out.reshape((int(num_segments),) + tuple(data.shape[1:])).type(data.dtype)

@@ -81,6 +81,19 @@ int hgn_segment_reduce_bwd(const float* d_out, int64_t ld_out, int D, const int3
                            const int32_t* argmax, const int32_t* argmin, const float* base, float* d_data,
                            int64_t ld_data, void* stream);
 
+/* The fifth operation of util.unsorted_segment_operation, 'std' (src/util.py:129-130 -> torch_scatter.scatter_std with its default
+ * unbiased = True; unreachable from the reference's configs).  torch-scatter 2.0.9 (torch_scatter/composite/std.py) as published:
+ *   count = max(#rows of the segment, 1);  mean = sum / count;  out = sqrt( sum (x - mean)^2 / (max(count - 1, 1) + 1e-6) )
+ * so an empty segment gives 0.  `mean` (nullable, [N, ld_out]) is written for the backward pass, which is the autograd of that
+ * composite:  d_data[pos][d] = d_out[n][d] (x - mean[n][d]) / (out[n][d] (max(count - 1, 1) + 1e-6))  -- NaN (0 / 0) for the rows of a
+ * segment without variance, exactly like the wheel's sqrt'(0) * 0. */
+int hgn_segment_std_fwd(const float* data, int64_t ld_data, int D, const int32_t* perm, const int32_t* rowptr, int64_t N,
+                        float* out, int64_t ld_out, float* mean, void* stream);
+int hgn_segment_std_bwd(const float* d_out, const float* out, const float* mean, int64_t ld_out, const float* data,
+                        int64_t ld_data, int D, const int32_t* perm, const int32_t* seg, const int32_t* rowptr, int64_t E,
+                        float* d_data, int64_t ld_d, void* stream);
+
+
 /* ------------------------------------------------------------------------------------------------------
  * a1/a3/a5: fused MLP  out = [res +] [LN](W3 relu(W2 relu(z1) + b2) + b3),
  *   z1 = b1 + sum_src W1[:, src.col0 : src.col0+src.K] * x_src[idx_src ? idx_src[i] : i]

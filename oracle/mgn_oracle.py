@@ -114,6 +114,12 @@ def segment_reduce(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: 
         out, arg = _FirstArgReduce.apply(src, segment_ids, num_segments, True)
     elif operation == 'min':
         out, arg = _FirstArgReduce.apply(src, segment_ids, num_segments, False)
+    elif operation == 'std':                                                  # util.py:129-130 (torch_scatter.scatter_std, unbiased)
+        zeros = src.new_zeros((num_segments,) + tuple(src.shape[1:]))
+        cnt = zeros.scatter_add(0, segment_ids, torch.ones_like(src)).clamp(min=1)
+        mean = zeros.scatter_add(0, segment_ids, src) / cnt
+        dev = src - mean.gather(0, segment_ids)
+        out = (zeros.scatter_add(0, segment_ids, dev * dev) / ((cnt - 1).clamp(min=1) + 1e-6)).sqrt()
     else:
         raise Exception('Invalid operation type!')                            # util.py:132
     out = out.type(data.dtype)                                                # util.py:133

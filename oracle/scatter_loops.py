@@ -12,6 +12,8 @@ Semantics restated (torch-scatter 2.0.9 documentation of scatter(..., reduce) an
   * max / min visit the elements in index order e = 0, 1, ... and replace the running value only on a STRICT improvement
     (`src[e] > out` / `src[e] < out`)  =>  AMONG EQUAL VALUES THE FIRST ELEMENT WINS; the returned arg is that element's
     position, or src.size(0) for an empty segment;
+  * std (torch_scatter/composite/std.py; src/util.py:129-130, unreachable from the configs): sqrt(sum (x - mean)^2 /
+    (max(count - 1, 1) + 1e-6)) with mean = sum / max(count, 1); 0 for an empty segment;
   * backward: sum -> grad_out[index[e]]; mean -> grad_out[index[e]] / max(count, 1); max / min -> grad_out goes to the single
     arg element, nothing to the others.
 Only tests/ (and tests/golden/gen_golden.py) import this module.
@@ -39,6 +41,27 @@ def scatter_forward(src: List[List[float]], index: List[int], dim_size: int, op:
                 for d in range(D):
                     out[n][d] = out[n][d] / c
         return out, [[E] * D for _ in range(dim_size)]
+    if op == 'std':
+        # torch_scatter/composite/std.py (2.0.9): count = max(#elements, 1); mean = sum / count; out = sum (x - mean)^2;
+        # unbiased: count = max(count - 1, 1); out = sqrt(out / (count + 1e-6)).  Empty segment: sqrt(0 / (1 + 1e-6)) = 0.
+        cnt = [0] * dim_size
+        tot = [[0.0] * D for _ in range(dim_size)]
+        for e in range(E):
+            cnt[index[e]] += 1
+            for d in range(D):
+                tot[index[e]][d] += src[e][d]
+        out = [[0.0] * D for _ in range(dim_size)]
+        for e in range(E):
+            n = index[e]
+            c = max(cnt[n], 1)
+            for d in range(D):
+                dev = src[e][d] - tot[n][d] / c
+                out[n][d] += dev * dev
+        for n in range(dim_size):
+            c = max(max(cnt[n], 1) - 1, 1)
+            for d in range(D):
+                out[n][d] = math.sqrt(out[n][d] / (c + 1e-6))
+        return out, [[E] * D for _ in range(dim_size)]
     if op not in ('max', 'min'):
         raise Exception('Invalid operation type!')
     start = -math.inf if op == 'max' else math.inf
@@ -59,9 +82,28 @@ def scatter_forward(src: List[List[float]], index: List[int], dim_size: int, op:
     return out, arg
 
 
-def scatter_backward(grad_out: List[List[float]], index: List[int], arg: List[List[int]], op: str, E: int) -> List[List[float]]:
+def scatter_backward(grad_out: List[List[float]], index: List[int], arg: List[List[int]], op: str, E: int,
+                     src: List[List[float]] = None) -> List[List[float]]:
     D = len(grad_out[0]) if grad_out else 0
     g = [[0.0] * D for _ in range(E)]
+    if op == 'std':
+        # autograd of the composite: d std / d x_e = (x_e - mean) / (std * (count_unbiased + 1e-6)); a segment without variance
+        # gives 0 / 0 = NaN (the wheel's sqrt'(0) * 0), an empty one has no elements
+        fwd, _ = scatter_forward(src, index, len(grad_out), 'std')
+        cnt = [0] * len(grad_out)
+        tot = [[0.0] * D for _ in range(len(grad_out))]
+        for e in range(E):
+            cnt[index[e]] += 1
+            for d in range(D):
+                tot[index[e]][d] += src[e][d]
+        for e in range(E):
+            n = index[e]
+            c = max(cnt[n], 1)
+            cu = max(c - 1, 1) + 1e-6
+            for d in range(D):
+                den = fwd[n][d] * cu
+                g[e][d] = grad_out[n][d] * (src[e][d] - tot[n][d] / c) / den if den != 0.0 else float('nan')
+        return g
     if op in ('sum', 'mean'):
         cnt = [0] * len(grad_out)
         for e in range(E):
@@ -102,6 +144,6 @@ def segment_op(data, segment_ids, num_segments: int, op: str, weight=None):
     gx = None
     if weight is not None:
         w = weight.detach().double().reshape(num_segments, -1).tolist()
-        g = scatter_backward(w, idx, arg, op, E)
+        g = scatter_backward(w, idx, arg, op, E, src)
         gx = torch.tensor(g, dtype=torch.float64).reshape(data.shape) if E else torch.zeros(data.shape, dtype=torch.float64)
     return o.to(data.dtype), a, gx

@@ -65,6 +65,32 @@ def test_g1_segment_ops_golden():
         hgn_amd.unsorted_segment_operation(g1['data2'].cuda(), (g1['ids'] + 100).cuda(), g1['num_segments'], 'sum')
 
 
+def test_g1_segment_std_golden():
+    """The fifth operation unsorted_segment_operation accepts, 'std' (src/util.py:129-130 -> torch_scatter.scatter_std, unbiased;
+    unreachable from the reference's configs): HIP kernels (hgn_segment_std_fwd / _bwd) against the reference's own function run
+    through the import stand-in AND against the brute-force loops stored next to it (tests/golden/gen_golden_std.py): values to 2e-6,
+    gradients to 2e-5 on the rows of segments with at least two elements; a one-element segment has no variance: its gradient is NaN
+    here as in the wheel's composite (sqrt'(0) * 0), an empty segment gives 0."""
+    import hgn_amd
+    fx = torch.load(os.path.join(H.GOLDEN, 'g1_segment_std.pt'))
+    assert set(fx) == {'wide', 'one_d', 'narrow_unsorted'}
+    for name, rec in fx.items():
+        for ids in (rec['ids'].cuda(), rec['ids'].clone()):
+            x = rec['data'].clone().cuda().requires_grad_(True)
+            y = hgn_amd.unsorted_segment_operation(x, ids, rec['num_segments'], 'std')
+            assert y.dtype == x.dtype and tuple(y.shape) == tuple(rec['ref_y'].shape)
+            assert H.rel_err(y, rec['ref_y']) <= 2e-6 and H.rel_err(y, rec['bf_y']) <= 2e-6, name
+            empty = (rec['count'] == 0).nonzero().flatten()
+            assert empty.numel() == 0 or float(y[empty.cuda()].abs().max()) == 0.0
+            (y * rec['w'].cuda()).sum().backward()
+            multi = (rec['count'][rec['ids']] >= 2)
+            g = x.grad.cpu()
+            assert H.rel_err(g[multi], rec['ref_gx'][multi]) <= 2e-5 and H.rel_err(g[multi].double(), rec['bf_gx'][multi]) <= 2e-5, name
+            single = ~multi
+            if single.any():
+                assert torch.isnan(g[single]).all() and torch.isnan(rec['ref_gx'][single]).all(), name
+
+
 @pytest.mark.parametrize('E,N,D', [(0, 5, 128), (1, 1, 128), (1000, 37, 128), (5000, 4000, 128), (777, 50, 3), (64, 9, 1)])
 def test_segment_ops_vs_oracle(E, N, D):
     import hgn_amd

@@ -427,8 +427,10 @@ def test_random_clustering_formula_and_get_rmp_surface():
         assert (alg is None) == (r['clustering'] == 'none') and (conn is None) == (r['connector'] in ('none', 'repeated')), name
     for cl in ('random', 'spectral', 'gmm', 'kmeans', 'k-means', 'none'):
         rmp.get_clustering_algorithm(cl, cfgs['flag']['model'])
+    h = rmp.get_clustering_algorithm('hdbscan', cfgs['flag']['model'])           # get_rmp.py:47-69: arguments from the `hdbscan` block
+    assert isinstance(h, rmp.HDBSCANClustering) and (h._max_cluster_size, h._min_cluster_size, h._min_samples) == (50, 20, 1)
     with pytest.raises(NotImplementedError):
-        rmp.get_clustering_algorithm('hdbscan', cfgs['flag']['model'])        # third-party wheel in the reference; not provided
+        rmp.get_clustering_algorithm('dbscan', cfgs['flag']['model'])
     with pytest.raises(NotImplementedError):
         rmp.get_connector('multigraph', cfgs['flag']['model'])                # get_rmp.py:92 rejects it too
 
@@ -544,3 +546,44 @@ def test_flat_params_reports_parameters_left_lazy_and_refuses_late_materialisati
     net(torch.randn(1, 3))                                     # the lazy layer materialises OUTSIDE the flat buffer
     with pytest.raises(RuntimeError, match='outside the flat buffer'):
         fp.check_outsiders()
+
+
+def test_hdbscan_clustering_host_logic():
+    """`clustering: hdbscan` (src/rmp/hdbscan.py:13-105, get_rmp.py:47-69) on scikit-learn's HDBSCAN with the reference's arguments:
+    labels equal the fixture (tests/golden/gen_hdbscan_fixture.py: the scikit-learn port is what is pinned -- the wheel the reference
+    imports is absent from this image), noise nodes (-1) join no cluster, neighbouring clusters come from mesh edges between two
+    different non-noise labels, the obstacle offset of `run(graph, number, b4)` pads the label list like the other algorithms, and
+    intra-cluster sampling (wheel internals) raises instead of doing something else."""
+    import importlib.util
+    from hgn_amd import rmp, util
+    spec = importlib.util.spec_from_file_location('gen_hdbscan_fixture', os.path.join(ROOT, 'tests', 'golden', 'gen_hdbscan_fixture.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fx = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'hdbscan_labels.json')))
+    X = torch.from_numpy(gen.cloud(fx['seed']))
+    n = X.shape[0]
+    snd = torch.arange(n - 1)
+    es = util.EdgeSet('mesh_edges', torch.zeros(n - 1, 7), snd, snd + 1)                 # a path: neighbours = label changes along it
+    graph = util.MultiGraphWithPos(node_features=[torch.zeros(n, 5)], edge_sets=[es], target_feature=X, mesh_features=X[:, :2],
+                                   model_type='flag', node_dynamic=torch.zeros(n), unnormalized_edges=es, obstacle_nodes=None)
+    cfg = {'rmp': {'clustering': 'hdbscan', 'connector': 'hyper', 'num_clusters': 10,
+                   'intra_cluster_sampling': {'enabled': False, 'alpha': 0.1, 'spotter_threshold': 0}, 'hdbscan': dict(fx['args'], spotter_threshold=0.9)}}
+    algo = rmp.get_clustering_algorithm('hdbscan', cfg)
+    assert isinstance(algo, rmp.HDBSCANClustering)
+    clusters = algo.run(graph)
+    labels = fx['labels']
+    assert algo._labels == labels
+    k = max(labels) + 1
+    assert len(clusters) == k == algo._num_clusters and k >= 2
+    for c, members in enumerate(clusters):
+        assert members.tolist() == [i for i, l in enumerate(labels) if l == c]
+    noise = {i for i, l in enumerate(labels) if l < 0}
+    assert noise and not (noise & {int(i) for m in clusters for i in m})
+    want = sorted({(min(labels[i], labels[i + 1]), max(labels[i], labels[i + 1])) for i in range(n - 1)
+                   if labels[i] != labels[i + 1] and labels[i] >= 0 and labels[i + 1] >= 0})
+    assert [tuple(p.tolist()) for p in algo.neigboring_clusters] == want
+    algo.run(graph, 3, True)
+    assert algo._labels == [-1] * 3 + labels
+    cfg['rmp']['intra_cluster_sampling']['enabled'] = True
+    with pytest.raises(NotImplementedError, match='condensed tree'):
+        rmp.get_clustering_algorithm('hdbscan', cfg).run(graph)

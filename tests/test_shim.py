@@ -28,7 +28,7 @@ PATHS = {
     'src.rmp.multigraph_connector': ['MultigraphConnector'], 'src.rmp.abstract_connector': ['AbstractConnector'],
     'src.rmp.abstract_clustering_algorithm': ['AbstractClusteringAlgorithm'], 'src.rmp.k_means_clustering': ['KMeansClustering'],
     'src.rmp.spectral_clustering': ['SpectralClustering'], 'src.rmp.gaussian_mixture': ['GaussianMixtureClustering'],
-    'src.rmp.random_clustering': ['RandomClustering'],
+    'src.rmp.random_clustering': ['RandomClustering'], 'src.rmp.hdbscan': ['HDBSCAN'],
     'src.graph_balancer.get_graph_balancer': ['get_balancer', 'get_balancer_algorithm'],
     'src.graph_balancer.graph_balancer': ['GraphBalancer'], 'src.graph_balancer.abstract_graph_balancer': ['AbstractGraphBalancer'],
     'src.graph_balancer.random_balancing': ['RandomGraphBalancer'], 'src.graph_balancer.ricci': ['Ricci'],
@@ -81,15 +81,15 @@ def test_modules_outside_the_hot_path_fall_through_to_the_reference_tree(tmp_pat
     (ref / 'src' / '__init__.py').write_text('')
     (ref / 'src' / 'algorithms' / 'MeshSimulator.py').write_text('from src.model.get_model import get_model\nWHO = "reference trainer"\n')
     (ref / 'src' / 'migration' / 'meshgraphnet.py').write_text('WHO = "reference model (must be shadowed)"\n')
-    (ref / 'src' / 'rmp' / 'hdbscan.py').write_text('WHO = "reference hdbscan wrapper"\n')
+    (ref / 'src' / 'rmp' / 'user_extension.py').write_text('WHO = "a module of the checkout the shim does not provide"\n')
     code = '''
         from src.algorithms.MeshSimulator import WHO, get_model
         import src.migration.meshgraphnet as m
-        import src.rmp.hdbscan as h
+        import src.rmp.user_extension as h
         import hgn_amd.system_model
         assert WHO == "reference trainer" and get_model is hgn_amd.system_model.get_model
         assert not hasattr(m, 'WHO') and m.MeshGraphNet.__module__ == 'hgn_amd.modules'
-        assert h.WHO == "reference hdbscan wrapper"
+        assert h.WHO == "a module of the checkout the shim does not provide"
         print('ok')
     '''
     r = _run(code, extra_path=[str(ref)])

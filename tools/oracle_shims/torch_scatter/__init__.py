@@ -76,4 +76,17 @@ def scatter_min(src, index, dim=0, out=None, dim_size=None):
 
 
 def scatter_std(src, index, dim=0, out=None, dim_size=None, unbiased=True):
-    raise NotImplementedError("scatter_std is unreachable from every reference config (src/util.py:129)")
+    """torch-scatter 2.0.9, torch_scatter/composite/std.py as published: count = clamp(#elements, 1); mean = sum / count;
+    out = scatter_sum((src - mean[index])^2); unbiased: count = clamp(count - 1, 1); out = sqrt(out / (count + 1e-6)).
+    A composite of differentiable ops, so autograd gives its backward (NaN where a segment's variance is 0, as in the wheel).
+    Unreachable from every reference config (src/util.py:129-130); restated because unsorted_segment_operation accepts it."""
+    _check(src, index, dim)
+    if out is not None:
+        dim_size = out.size(0)
+    count = scatter_add(torch.ones_like(src), index, 0, None, dim_size).clamp(1)
+    mean = scatter_add(src, index, 0, None, dim_size).div(count)
+    var = src - mean.gather(0, index)
+    res = scatter_add(var * var, index, 0, None, dim_size)
+    if unbiased:
+        count = count.sub(1).clamp_(1)
+    return res.div(count + 1e-6).sqrt()
