@@ -17,6 +17,7 @@ from ._lib import OP_CODES
 LAT = 128
 _ws_cache = {}
 _GATE_LOG = None              # tests only: when a list, every training forward appends (first-layer weight ptr, ReLU sign words, row index)
+_ARG_LOG = None               # tests only: when a list, every training edge block with max / min aggregates appends (first-layer weight ptr, argmax, argmin, sorted position -> edge index)
 
 
 _WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
@@ -620,6 +621,8 @@ class EdgeBlockFn(torch.autograd.Function):
             L.hgn_prof_tag(0)
         if train and _GATE_LOG is not None:
             _GATE_LOG.append((wt[0].data_ptr(), saves[4], topo.r.perm))
+        if train and _ARG_LOG is not None and (amax is not None or amin is not None):
+            _ARG_LOG.append((wt[0].data_ptr(), amax, amin, topo.r.perm))
         if train:
             ctx.set_materialize_grads(False)
             ctx.topo = topo

@@ -175,6 +175,96 @@ class GateTransfer:
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# Winner transfer: the fp64 oracle evaluated with the max / min WINNERS the HIP forward chose.
+# A `pna` block takes, per receiver and feature, the largest and the smallest incoming edge value.  Where two candidates sit within
+# fp32 rounding of each other the fp32 evaluation may crown the other one than fp64 does -- like a ReLU gate, a discrete decision
+# that moves the gradient routing (all of d(max) goes to ONE edge) without being an error of the arithmetic.  With the HIP
+# forward's winners (hgn_segment_reduce_fwd returns them: CSR positions) forced in the oracle, what is left is the arithmetic.
+# ------------------------------------------------------------------------------------------------------------------
+def hip_winners(model, log):
+    """ops._ARG_LOG of one training forward -> {edge-set name: [{'max': arg, 'min': arg}, ...] in block order}; arg [N, 128] holds
+    the ORIGINAL edge index of the winner (-1: empty segment)."""
+    name_of = {}
+    for k, p in model.named_parameters():
+        if '.edge_models.' in k and k.startswith('processor.') and k.endswith('.layers.linear_0.weight'):
+            name_of[p.data_ptr()] = k.split('.edge_models.')[1].split('.')[0]
+    out = {}
+    for ptr, amax, amin, perm in log:
+        p = perm.detach().cpu().long()
+        rec = {}
+        for op, a in (('max', amax), ('min', amin)):
+            if a is not None:
+                a = a.detach().cpu().long()
+                rec[op] = torch.where(a >= 0, p[a.clamp(min=0)], torch.full_like(a, -1))
+        out.setdefault(name_of[ptr], []).append(rec)
+    return out
+
+
+class WinnerTransfer:
+    """Context manager: inside it the oracle's max / min aggregates take the given winners; counts where they differ from the
+    oracle's own and how far the two candidates were apart there (relative to the aggregate's scale)."""
+
+    def __init__(self, winners):
+        self.winners = {k: list(v) for k, v in winners.items()}
+        self.flipped, self.total, self.max_gap_at_flip = 0, 0, 0.0
+
+    def __enter__(self):
+        self._agg = O.aggregation
+
+        def aggregation(edge_sets, features, num_nodes, aggregator):
+            for es in edge_sets:
+                ops = O.PNA_OPS if aggregator == 'pna' else (aggregator,)
+                rec = None
+                for op in ops:
+                    if op not in ('max', 'min'):
+                        features.append(O.segment_reduce(es.features, es.receivers, num_nodes, op))
+                        continue
+                    if rec is None:
+                        rec = self.winners[es.name].pop(0)
+                    arg = rec[op]
+                    assert arg.shape == (num_nodes, es.features.shape[1]), (arg.shape, num_nodes)
+                    own, own_arg = O.segment_reduce(es.features, es.receivers, num_nodes, op, return_arg=True)
+                    has = arg >= 0
+                    picked = es.features.gather(0, arg.clamp(min=0)) * has.to(es.features.dtype)
+                    assert bool(((own_arg < es.features.shape[0]) == has).all()), 'empty segments differ'
+                    diff = has & (own_arg != arg)
+                    self.total += int(has.sum())
+                    n = int(diff.sum())
+                    if n:
+                        self.flipped += n
+                        gap = (picked.detach() - own.detach()).abs()[diff].max() / es.features.detach().abs().max().clamp(min=1e-30)
+                        self.max_gap_at_flip = max(self.max_gap_at_flip, float(gap))
+                    features.append(picked)
+            return torch.cat(features, dim=-1)
+        O.aggregation = aggregation
+        return self
+
+    def __exit__(self, *exc):
+        O.aggregation = self._agg
+        return False
+
+
+def hip_run_logged(model, graph, target, mask):
+    """hip_run that also returns the discrete decisions of the HIP forward: (ReLU gates, max / min winners) for the transfers."""
+    from hgn_amd import ops
+    ops._GATE_LOG, ops._ARG_LOG = [], []
+    try:
+        res = hip_run(model, graph, target, mask)
+        gates, winners = hip_gates(model, ops._GATE_LOG), hip_winners(model, ops._ARG_LOG)
+    finally:
+        ops._GATE_LOG, ops._ARG_LOG = None, None
+    return res + (gates, winners)
+
+
+def oracle_run_with_hip_decisions(sd, graph, arch, agg, target, mask, gates, winners, set_order=None):
+    """The fp64 oracle with the HIP forward's ReLU gates AND max / min winners: -> (out, loss, grads, GateTransfer, WinnerTransfer)."""
+    with GateTransfer(gates) as gt, WinnerTransfer(winners) as wt:
+        out, loss, grads, _ = oracle_run(sd, graph, arch, agg, target, mask, set_order=set_order)
+    assert all(len(v) == 0 for v in gt.gates.values()) and all(len(v) == 0 for v in wt.winners.values()), 'decisions left over'
+    return out, loss, grads, gt, wt
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # Conditioning of a test instance, measured on an fp64 oracle run: distance from a ReLU kink / from a max-min tie.
 # ------------------------------------------------------------------------------------------------------------------
 class KinkMargin:
