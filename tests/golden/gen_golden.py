@@ -82,11 +82,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', required=True)
     ap.add_argument('--only-g1', action='store_true')
+    ap.add_argument('--only-cases', default=None, help='comma-separated substrings: write only the model fixtures whose name matches (and nothing else)')
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(4)
 
     # ---- G1: unsorted_segment_operation ---------------------------------------------------------------
+    if not a.only_cases:
+        write_g1(a)
+    if a.only_g1:
+        print('G1 done')
+        return
+    write_models(a)
+    if not a.only_cases:
+        write_g6_g7(a)
+    print('done')
+
+
+def write_g1(a):
     gen = torch.Generator().manual_seed(1)
     E, N, D = 97, 23, 128
     ids = torch.randint(0, N, (E,), generator=gen)
@@ -133,10 +146,9 @@ def main():
             assert torch.allclose(x.grad.double(), gx, rtol=1e-6, atol=1e-6), (cname, op)
         g1['adversarial'][cname] = rec
     torch.save(g1, os.path.join(a.out, 'g1_segment_ops.pt'))
-    if a.only_g1:
-        print('G1 done')
-        return
 
+
+def write_models(a):
     # ---- G2-G4: model-level goldens ---------------------------------------------------------------------
     set_order = list({'mesh_edges', 'world_edges'})      # iteration order under this PYTHONHASHSEED
     set_order_h = list({'inter_cluster', 'inter_cluster_world'})
@@ -164,7 +176,16 @@ def main():
         ('none_pna_L1_lat128', 'none', 'pna', 1, ['mesh_edges'], dict(nx=10, ny=10), 128, 'seeded'),
         ('hyper_pna_L1_lat128', 'hyper', 'pna', 1, hyper_sets, dict(nx=10, ny=10, clusters=5), 128, 'seeded'),
         ('none_sum_L15_lat128', 'none', 'sum', 15, ['mesh_edges'], dict(nx=10, ny=10), 128, 'seeded'),
+        # round 4: the remaining block types directly against reference-generated numbers at the width the HIP kernels are built
+        # for -- hetero in the structure of configs/plateCluster.yaml (mesh + world + up / down / inter sets, pna, L = 5),
+        # multiscale, repeated and multi
+        ('hetero_pna_L5_lat128', 'hetero', 'pna', 5, hyper_sets + ['world_edges'], dict(nx=10, ny=10, clusters=5, world=17), 128, 'seeded'),
+        ('multiscale_pna_L2_lat128', 'multiscale', 'pna', 2, hyper_sets, dict(nx=10, ny=10, clusters=5), 128, 'seeded'),
+        ('repeated_pna_L2_lat128', 'repeated', 'pna', 2, ['mesh_edges'], dict(nx=10, ny=10), 128, 'seeded'),
+        ('multi_sum_L2_lat128', 'multi', 'sum', 2, ['mesh_edges'], dict(nx=10, ny=10), 128, 'seeded'),
     ]
+    if a.only_cases:
+        cases = [c for c in cases if any(s_ in c[0] for s_ in a.only_cases.split(','))]
     for name, arch, agg, steps, sets, gkw, latent, wmode in cases:
         seed = hash_name(name) % 1000
         graph = synth.grid_graph(seed=seed, **gkw)
@@ -191,6 +212,9 @@ def main():
         torch.save(fx, os.path.join(a.out, f'mgn_{name}.pt'))
         print(name, 'loss', float(loss), 'out', tuple(out.shape), 'params', sum(v.numel() for v in sd.values()))
 
+
+
+def write_g6_g7(a):
     # ---- G6: MeshSimulator._get_batched index mapping ---------------------------------------------------
     g6 = {}
     for B in (1, 2, 3):
@@ -216,7 +240,6 @@ def main():
     torch.save({'xs': xs, 'ys': ys, 'y_eval': y_eval, 'inv': inv, 'acc_sum': nz._acc_sum.clone(),
                 'acc_sum_sq': nz._acc_sum_squared.clone(), 'acc_count': nz._acc_count.clone(),
                 'zs': zs, 'ws': ws}, os.path.join(a.out, 'g7_normalizer.pt'))
-    print('done')
 
 
 if __name__ == '__main__':
