@@ -109,7 +109,7 @@ def secondary_configs(args):
       * the plate configuration's EDGE-SET STRUCTURE on the flag grids (what round 2 reported as "plate config"): kept for
         continuity under a name that says what it is."""
     out = {}
-    base = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '2', '--no-cold', '--no-cpu-baseline', '--no-prof',
+    base = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '2', '--no-cold', '--no-cpu-baseline',
             '--no-secondary', '--batch', str(args.batch)]
     for name, extra in (('flag_simple_shape_pna_L15', ['--agg', 'pna']),
                         ('deforming_plate_shape_PlateModel_spectral_K31_hetero_pna_L5',
@@ -129,6 +129,13 @@ def secondary_configs(args):
                              'workload': d['config']['workload']}
                 if 'graph_build' in d['config']:
                     out[name]['graph_build'] = d['config']['graph_build']
+                if 'roofline' in d:            # the child's own dominant kernel (HIP events of its eager pass): bytes, time, fraction
+                    r_ = d['roofline']
+                    out[name]['roofline'] = {k_: r_.get(k_) for k_ in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                                                         'algorithmic_bytes_per_launch', 'rows_per_launch', 'ms_per_launch')}
+                    out[name]['roofline']['share_of_step'] = d.get('kernels', {}).get(r_.get('kernel'), {}).get('share_of_step')
+                if 'roofline_aggregation' in d:
+                    out[name]['roofline_aggregation'] = {k_: d['roofline_aggregation'].get(k_) for k_ in ('kernel', 'achieved', 'frac', 'ms_per_launch')}
             else:
                 out[name] = {'error': (r.stderr or '')[-300:]}
         except Exception as ex:                             # a secondary figure must never cost the headline line
@@ -497,11 +504,13 @@ def main():
         torch.cuda.synchronize()
         t_hit = (time.perf_counter() - t0) / n_cold * 1e3
         # (capturing a HIP graph empties the allocator's cache -- torch.cuda.graph.__enter__ --, so the first eager step after the
-        # capture above pays for ~45 GB of device mallocs: 0.1 s on some boxes, 2 s on others; one untimed step takes that out
-        # of a figure that is about the topology cache)
+        # capture above pays for ~45 GB of device mallocs: 0.1 s on some boxes, 2 s on others; that step is timed on its own
+        # (first_eager_step_after_capture_ms) and kept out of the figure that is about the topology cache)
         topo_mod.clear_cache()
+        t0 = time.perf_counter()
         trainer.step(fresh(), target, mask)
         torch.cuda.synchronize()
+        t_first_eager = (time.perf_counter() - t0) * 1e3
         ms0 = torch.cuda.memory_stats()
         t0 = time.perf_counter()
         for _ in range(3):
@@ -515,6 +524,9 @@ def main():
             ms1['segment.all.allocated'] - ms0['segment.all.allocated'], ms1['num_alloc_retries'] - ms0['num_alloc_retries']))
         cold = {'fresh_index_tensors_topology_found_by_content_ms': t_hit, 'captures': cache.captures,
                 'fresh_index_tensors_topology_rebuilt_eager_ms': t_miss,
+                # a real once-per-(mesh, batch size) cost of the reference's loop, reported instead of warmed away: capturing a HIP graph
+                # empties the caching allocator, so the first eager step behind a capture re-mallocs its working set from the driver
+                'first_eager_step_after_capture_ms': t_first_eager,
                 'note': 'per step, 128-graph batch; replayed step with warm tensors = ms_per_step above',
                 'topology_cache': dict(topo_mod.stats)}
         log(f'cold steps: content hit {t_hit:.2f} ms, rebuild {t_miss:.2f} ms')
@@ -625,6 +637,20 @@ def main():
                                                'products': 'fp32 MFMA' if fp32_only else
                                                'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate'},
                                'selection': 'largest accumulated time' + (' among forward kernels (side stream on)' if overlapped else '')}
+            # what the hardware counters of the same launch say (profiles/sq_counters.json: rocprofv3 --pmc SQ_* passes of
+            # tools/fusedbench.py on these kernel sources; dropped when the sources have changed since)
+            try:
+                sq = json.load(open(os.path.join(ROOT, 'profiles', 'sq_counters.json')))
+                ent = sq.get('kernels', {}).get(name)
+                if sq.get('kernel_source_sha') == sha and ent:
+                    res['roofline']['counters'] = dict(ent, source=f"profiles/sq_counters.json (commit {sq.get('commit')}, kernel sources {sha})")
+                    res['roofline']['limited_by'] = ('issue: neither roof binds -- ' + ent.get('summary', ''))
+                else:
+                    res['roofline']['counters'] = None
+                    res['roofline']['limited_by'] = (f"(profiles/sq_counters.json is for kernel sources {sq.get('kernel_source_sha')}, now {sha}: dropped as stale)")
+            except Exception as ex:
+                res['roofline']['counters'] = None
+                res['roofline']['limited_by'] = f'no SQ counter record ({type(ex).__name__})'
             if name in replaces:      # one launch doing the work of several: the bytes THOSE would move, over this kernel's time
                 rb = replaces[name][0] * rows + replaces[name][1]
                 res['roofline']['replaces_bytes_per_launch'] = rb
@@ -633,9 +659,16 @@ def main():
             # whole-step matrix utilisation: algorithmic flops of every MFMA launch of the step / step time
             step_flops = sum(v2['units'] / psteps * ({'wgrad': 1, 'wgrad_node': 1, 'linear_fwd': 2, 'linear_bwd': 2, 'edge_bwd_fused': 5}.get(n2, 3)) * 2 * 128 * 128
                              for n2, v2 in k.items() if n2.startswith(('mlp', 'wgrad', 'linear', 'edge_bwd')))
-            res['roofline_step'] = {'bound': 'mfma', 'achieved': step_flops / (ms_per_step * 1e-3) / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS,
-                                    'unit': 'TFLOP/s', 'frac': step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                    'note': 'lower bound: node MLPs with more than one 128-wide source do more than 3 products'}
+            step_tf = step_flops / (ms_per_step * 1e-3) / 1e12
+            res['roofline_step'] = {'bound': 'mfma', 'achieved': step_tf, 'peak': PEAK_F32_MFMA_TFLOPS,
+                                    'unit': 'TFLOP/s', 'frac': step_tf / PEAK_F32_MFMA_TFLOPS,
+                                    # the pipe these products really run on: six bf16 MFMAs per fp32-accurate product, so the hardware
+                                    # roof for fp32-equivalent work is the bf16 peak / 6 (417 TFLOP/s) -- `frac` above prices bf16-pipe
+                                    # work against the fp32-MFMA peak and is NOT a hardware fraction
+                                    'bf16x6_roof_TFLOPs': None if fp32_only else PEAK_BF16_MFMA_TFLOPS / 6,
+                                    'frac_of_bf16x6_roof': None if fp32_only else step_tf / (PEAK_BF16_MFMA_TFLOPS / 6),
+                                    'note': 'fp32-equivalent flops (one per fp32 product term, not per bf16 MFMA); lower bound: node MLPs with '
+                                            'more than one 128-wide source do more than 3 products'}
             # the scatter-add (segment-sum) kernel vs HBM.  With `sum` aggregation the forward aggregate is formed inside the
             # edge kernel, so the stand-alone launches left in the step are the sender sums of dz1 in the backward (same
             # kernel, rows gathered through the sender permutation); with pna the forward aggregation launch is reported.
@@ -648,9 +681,21 @@ def main():
                 bytes_launch = 4 * 128 * E_rank + 4 * (N_nodes + 1) + 4 * 128 * N_nodes * n_out + (0 if which == 'forward aggregation' else 4 * E_rank)
                 t = s['ms'] / s['count'] * 1e-3
                 ach = bytes_launch / t / 1e9
+                agg_traffic, agg_note = None, None
+                try:        # PMC bytes of that launch, same stamped record as the dominant kernel's
+                    pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+                    ent = pm.get('seg_fwd_agg' if which == 'forward aggregation' else 'seg_fwd')
+                    if pm.get('kernel_source_sha') != sha:
+                        agg_note = f"profiles/pmc_traffic.json is for kernel sources {pm.get('kernel_source_sha')}, now {sha}: dropped as stale"
+                    elif ent and int(ent.get('rows_per_launch', -1)) in (int(N_nodes), int(E_rank)):
+                        agg_traffic = ent['traffic_bytes_per_launch']
+                        agg_note = f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE at commit {pm.get('commit')}: profiles/pmc_traffic.json"
+                except Exception as ex:
+                    agg_note = f'no PMC record ({type(ex).__name__})'
                 res['roofline_aggregation'] = {'kernel': f'seg_fwd128 ({which})', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
-                                               'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
-                                               'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3}
+                                               'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': agg_traffic, 'traffic_source': agg_note,
+                                               'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3,
+                                               'north_star_target': 'at least 0.40 of the HBM roofline on the scatter-add aggregation'}
         if collective is not None:
             res['collective'] = collective
         if 'graph_build' in wk:

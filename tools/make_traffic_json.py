@@ -30,6 +30,8 @@ for bench_name, kern in (('mlp_fwd_edge', 'mlp6_fwd_kernel'), ('mlp_bwd_edge', '
     if bench_name == 'mlp_bwd_edge' and fused_present:
         continue                                              # only the encoder's backward is left on that kernel at the edge grid
     keys = [k for k in fetch if kern in k[0]]
+    if bench_name == 'mlp_fwd_edge' and any('mlp6_fwd_edge_kernel' in k[0] for k in fetch):
+        keys = [k for k in fetch if 'mlp6_fwd_edge_kernel' in k[0]]          # the training edge block's own kernel (round 4)
     if not keys:
         continue
     k = max(keys, key=lambda kk: (fetch[kk][1], kk[1]))       # the processor's edge launches: the most frequent (kernel, grid), then the largest
