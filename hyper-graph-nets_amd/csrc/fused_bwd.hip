@@ -463,7 +463,16 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     // ================================= data-gradient chain =================================
     const hgn_dx_t d = a.dx[0];
     const bool has_dout = a.d_out != nullptr, has_agg = a.agg_dout != nullptr;
-    Act g, t, gout, ga;
+    // Four row tiles of registers and when each is free (a load can only land where nothing lives):
+    //   xh   : x-hat of the tile.  Consumed by the LayerNorm backward at the tile's start, so the NEXT tile's rows are fetched right
+    //          behind it -- eleven phases (~ 14 us) ahead of their use.
+    //   dout : d(e') rows of the tile, added into `geff` at the tile's start: the next tile's rows are fetched in phase 1.
+    //   geff : the receiver's d(agg) row on arrival, then d_out_eff = d(e') + d(agg) -- alive until phase 8, where it starts the last
+    //          layer's accumulators (the skip connection); the next tile's d(agg) rows (cache resident) are gathered in phase 9.
+    //   g    : the gradient on its way down the chain (LayerNorm backward -> dz3 -> dz2 -> dz1 -> de), products accumulating in place.
+    // The first version of this schedule fetched x-hat in phase 8, d(e') in 9 and the rest in 10: the youngest of them was two phases
+    // (~ 3 us) old when the next tile needed it, and the ablation without these loads ran 0.27 ms faster.
+    Act g, xh, dout, geff;
     unsigned pf_m1 = 0, pf_m2 = 0;
     float pf_rstd = 0.f;
     int seg_next = 0;
@@ -471,26 +480,40 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     int n = lane & 15, kq = lane >> 4;
     float lnacc_g[2] = {0.f, 0.f}, lnacc_b[2] = {0.f, 0.f};      // LayerNorm-affine gradient partials of the lane's 2 + 2 features, over all tiles
     const unsigned ld_dout4 = (unsigned)a.ld_dout * 4u;
-    // rows of tile `tile`: x-hat -> g, d(e') -> gout, the receiver's d(agg) row -> ga, sign words, 1 / sigma
-    auto prefetch = [&](long tile, int seg) {
-      const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
-      const unsigned rc = (unsigned)(row < M ? row : M - 1);
-      t_load32(g, a.xhat, rc * (LAT * 4u) + 16u * kq);
-      if (has_dout) t_load32(gout, a.d_out, rc * ld_dout4 + 16u * kq);
-      if (has_agg) {                                  // `sum` aggregation backward: the receiver's row (cache-resident gather; 64-bit offset)
-        const char* ar = reinterpret_cast<const char*>(a.agg_dout) + ((long)seg * a.ld_agg * 4 + 16 * kq);
-        HGN_FOR_B(fb) ga.v[fb] = *reinterpret_cast<const f32x4*>(ar + 64 * fb);
-      }
-      const unsigned* bits = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.relu_bits) + (rc * 32u + 4u * kq));
+    auto row_of = [&](long tile, int n_) -> unsigned {
+      const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n_;
+      return (unsigned)(row < M ? row : M - 1);
+    };
+    auto fetch_xhat = [&](long tile, int n_, int kq_) {
+      if (!(HGN_FEXP & 8)) t_load32(xh, a.xhat, row_of(tile, n_) * (LAT * 4u) + 16u * kq_);
+    };
+    auto fetch_dout = [&](long tile, int n_, int kq_) {
+      if (has_dout && !(HGN_FEXP & 8)) t_load32(dout, a.d_out, row_of(tile, n_) * ld_dout4 + 16u * kq_);
+    };
+    auto fetch_small = [&](long tile, int n_, int kq_) {         // sign words, 1 / sigma
+      const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n_;
+      const unsigned rc = row_of(tile, n_);
+      const unsigned* bits = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.relu_bits) + (rc * 32u + 4u * kq_));
       pf_m1 = bits[0];
       pf_m2 = bits[4];
       pf_rstd = row < M ? a.rstd[rc] : 0.f;           // rows past the end contribute nothing to any gradient
+    };
+    auto fetch_agg = [&](int seg, int kq_) {          // `sum` aggregation backward: the receiver's row (cache-resident gather; 64-bit offset)
+      if (has_agg && !(HGN_FEXP & 8)) {
+        const char* ar = reinterpret_cast<const char*>(a.agg_dout) + ((long)seg * a.ld_agg * 4 + 16 * kq_);
+        HGN_FOR_B(fb) geff.v[fb] = *reinterpret_cast<const f32x4*>(ar + 64 * fb);
+      }
     };
     auto seg_of = [&](long tile) -> int {
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       return has_agg ? a.agg_seg[row < M ? row : M - 1] : 0;
     };
-    prefetch(t_beg, seg_of(t_beg));
+    if (!has_dout) t_zero(dout);
+    if (!has_agg) t_zero(geff);
+    fetch_xhat(t_beg, n, kq);
+    fetch_dout(t_beg, n, kq);
+    fetch_agg(seg_of(t_beg), kq);
+    fetch_small(t_beg, n, kq);
     bar_lds();                                        // (S) LayerNorm weights in LDS; pairs with the wgrad waves' first barrier
     for (long tile = t_beg; tile < t_end; ++tile) {
       // everything per-lane is re-derived from an opaque lane id inside the loop: otherwise the compiler hoists two dozen loop-
@@ -500,41 +523,39 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       const bool valid = row < M;
       FSTAMP(0, 0);
-      seg_next = seg_of(tile + 1);                    // consumed by the prefetch in layer 1
+      seg_next = seg_of(tile + 1);                    // consumed by the gather in phase 9
       const unsigned mb1 = pf_m1, mb2 = pf_m2;
       // ---- LayerNorm backward -> dz3 (g) ------------------------------------------------------------------------------------
       {
-        const Act& xh = g;                            // x-hat of this tile (prefetched); dz3 replaces it element by element below
-        Act& gg = t;                                  // d_out_eff * gamma (t is free until layer 1)
-        if (!has_dout) t_zero(gout);
-        if (has_agg) HGN_FOR_B(fb) gout.v[fb] += ga.v[fb];
+        HGN_FOR_B(fb) geff.v[fb] += dout.v[fb];       // d_out_eff (either part may be zeros); `dout` is free from here
         // LayerNorm-affine gradient partials of this wave's 16 rows: column sums of d_out_eff * x-hat and of d_out_eff by the
         // transposing butterfly (hgn_device.h: 90 instructions per array; the row16_sum form was ~640 for the two, a third of this
         // role's vector instructions), accumulated in registers over the tiles -- no LDS, no exec-masked stores.
         if (tile + 1 == t_end && (M & (TILE_ROWS - 1)) != 0)      // rows past the end (the launch's last tile only; uniform)
-          HGN_FOR_B(fb) gout.v[fb] = valid ? gout.v[fb] : f32x4{0.f, 0.f, 0.f, 0.f};
+          HGN_FOR_B(fb) geff.v[fb] = valid ? geff.v[fb] : f32x4{0.f, 0.f, 0.f, 0.f};
         {
-          HGN_FOR_B(fb) gg.v[fb] = gout.v[fb] * xh.v[fb];
+          HGN_FOR_B(fb) g.v[fb] = geff.v[fb] * xh.v[fb];
           float sg[2], sb[2];
-          row16_sums_transposed(gg, sg);
-          row16_sums_transposed(gout, sb);
+          row16_sums_transposed(g, sg);
+          row16_sums_transposed(geff, sb);
           lnacc_g[0] += sg[0]; lnacc_g[1] += sg[1];
           lnacc_b[0] += sb[0]; lnacc_b[1] += sb[1];
         }
-        HGN_FOR_B(fb) gg.v[fb] = gout.v[fb] * *reinterpret_cast<const f32x4*>(lng + 16 * fb + 4 * kq);
-        const float m1 = row_sum(gg) * (1.f / LAT);
+        HGN_FOR_B(fb) g.v[fb] = geff.v[fb] * *reinterpret_cast<const f32x4*>(lng + 16 * fb + 4 * kq);
+        const float m1 = row_sum(g) * (1.f / LAT);
         float q0 = 0.f, q1 = 0.f;
         HGN_FOR_B(fb) {
-          q0 += gg.v[fb][0] * xh.v[fb][0] + gg.v[fb][1] * xh.v[fb][1];
-          q1 += gg.v[fb][2] * xh.v[fb][2] + gg.v[fb][3] * xh.v[fb][3];
+          q0 += g.v[fb][0] * xh.v[fb][0] + g.v[fb][1] * xh.v[fb][1];
+          q1 += g.v[fb][2] * xh.v[fb][2] + g.v[fb][3] * xh.v[fb][3];
         }
         float qs = q0 + q1;
         qs += __shfl_xor(qs, 16);
         qs += __shfl_xor(qs, 32);
         const float m2 = qs * (1.f / LAT);
         const float r = pf_rstd;
-        HGN_FOR_B(fb) g.v[fb] = r * (gg.v[fb] - m1 - g.v[fb] * m2);
+        HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - xh.v[fb] * m2);
       }
+      fetch_xhat(tile + 1, n, kq);                    // x-hat of the NEXT tile: its registers are free for the rest of this one
       FSTAMP(0, 1);
       // ---- layers 3 and 2: ONE copy of the code (a run-time loop: fully unrolled the kernel is 63 KB of instructions; the
       // counters show no instruction-cache misses either way, the loop is kept for build time and register pressure).
@@ -553,6 +574,9 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
         FSTAMP(0, 3 + 8 * li);
         if (wave >= 2) write_gops<NP>(smem, gw, xs);            // rows 32-63: free now (the previous layer's second block is done)
         sweep_piece<0, NP, 1>(g, xs, ring);
+        // (one array per phase: one burst of all of them holds up every other memory instruction of the CU -- the ring's DMA among
+        // them -- for thousands of cycles)
+        if (li == 0) fetch_dout(tile + 1, (int)opaque((unsigned)n), kq);       // phase 1: d(e') of the next tile
         ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 2 : 1) * PIECE_BYTES));
         FSTAMP(0, 4 + 8 * li); bar_lds(); FSTAMP(0, 5 + 8 * li);
         sweep_piece<1, NP>(g, xs, ring);                        // ---- phase 4 li + 1
@@ -563,49 +587,28 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
         FSTAMP(0, 8 + 8 * li); bar_lds(); FSTAMP(0, 9 + 8 * li);
         sweep_piece<3, NP>(g, xs, ring);                        // ---- phase 4 li + 3
         relu_mask_bits(g, li == 0 ? mb2 : mb1);                 // dz2 / dz1
+        if (li == 0) fetch_small(tile + 1, (int)opaque((unsigned)n), kq);      // (mb1 / mb2 hold this tile's words; pf_* the next tile's)
       }
-      // ---- layer 1: de = d_out_eff + dz1 W1e; the next tile's rows start their way, one array per phase (one burst of all of
-      // them holds up every other memory instruction of the CU -- the ring's DMA among them -- for thousands of cycles) -------------
+      // ---- layer 1: de = d_out_eff + dz1 W1e, accumulated in g from `geff` (the first product's C operand) -----------------
       // (dz1: whole 64-row tiles are stored; rows past M land in the padding the caller provides)
 #if HGN_FEXP & 256
       t_store32c(g, a.dz1, ((unsigned)(row - n) + (lane_i >> 5)) * (LAT * 4u) + 16u * (lane_i & 31));
 #else
       if (!(HGN_FEXP & 4)) t_store32(g, a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
 #endif
-      split3(g, xs);                                            // (t starts from gout, the skip connection: sweep_piece START = 2)
-      const long nrow = (tile + 1) * TILE_ROWS + wave * WAVE_ROWS + n;
-      const unsigned nrc = (unsigned)(nrow < M ? nrow : M - 1);
+      split3(g, xs);
       const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16));
-#if HGN_FEXP & 16
-      const unsigned nrcc = (unsigned)(nrow - n + 16 <= M ? nrow - n : 0) + (lane_i >> 5);
-      t_load32c(g, a.xhat, nrcc * (LAT * 4u) + 16u * (lane_i & 31));
-#else
-      if (!(HGN_FEXP & 8)) t_load32(g, a.xhat, nrc * (LAT * 4u) + 16u * kq);
-#endif
-      FSTAMP(0, 18); bar_lds(); FSTAMP(0, 19); sweep_piece<0, NP, 2>(t, xs, ring + 2 * PIECE_BYTES, &gout);                // ---- phase 8
-#if HGN_FEXP & 16
-      if (has_dout) t_load32c(gout, a.d_out, nrcc * ld_dout4 + 16u * (lane_i & 31));
-#else
-      if (has_dout && !(HGN_FEXP & 8)) t_load32(gout, a.d_out, nrc * ld_dout4 + 16u * kq);
-#endif
-      FSTAMP(0, 20); bar_lds(); FSTAMP(0, 21); sweep_piece<1, NP>(t, xs, ring + 0 * PIECE_BYTES);                // ---- phase 9
-      if (has_agg && !(HGN_FEXP & 8)) {               // `sum` aggregation backward: the receiver's row (cache-resident gather; 64-bit offset)
-        const char* ar = reinterpret_cast<const char*>(a.agg_dout) + ((long)seg_next * a.ld_agg * 4 + 16 * kq);
-        HGN_FOR_B(fb) ga.v[fb] = *reinterpret_cast<const f32x4*>(ar + 64 * fb);
-      }
-      {
-        const unsigned* bits = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.relu_bits) + (nrc * 32u + 4u * kq));
-        pf_m1 = bits[0];
-        pf_m2 = bits[4];
-        pf_rstd = nrow < M ? a.rstd[nrc] : 0.f;       // rows past the end contribute nothing to any gradient
-      }
-      FSTAMP(0, 22); bar_lds(); FSTAMP(0, 23); sweep_piece<2, NP>(t, xs, ring + 1 * PIECE_BYTES);                // ---- phase 10
-      FSTAMP(0, 24); bar_lds(); FSTAMP(0, 25); sweep_piece<3, NP>(t, xs, ring + 2 * PIECE_BYTES);                // ---- phase 11
+      FSTAMP(0, 18); bar_lds(); FSTAMP(0, 19); sweep_piece<0, NP, 2>(g, xs, ring + 2 * PIECE_BYTES, &geff);                // ---- phase 8
+      FSTAMP(0, 20); bar_lds(); FSTAMP(0, 21);
+      if (has_agg) fetch_agg(seg_next, kq); else t_zero(geff);      // phase 9: `geff` has started the accumulators; the next tile's d(agg) rows
+      sweep_piece<1, NP>(g, xs, ring + 0 * PIECE_BYTES);                // ---- phase 9
+      FSTAMP(0, 22); bar_lds(); FSTAMP(0, 23); sweep_piece<2, NP>(g, xs, ring + 1 * PIECE_BYTES);                // ---- phase 10
+      FSTAMP(0, 24); bar_lds(); FSTAMP(0, 25); sweep_piece<3, NP>(g, xs, ring + 2 * PIECE_BYTES);                // ---- phase 11
       FSTAMP(0, 26);
 #if HGN_FEXP & 256
-      t_store32c(t, d.dx, ((unsigned)(row - n) + (lane_i >> 5)) * ((unsigned)d.ld * 4u) + 16u * (lane_i & 31));
+      t_store32c(g, d.dx, ((unsigned)(row - n) + (lane_i >> 5)) * ((unsigned)d.ld * 4u) + 16u * (lane_i & 31));
 #else
-      if (valid && !(HGN_FEXP & 4)) t_store32(t, d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
+      if (valid && !(HGN_FEXP & 4)) t_store32(g, d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
 #endif
     }
     {                                                 // lane (n, kq) holds features 16 (n >> 1) + 4 kq + 2 (n & 1) + {0, 1} (row16_sums_transposed)
