@@ -651,8 +651,7 @@ extern "C" int hgn_edge_bwd_fused_workspace_bytes(int64_t M, size_t* bytes) {
 }
 
 extern "C" int hgn_edge_bwd_fused_eligible(const hgn_mlp_bwd_t* a) {
-  static const bool off = getenv("HGN_NO_FUSED_BWD") != nullptr || getenv("HGN_FP32_MFMA") != nullptr;
-  if (off || !a || !hgn_mlp_bwd6_eligible(a)) return 0;
+  if (!a || !hgn_mlp_bwd6_eligible(a)) return 0;          // (includes the HGN_F_FP32_MFMA flag of the call)
   if (a->n_dx != 1 || !a->dx[0].residual || a->dx[0].K != 128 || a->seg_dz1 || !a->dz1) return 0;
   if (a->agg_dout && (a->n_agg_ops != 1 || a->agg_ops[0] != HGN_OP_SUM)) return 0;      // several aggregates (pna): the two-launch path
   const int64_t ldmax = a->ld_dout > a->dx[0].ld ? a->ld_dout : a->dx[0].ld;
@@ -691,7 +690,7 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   fa.slabs = (float*)workspace;
   fa.tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(14, (double)a->M, stream);
-  if (bwd_products() == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  if (bwd_products(a->products) == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
   else hipLaunchKernelGGL((edge_bwd_fused_kernel<6>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
   if (hgn_check_launch("hgn_edge_bwd_fused") != HGN_OK) return HGN_E_LAUNCH;
   // fixed-order sums of the per-workgroup partials: two weight gradients + biases, and the LayerNorm-affine gradients

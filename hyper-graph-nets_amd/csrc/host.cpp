@@ -1,6 +1,7 @@
 // Error reporting, version, and the optional HIP-event profiler of libhgn_mp.so.
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "hgn_host.h"
@@ -9,9 +10,11 @@ namespace hgn {
 
 static thread_local char g_err[512] = "";
 thread_local int g_prof_tag = 0;
-static int g_products = 6;
-int matmul_products() { return g_products; }
-int bwd_products() { return g_products == 6 ? 6 : 1; }
+// the DEFAULT for calls that leave `products` at 0: one word, written by hgn_set_matmul_products only (relaxed atomic)
+static std::atomic<int> g_products{6};
+int matmul_products(int per_call) { return per_call ? per_call : g_products.load(std::memory_order_relaxed); }
+int bwd_products(int per_call) { return matmul_products(per_call) == 6 ? 6 : 1; }
+bool valid_products(int p) { return p == 0 || p == 1 || p == 2 || p == 6; }
 
 int hgn_fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -67,10 +70,10 @@ extern "C" int hgn_prof_enable(int on) {
 extern "C" int hgn_set_matmul_products(int n) {
   if (n != 1 && n != 2 && n != 6)
     return hgn_fail(HGN_E_INVALID, "hgn_set_matmul_products: 6 (fp32-accurate), 1 (single bf16 product) or 2 (single fp16 product in the forward)");
-  g_products = n;
+  g_products.store(n, std::memory_order_relaxed);
   return HGN_OK;
 }
-extern "C" int hgn_get_matmul_products(void) { return g_products; }
+extern "C" int hgn_get_matmul_products(void) { return g_products.load(std::memory_order_relaxed); }
 extern "C" int hgn_prof_tag(int tag) { g_prof_tag = tag; return HGN_OK; }
 extern "C" int hgn_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);

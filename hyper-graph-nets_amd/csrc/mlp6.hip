@@ -791,7 +791,7 @@ extern "C" int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* a) {
     if (!s.Wpk || s.K < 1) return 0;
   }
   if ((a->ld_out & 3) || !aligned16(a->out) || (a->res && ((a->ld_res & 3) || !aligned16(a->res)))) return 0;
-  return getenv("HGN_FP32_MFMA") ? 0 : 1;
+  return (a->flags & HGN_F_FP32_MFMA) ? 0 : 1;
 }
 
 namespace hgn {
@@ -832,7 +832,7 @@ bool cs_eligible(const hgn_mlp_fwd_t* a) {
 
 // the arguments of a training edge block as mlp6_fwd_edge_kernel assumes them (everything else: the general kernel)
 static bool edge_block_shape(const hgn_mlp_fwd_t* a) {
-  if (getenv("HGN_NO_EDGE_FWD") || a->n_src != 1 || a->n_add != 2 || a->n_post != 0) return false;
+  if ((a->flags & HGN_F_GENERAL_FWD) || a->n_src != 1 || a->n_add != 2 || a->n_post != 0) return false;
   const hgn_src_t& s = a->src[0];
   if (s.K != 128 || s.idx || s.ld != 128 || !aligned16(s.x)) return false;
   if (!a->z1 || !a->z2 || !a->xhat || !a->rstd || !a->relu_bits || !a->ln_g || !a->ln_b || !a->res) return false;
@@ -844,11 +844,12 @@ static bool edge_block_shape(const hgn_mlp_fwd_t* a) {
 }
 
 int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
+  const int np_ = matmul_products(a->products);
 #if HGN_LAB
   if (g_big_tiles && !tile128() && a->M >= big_min_rows()) {
     const long tiles = (a->M + 191) / 192;
-    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
-    else if (matmul_products() == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
+    if (np_ == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
+    else if (np_ == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 12>), dim3((unsigned)tiles), dim3(768), 0, (hipStream_t)stream, *a);
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
   }
@@ -856,8 +857,8 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   if (cs_eligible(a)) {
     const long wgs = (a->M + 15) / 16;               // inference on at most 16 rows per CU: the column-split latency form
     constexpr int T = 64 * (4 + CS_LOADERS);
-    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
-    else if (matmul_products() == 2) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<2>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+    if (np_ == 1) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+    else if (np_ == 2) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<2>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_cs_kernel<6>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, column-split latency form)");
   }
@@ -865,23 +866,23 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
 #if HGN_LAB
     static const int nl = getenv("HGN_LAT_LOADERS") ? atoi(getenv("HGN_LAT_LOADERS")) : LAT_LOADERS;
-    if (matmul_products() == 6 && nl == 1) { hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 5>), dim3((unsigned)tiles), dim3(320), 0, (hipStream_t)stream, *a); return hgn_check_launch("hgn_mlp_fwd (latency form, 1 loader)"); }
-    if (matmul_products() == 6 && nl == 4) { hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 8>), dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *a); return hgn_check_launch("hgn_mlp_fwd (latency form, 4 loaders)"); }
+    if (np_ == 6 && nl == 1) { hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 5>), dim3((unsigned)tiles), dim3(320), 0, (hipStream_t)stream, *a); return hgn_check_launch("hgn_mlp_fwd (latency form, 1 loader)"); }
+    if (np_ == 6 && nl == 4) { hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 8>), dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *a); return hgn_check_launch("hgn_mlp_fwd (latency form, 4 loaders)"); }
 #endif
     constexpr int T = 64 * (4 + LAT_LOADERS);
-    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
-    else if (matmul_products() == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+    if (np_ == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+    else if (np_ == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, latency form)");
   }
-  if ((tile128() || (tile128_fwd() && a->M >= big_min_rows())) && matmul_products() == 6 && a->M > TILE_ROWS) {
+  if ((tile128() || (tile128_fwd() && a->M >= big_min_rows())) && np_ == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
     if (edge_block_shape(a)) hipLaunchKernelGGL((mlp6_fwd_edge_kernel<6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   } else {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
-    if (matmul_products() == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
-    else if (matmul_products() == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    if (np_ == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else if (np_ == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6>), dim3((unsigned)tiles), dim3(WG), lds_pad(), (hipStream_t)stream, *a);
   }
   return hgn_check_launch("hgn_mlp_fwd (split-bf16)");
@@ -970,13 +971,15 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_fwd_cs_kerne
 }  // namespace hgn
 
 extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
-                                int64_t ld_out, float* zero_rows, int64_t ld_zero, void* stream);
+                                int64_t ld_out, float* zero_rows, int64_t ld_zero, int products, void* stream);
 extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
-                               int64_t ld_out, void* stream) {
-  return hgn_linear_fwd6z(x, ldx, M, pk_blocks, nb, out, ld_out, nullptr, 0, stream);
+                               int64_t ld_out, int products, void* stream) {
+  return hgn_linear_fwd6z(x, ldx, M, pk_blocks, nb, out, ld_out, nullptr, 0, products, stream);
 }
 extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
-                                int64_t ld_out, float* zero_rows, int64_t ld_zero, void* stream) {
+                                int64_t ld_out, float* zero_rows, int64_t ld_zero, int products, void* stream) {
+  if (!valid_products(products)) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: products must be 0 (default), 6, 1 or 2");
+  const int np_ = matmul_products(products);
   if (M == 0) return HGN_OK;
   if (!x || !pk_blocks || !out || M < 0 || nb < 1 || nb > 4 || (ldx & 3) || (ld_out & 3) || !aligned16(x) || !aligned16(out) ||
       (zero_rows && ((ld_zero & 3) || ld_zero < 128 || !aligned16(zero_rows))))
@@ -991,20 +994,20 @@ extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const vo
   if (M <= 16 * hgn::lat_max_tiles() && hgn::cs_enabled()) {
     constexpr int T = 64 * (4 + hgn::CS_LOADERS);
     const long wgs = (M + 15) / 16;
-    if (matmul_products() == 1) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
-    else if (matmul_products() == 2) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<2>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    if (np_ == 1) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    else if (np_ == 2) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<2>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<6>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
     return hgn_check_launch("hgn_linear_fwd6 (column-split latency form)");
   }
   if (tiles <= hgn::lat_max_tiles()) {
     constexpr int T = 64 * (4 + hgn::LAT_LOADERS);
-    if (matmul_products() == 1) hipLaunchKernelGGL((linear6_fwd_kernel<1, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
-    else if (matmul_products() == 2) hipLaunchKernelGGL((linear6_fwd_kernel<2, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    if (np_ == 1) hipLaunchKernelGGL((linear6_fwd_kernel<1, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    else if (np_ == 2) hipLaunchKernelGGL((linear6_fwd_kernel<2, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((linear6_fwd_kernel<6, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
     return hgn_check_launch("hgn_linear_fwd6 (latency form)");
   }
-  if (matmul_products() == 1) hipLaunchKernelGGL(linear6_fwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
-  else if (matmul_products() == 2) hipLaunchKernelGGL(linear6_fwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  if (np_ == 1) hipLaunchKernelGGL(linear6_fwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  else if (np_ == 2) hipLaunchKernelGGL(linear6_fwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear6_fwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_fwd6");
 }
@@ -1016,13 +1019,14 @@ extern "C" int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* a) {
     if (!d.Wpk_t || (d.K & 127) || (d.ld & 3) || !aligned16(d.dx)) return 0;
   }
   if (a->d_out && ((a->ld_dout & 3) || !aligned16(a->d_out))) return 0;
-  return getenv("HGN_FP32_MFMA") ? 0 : 1;
+  return (a->flags & HGN_F_FP32_MFMA) ? 0 : 1;
 }
 
 namespace hgn {
 // *n_slabs = number of 256-float LayerNorm-gradient partials written to a->ln_ws (one per workgroup)
 int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
-  if (tile128() && bwd_products() == 6 && a->M > TILE_ROWS) {
+  const int nb_ = bwd_products(a->products);
+  if (tile128() && nb_ == 6 && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
     hipLaunchKernelGGL((mlp6_bwd_kernel<2, 6, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     *n_slabs = tiles;
@@ -1031,7 +1035,7 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
     bool park = false;                      // several aggregation ops feeding a residual source gradient (pna edge blocks)
     if (a->agg_dout && a->n_agg_ops > 1)
       for (int i = 0; i < a->n_dx; ++i) park = park || a->dx[i].residual;
-    if (bwd_products() == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    if (nb_ == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else if (park) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, true>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, false>), dim3((unsigned)tiles), dim3(WG), lds_pad(), (hipStream_t)stream, *a);
     *n_slabs = tiles;
@@ -1041,7 +1045,9 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
 }  // namespace hgn
 
 extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* pk_blocks, int nb, float* dx,
-                               int64_t ld_dx, void* stream) {
+                               int64_t ld_dx, int products, void* stream) {
+  if (!valid_products(products)) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: products must be 0 (default), 6, 1 or 2");
+  const int nb_ = bwd_products(products);
   if (M == 0) return HGN_OK;
   if (!g || !pk_blocks || !dx || M < 0 || nb < 1 || nb > 4 || (ldg & 3) || (ld_dx & 3) || !aligned16(g) || !aligned16(dx))
     return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: bad argument");
@@ -1052,7 +1058,7 @@ extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const voi
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(8, (double)M, (hipStream_t)stream);
-  if (bwd_products() == 1) hipLaunchKernelGGL(linear6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  if (nb_ == 1) hipLaunchKernelGGL(linear6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear6_bwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_bwd6");
 }

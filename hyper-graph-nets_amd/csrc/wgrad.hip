@@ -592,6 +592,9 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   for (int i = 0; i < n_tasks; ++i) if (tasks[i].type == 1) order[nd + ng + n1++] = i;
   const int n0 = nd + ng;
   if (n0 + n1 != n_tasks) return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad task type");
+  for (int i = 0; i < n_tasks; ++i)
+    if (!valid_products(tasks[i].products) || tasks[i].products != tasks[0].products || tasks[i].flags != tasks[0].flags)
+      return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: products (0, 6, 1 or 2) and flags must agree over the tasks of one launch");
   const int nch0 = chunks_mfma(M, n0), nch1 = chunks_ln(M);
   WArgs wa; RArgs ra;
   wa.M = M;
@@ -614,7 +617,7 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   };
   ProfScope ps(g_prof_tag == 1 ? 11 : 4, (double)M * n0, (hipStream_t)stream);
   if (nd) {
-    static const bool fp32_only = getenv("HGN_FP32_MFMA") != nullptr;
+    const bool fp32_only = (tasks[0].flags & HGN_F_FP32_MFMA) != 0;
     wa.n_chunks = nch0; wa.task0 = 0;
     if (fp32_only) {
       wa.rows_per_chunk = rows_per(nch0, DT);
@@ -626,7 +629,7 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
       if (resplit) hipLaunchKernelGGL(wgrad6_kernel, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
       else
 #endif
-      if (bwd_products() == 1) hipLaunchKernelGGL(wgrad6s_kernel<1>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+      if (bwd_products(tasks[0].products) == 1) hipLaunchKernelGGL(wgrad6s_kernel<1>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
       else hipLaunchKernelGGL(wgrad6s_kernel<6>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
     }
   }

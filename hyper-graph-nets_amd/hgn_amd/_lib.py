@@ -17,6 +17,7 @@ PACK_BLOCK_BYTES = 98304
 HGN_MAX_PACK = 32
 NUM_KERNEL_IDS = 15
 OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
+F_FP32_MFMA, F_GENERAL_FWD = 1, 2          # hgn_mlp_fwd_t.flags / hgn_mlp_bwd_t.flags / hgn_wtask_t.flags
 KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
                 'linear_bwd', 'adam', 'csr', 'wgrad_node', 'seg_fwd_agg', 'features', 'edge_bwd_fused']
 
@@ -40,7 +41,7 @@ class MlpFwd(C.Structure):
                 ('z2', c_f32p), ('xhat', c_f32p), ('rstd', c_f32p), ('W2pk', C.c_void_p), ('W3pk', C.c_void_p),
                 ('relu_bits', C.c_void_p), ('seg_out', c_f32p), ('ld_seg_out', C.c_int64), ('seg_ids', c_i32p),
                 ('post_pk', C.c_void_p * 4), ('n_post', C.c_int32), ('post_out', c_f32p), ('ld_post', C.c_int64),
-                ('post_zero', c_f32p), ('ld_post_zero', C.c_int64)]
+                ('post_zero', c_f32p), ('ld_post_zero', C.c_int64), ('products', C.c_int32), ('flags', C.c_int32)]
 
 
 class Dx(C.Structure):
@@ -57,13 +58,13 @@ class MlpBwd(C.Structure):
                 ('agg_seg', c_i32p), ('agg_rowptr', c_i32p), ('agg_argmax', c_i32p), ('agg_argmin', c_i32p),
                 ('d_gamma', c_f32p), ('d_beta', c_f32p), ('ln_ws', c_f32p), ('ln_accumulate', C.c_int32),
                 ('W3pk_t', C.c_void_p), ('W2pk_t', C.c_void_p), ('relu_bits', C.c_void_p),
-                ('seg_dz1', c_f32p), ('ld_seg_dz1', C.c_int64), ('seg_ids', c_i32p)]
+                ('seg_dz1', c_f32p), ('ld_seg_dz1', C.c_int64), ('seg_ids', c_i32p), ('products', C.c_int32), ('flags', C.c_int32)]
 
 
 class WTask(C.Structure):
     _fields_ = [('type', C.c_int32), ('A', c_f32p), ('lda', C.c_int64), ('K', C.c_int32), ('idxA', c_i32p),
                 ('G', c_f32p), ('ldg', C.c_int64), ('n_out', C.c_int32), ('dW', c_f32p), ('ldw', C.c_int64),
-                ('db', c_f32p), ('accumulate', C.c_int32)]
+                ('db', c_f32p), ('accumulate', C.c_int32), ('products', C.c_int32), ('flags', C.c_int32)]
 
 
 class WFuse(C.Structure):
@@ -101,12 +102,12 @@ _SIGS = {
     'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
     'hgn_mlp_fwd_post_eligible': (C.c_int, [C.POINTER(MlpFwd)]),
     'hgn_linear_fwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
-                                  C.c_void_p]),
+                                  C.c_int, C.c_void_p]),
     'hgn_linear_fwd6z': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
-                                   C.c_void_p, C.c_int64, C.c_void_p]),
+                                   C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'hgn_mlp_bwd6_eligible': (C.c_int, [C.POINTER(MlpBwd)]),
     'hgn_linear_bwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
-                                  C.c_void_p]),
+                                  C.c_int, C.c_void_p]),
     'hgn_mlp_bwd_ln_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     'hgn_mlp_bwd': (C.c_int, [C.POINTER(MlpBwd), C.c_void_p]),
     'hgn_edge_bwd_fused_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),

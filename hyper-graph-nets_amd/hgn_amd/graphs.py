@@ -48,32 +48,33 @@ class GraphedForward:
 
     def _capture(self):
         model = self.model
+        ctx = self.ctx = getattr(model, '_hgn_ctx', None) or ops.default_context()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         rec = []
         with torch.cuda.stream(side), torch.no_grad():
             for i in range(self.warmup):
                 if i == self.warmup - 1:
-                    ops._pack_recorder = rec
+                    ctx.pack_recorder = rec
                 try:
                     model(self.static)
                 finally:
-                    ops._pack_recorder = None
+                    ctx.pack_recorder = None
         torch.cuda.current_stream().wait_stream(side)
         seen, self._packs = set(), []
         for w, t in rec:
             if (id(w.w1), t) not in seen:
                 seen.add((id(w.w1), t))
                 self._packs.append((w, t))
-        self._sig = ops.pack_signature(self._packs)
+        self._sig = ops.pack_signature(self._packs, ctx)
         self._where = ops.storage_signature(self._packs)
         self.graph = torch.cuda.CUDAGraph()
-        ops._pack_in_capture = False
+        ctx.pack_in_capture = False
         try:
             with torch.no_grad(), torch.cuda.graph(self.graph):
                 self.out = model(self.static)
         finally:
-            ops._pack_in_capture = True
+            ctx.pack_in_capture = True
         self.captures += 1
 
     def __call__(self, node_features: Sequence[torch.Tensor], edge_features: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -81,11 +82,11 @@ class GraphedForward:
             # parameter storage was re-homed since the capture (FlatParams, model.to(): the old addresses are baked into the
             # graph and may be freed memory by now): capture again on the same static inputs
             self._capture()
-        sig = ops.pack_signature(self._packs)
+        sig = ops.pack_signature(self._packs, self.ctx)
         if sig != self._sig:                        # the weights were updated since the images were made: same buffers, new contents
             for w, t in self._packs:
-                ops.packs_of(w, t)
-            self._sig = ops.pack_signature(self._packs)
+                ops.packs_of(w, t, ctx=self.ctx)
+            self._sig = ops.pack_signature(self._packs, self.ctx)
         _copy_in(self.static, node_features, edge_features)
         self.graph.replay()
         return self.out
@@ -120,8 +121,7 @@ class GraphedTrainStep:
         if target is not None:
             self.target.copy_(target, non_blocking=True)
         self.graph.replay()
-        from . import ops
-        ops.invalidate_packs()      # the replayed Adam kernel rewrote the parameters: an eager forward must re-pack them
+        self.trainer.ctx.invalidate_packs()      # the replayed Adam kernel rewrote the parameters: an eager forward must re-pack them
         return self.loss
 
 
@@ -154,18 +154,18 @@ class GraphedShardStep:
     def _fwd_bwd(self) -> torch.Tensor:
         from . import ops
         tr = self.trainer
-        ops.discard_stale_wgrad()        # tasks a failed backward pass left queued belong to no step
+        ops.discard_stale_wgrad(tr.ctx)        # tasks a failed backward pass left queued belong to no step
         tr.fp.zero_grad()
         tr._pending, tr._done_upto = [], None
         if tr.side is not None:
             tr.side.wait_stream(torch.cuda.current_stream())
-            ops.set_wgrad_stream(tr.side)
+            tr.ctx.wgrad_stream = tr.side
         out = tr.model(self.static)
         self.width = out.shape[1]
         s = ((out - self.target) * self.maskf).square().sum()
         s.backward()
         if tr.side is not None:
-            ops.set_wgrad_stream(None)
+            tr.ctx.wgrad_stream = None
             torch.cuda.current_stream().wait_stream(tr.side)
         return s.detach()
 

@@ -419,14 +419,24 @@ class MeshGraphNet(nn.Module):
                                    message_passing_aggregator=self._message_passing_aggregator, edge_sets=edge_sets,
                                    graphnet_block=graphnet_block)
         self.decoder = Decoder(make_mlp=functools.partial(self._make_mlp, layer_norm=False), output_size=self._output_size)
+        # Launch context of THIS model (ops.Context): precision mode and kernel-selection flags, the deferred weight-gradient queue,
+        # pack epoch, workspaces.  Two models -- or two threads -- in one process share none of it; fields left unset follow the
+        # process defaults (hgn_amd.set_matmul_precision).
+        self._hgn_ctx = ops.Context()
+
+    def set_matmul_precision(self, mode) -> None:
+        """This model's own precision: 'fp32' (six split-bf16 products, fp32 accurate), 'bf16', 'fp16', or None = follow the
+        process default.  Other models of the process are not affected."""
+        self._hgn_ctx.set_matmul_precision(mode)
 
     def forward(self, graph: MultiGraph) -> Tensor:
         if self._latent_size != ops.LAT or self._num_layers != 2:
             raise HgnError('the HIP path implements latent_size=128, num_layers=2 (hard-coded by the reference models: '
                            'src/model/flag.py:57-58, plate.py:61-62, cylinder.py:57-58)')
-        lat = self.encoder._encode(graph)
-        lat = self.processor(lat)
-        return self.decoder(MultiGraph(lat.nodes[0], None))
+        with ops.using(self.__dict__.get('_hgn_ctx') or ops.default_context()):
+            lat = self.encoder._encode(graph)
+            lat = self.processor(lat)
+            return self.decoder(MultiGraph(lat.nodes[0], None))
 
     def _make_mlp(self, output_size: int, layer_norm=True) -> nn.Module:
         """`num_layers` hidden Linear+ReLU stages of the latent width, one output Linear; the LayerNorm'd variant is a Sequential

@@ -15,66 +15,169 @@ from . import _lib
 from ._lib import OP_CODES
 
 LAT = 128
-_ws_cache = {}
 _GATE_LOG = None              # tests only: when a list, every training forward appends (first-layer weight ptr, ReLU sign words, row index)
 _ARG_LOG = None               # tests only: when a list, every training edge block with max / min aggregates appends (first-layer weight ptr, argmax, argmin, sorted position -> edge index)
 
+_PRODUCTS = {'fp32': 6, 'bf16': 1, 'fp16': 2}
+_ENV = __import__('os').environ
+# Process-wide DEFAULTS, resolved once here (the library itself reads no environment variable): what a Context that does not say
+# otherwise follows.  HGN_FP32_MFMA: the plain fp32-MFMA kernels everywhere; HGN_NO_FUSED_BWD: hgn_mlp_bwd + hgn_mlp_wgrad instead of
+# hgn_edge_bwd_fused; HGN_NO_EDGE_FWD: the general forward kernel for training edge blocks too.
+_DEFAULTS = {'precision': 'fp32', 'fp32_mfma': bool(_ENV.get('HGN_FP32_MFMA')), 'general_fwd': bool(_ENV.get('HGN_NO_EDGE_FWD')),
+             'fused_edge_bwd': not bool(_ENV.get('HGN_NO_FUSED_BWD')) and not bool(_ENV.get('HGN_FP32_MFMA'))}
+_defaults_epoch = 0           # bumped when a default changes: packed weight images of every context are rebuilt on their next use
+_FUSED_SEG_MAX_ROWS = 65      # a segment of <= 65 consecutive rows touches at most two 64-row tiles
+_DEFER_NODE_WGRAD = not bool(_ENV.get('HGN_NO_DEFERRED_WGRAD'))
 
-_WGRAD_STREAM = None          # set by parallel.DataParallelTrainer: weight-gradient launches go to this side stream
-# edge blocks: data gradients and weight gradients in one pass (hgn_edge_bwd_fused) wherever the arguments are eligible (one `sum`
-# aggregate or none, no side stream): it moves 2.5 KB per edge and layer less than the two launches it replaces; kernel for
-# kernel it is at parity (1.64 + 0.27 + 0.14 ms for the kernel, the dW1e task and the receiver sums against 1.37 + 0.78 ms at
-# 1.19 M rows), the whole training step is 2.6 % faster with it (67.9 vs 69.7 ms, profiles/r02_other_configs.json; DESIGN.md
-# section 5.6).  HGN_NO_FUSED_BWD=1 or set_fused_edge_backward(False): always hgn_mlp_bwd + hgn_mlp_wgrad.
-_FUSED_EDGE_BWD_DEFAULT = not bool(__import__('os').environ.get('HGN_NO_FUSED_BWD'))
-_FUSED_EDGE_BWD = _FUSED_EDGE_BWD_DEFAULT
+
+class Context:
+    """Everything a model's launches depend on BESIDES their arguments -- precision mode and kernel-selection flags (they travel in
+    every argument struct: include/hgn_mp.h `products` / `flags`), the deferred weight-gradient queue, the pack epoch, workspaces, the
+    side stream.  One per MeshGraphNet (`model._hgn_ctx`): two models, or two threads, in one process share none of it.  A field left at
+    None follows the process default (set_matmul_precision / set_fused_edge_backward / the environment switches above).
+
+    The current context is thread-local (`using`); an autograd Function records the context of its forward and hands it to its
+    backward explicitly, because the engine runs backward passes on threads of its own."""
+
+    def __init__(self, precision=None, fused_edge_bwd=None, fp32_mfma=None, general_fwd=None):
+        if precision is not None and precision not in _PRODUCTS:
+            raise ValueError("matmul precision must be 'fp32', 'bf16' or 'fp16'")
+        self.precision, self.fused_edge_bwd, self.fp32_mfma, self.general_fwd = precision, fused_edge_bwd, fp32_mfma, general_fwd
+        self.wgrad_stream = None          # weight-gradient launches go to this side stream (parallel.DataParallelTrainer)
+        self.wq = {}                      # (M, device) -> [tasks, tensors kept alive, set of queued dW / db target addresses]
+        self.wq_graph_task = -1           # id of the autograd engine run whose final callback will flush the queue (-1: none armed)
+        self.pack_epoch = 0
+        self.pack_in_capture = True       # graphs.GraphedForward keeps the pack launches out of its captured graph
+        self.pack_recorder = None         # list that collects the (weights, form) pairs a forward pass packs
+        self.ws_cache = {}
+        self.post_result = None
+
+    # -- what travels in the argument structs ---------------------------------------------------------------------------------
+    def mode(self) -> str:
+        return self.precision if self.precision is not None else _DEFAULTS['precision']
+
+    def products(self) -> int:
+        return _PRODUCTS[self.mode()]
+
+    def flags(self) -> int:
+        f32 = self.fp32_mfma if self.fp32_mfma is not None else _DEFAULTS['fp32_mfma']
+        gen = self.general_fwd if self.general_fwd is not None else _DEFAULTS['general_fwd']
+        return (_lib.F_FP32_MFMA if f32 else 0) | (_lib.F_GENERAL_FWD if gen else 0)
+
+    def fp32_only(self) -> bool:
+        return bool(self.flags() & _lib.F_FP32_MFMA)
+
+    def fused(self) -> bool:
+        return self.fused_edge_bwd if self.fused_edge_bwd is not None else _DEFAULTS['fused_edge_bwd']
+
+    def stamp(self, args) -> None:
+        """Fill the per-call options of an MlpFwd / MlpBwd / WTask."""
+        args.products, args.flags = self.products(), self.flags()
+
+    # -- state --------------------------------------------------------------------------------------------------------------------
+    def set_matmul_precision(self, mode) -> None:
+        """This context's own precision ('fp32' / 'bf16' / 'fp16'; None: follow the process default again)."""
+        if mode is not None and mode not in _PRODUCTS:
+            raise ValueError("matmul precision must be 'fp32', 'bf16' or 'fp16'")
+        self.precision = mode
+        self.invalidate_packs()
+
+    def invalidate_packs(self) -> None:
+        """Call after the parameters were changed behind torch's back (the flat-buffer Adam kernels): packed images are rebuilt
+        on their next use.  In-place torch updates of a parameter are detected through its version counter."""
+        self.pack_epoch += 1
+
+    def workspace(self, device, nbytes: int, tag: str = 'wgrad') -> torch.Tensor:
+        key = (device.type, device.index, tag)
+        ws = self.ws_cache.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self.ws_cache[key] = ws
+        return ws
+
+    def __getstate__(self):               # a pickled model starts with a fresh queue / cache (settings travel)
+        return {'precision': self.precision, 'fused_edge_bwd': self.fused_edge_bwd, 'fp32_mfma': self.fp32_mfma, 'general_fwd': self.general_fwd}
+
+    def __setstate__(self, st):
+        self.__init__(**st)
+
+
+_DEFAULT_CTX = Context()
+_tls = __import__('threading').local()
+
+
+def default_context() -> Context:
+    return _DEFAULT_CTX
+
+
+def current() -> Context:
+    stack = getattr(_tls, 'stack', None)
+    return stack[-1] if stack else _DEFAULT_CTX
+
+
+class using:
+    """with ops.using(ctx): ...   -- launches issued by this thread inside the block belong to `ctx`."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def __enter__(self):
+        if not hasattr(_tls, 'stack'):
+            _tls.stack = []
+        _tls.stack.append(self.ctx)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _tls.stack.pop()
+        return False
 
 
 def set_fused_edge_backward(on) -> None:
-    """True: eligible edge-block backwards go through hgn_edge_bwd_fused (the default); False: hgn_mlp_bwd + hgn_mlp_wgrad;
-    None: back to the process default."""
-    global _FUSED_EDGE_BWD
-    _FUSED_EDGE_BWD = _FUSED_EDGE_BWD_DEFAULT if on is None else bool(on)
-
-
-_PRODUCTS = {'fp32': 6, 'bf16': 1, 'fp16': 2}
+    """Process default: True: eligible edge-block backwards go through hgn_edge_bwd_fused (the default); False: hgn_mlp_bwd +
+    hgn_mlp_wgrad; None: back to the start-up default.  (A Context's own `fused_edge_bwd` overrides it.)"""
+    _DEFAULTS['fused_edge_bwd'] = (not bool(_ENV.get('HGN_NO_FUSED_BWD')) and not bool(_ENV.get('HGN_FP32_MFMA'))) if on is None else bool(on)
 
 
 def set_matmul_precision(mode: str) -> None:
-    """'fp32' (default): every 128x128 product as six split-bf16 MFMAs, fp32 accurate -- the mode all parity claims refer to.
+    """Process DEFAULT (contexts that set their own precision are not touched).
+    'fp32' (default): every 128x128 product as six split-bf16 MFMAs, fp32 accurate -- the mode all parity claims refer to.
     'bf16': ONE bf16 MFMA per product (operands rounded to bf16, fp32 accumulation; ~4e-3 relative error per product).
     'fp16': the forward products as ONE fp16 MFMA (11 significant bits: ~5e-4 per product; activations behind a LayerNorm and
     weights are far inside fp16's range), the backward / weight-gradient products as one bf16 MFMA (fp32 range: gradients need no
-    loss scaling) -- the "fp16 MFMA edge-MLP" of BASELINE.json configs[4].  Opt-in, process wide (include/hgn_mp.h:
-    hgn_set_matmul_products); packed weight images are rebuilt on the next use."""
+    loss scaling) -- the "fp16 MFMA edge-MLP" of BASELINE.json configs[4].  Opt-in; also becomes the library's default for callers
+    of the C ABI that leave `products` at 0 (include/hgn_mp.h: hgn_set_matmul_products); packed weight images are rebuilt on
+    their next use."""
+    global _defaults_epoch
     if mode not in _PRODUCTS:
         raise ValueError("matmul precision must be 'fp32', 'bf16' or 'fp16'")
     _lib.check(_lib.lib().hgn_set_matmul_products(_PRODUCTS[mode]), 'hgn_set_matmul_products')
-    invalidate_packs()
+    _DEFAULTS['precision'] = mode
+    _defaults_epoch += 1
 
 
 def get_matmul_precision() -> str:
-    n = _lib.lib().hgn_get_matmul_products()
-    return {6: 'fp32', 1: 'bf16', 2: 'fp16'}[n]
+    return _DEFAULTS['precision']
+
+
+def invalidate_packs() -> None:
+    """EVERY context's packed images are stale (parameters changed behind torch's version counters, and the caller does not know
+    whose): rebuilt on their next use.  A trainer that knows its model uses Context.invalidate_packs."""
+    global _defaults_epoch
+    _defaults_epoch += 1
 
 
 def set_wgrad_stream(stream):
-    """Run every hgn_mlp_wgrad launch on `stream` (forked from / joined to the current stream by the caller).
+    """Run every hgn_mlp_wgrad launch of the current context on `stream` (forked from / joined to the current stream by the caller).
 
     Weight gradients are only consumed by the optimiser, so they need not sit on the critical path of the backward pass;
     on a second stream they co-run with the next layer's backward kernels, whose memory-bound and MFMA-bound phases they
     fill.  Only valid when the consumer joins the stream before reading gradients (the flat-buffer trainer does)."""
-    global _WGRAD_STREAM
-    _WGRAD_STREAM = stream
+    current().wgrad_stream = stream
 
 
 def _workspace(device, nbytes: int, tag: str = 'wgrad') -> torch.Tensor:
-    key = (device.type, device.index, tag)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+    """Scratch of the current context (feature kernels, topology builds: callers outside the autograd functions)."""
+    return current().workspace(device, nbytes, tag)
 
 
 def _rowmajor(t: torch.Tensor) -> torch.Tensor:
@@ -117,28 +220,15 @@ class MLPWeights:
 # ------------------------------------------------------------------------------------------------------------
 # packed weight images for the split-bf16 kernels (include/hgn_mp.h: hgn_pack_bf16x3)
 # ------------------------------------------------------------------------------------------------------------
-_pack_epoch = 0
-_FUSED_SEG_MAX_ROWS = 65      # a segment of <= 65 consecutive rows touches at most two 64-row tiles
-_FP32_ONLY = bool(__import__('os').environ.get('HGN_FP32_MFMA'))
-
-
-def invalidate_packs() -> None:
-    """Call after the parameters were changed behind torch's back (the flat-buffer Adam kernels): packed images are rebuilt
-    on their next use.  In-place torch updates of a parameter are detected through its version counter."""
-    global _pack_epoch
-    _pack_epoch += 1
-
-
 # graphs.GraphedForward (inference: the weights do not change between replays) keeps the pack kernels OUT of its captured graph and
-# re-packs eagerly when a version counter or the pack epoch has moved; a captured TRAINING step packs inside the graph (its own Adam
-# kernel rewrites the weights every replay).  `_pack_recorder`: list that collects the (weights, form) pairs a forward pass packs.
-_pack_in_capture = True
-_pack_recorder = None
+# re-packs eagerly when a version counter or a pack epoch has moved (Context.pack_in_capture / pack_recorder); a captured TRAINING step
+# packs inside the graph (its own Adam kernel rewrites the weights every replay).
 
 
-def pack_signature(pairs) -> tuple:
+def pack_signature(pairs, ctx: Optional[Context] = None) -> tuple:
     """What packs_of keys its cache on, for a list of (MLPWeights, transposed) pairs."""
-    return (_pack_epoch,) + tuple(v for w, _ in pairs for v in (w.w1._version, w.w2._version, w.w3._version))
+    c = ctx if ctx is not None else current()
+    return (_defaults_epoch, c.pack_epoch, c.products()) + tuple(v for w, _ in pairs for v in (w.w1._version, w.w2._version, w.w3._version))
 
 
 # A captured graph has the ADDRESSES of biases, LayerNorm vectors, the decoder's weights and the packed images baked in.  Whatever
@@ -156,25 +246,26 @@ def storage_signature(pairs) -> tuple:
     return (_storage_epoch,) + tuple(w.w1.data_ptr() for w, _ in pairs)
 
 
-def packs_of(w: MLPWeights, transposed: bool = False):
+def packs_of(w: MLPWeights, transposed: bool = False, ctx: Optional[Context] = None):
     """-> uint8 tensor holding the packed blocks [W1 block 0 .. nb1-1, W2, W3] of this MLP (forward or transposed form; a
     first-layer width that is not a multiple of 128 gives a zero-padded last block), or None for a narrow output (decoder)."""
     if w.w3.shape[0] != LAT or not w.w1.is_cuda:
         return None
+    c = ctx if ctx is not None else current()
     nb1 = (w.w1.shape[1] + LAT - 1) // LAT
     attr = '_hgn_pk_t' if transposed else '_hgn_pk'
-    key = (_pack_epoch, w.w1._version, w.w2._version, w.w3._version, w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr())
+    # forward-form images of the fp16 mode carry fp16 bit patterns in their leading third (hgn_pack_t.transposed | 2)
+    t = 1 if transposed else (2 if c.products() == 2 else 0)
+    key = (_defaults_epoch, c.pack_epoch, t, w.w1._version, w.w2._version, w.w3._version, w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr())
     st = getattr(w.w1, attr, None)
-    if _pack_recorder is not None:
-        _pack_recorder.append((w, transposed))
-    capturing = torch.cuda.is_current_stream_capturing() and _pack_in_capture
+    if c.pack_recorder is not None:
+        c.pack_recorder.append((w, transposed))
+    capturing = torch.cuda.is_current_stream_capturing() and c.pack_in_capture
     if st is not None and st[0] == key and not capturing:
         return st[1]
     buf = st[1] if st is not None and st[1].numel() == (nb1 + 2) * _lib.PACK_BLOCK_BYTES else \
         torch.empty((nb1 + 2) * _lib.PACK_BLOCK_BYTES, dtype=torch.uint8, device=w.w1.device)
     arr = (_lib.Pack * (nb1 + 2))()
-    # forward-form images of the fp16 mode carry fp16 bit patterns in their leading third (hgn_pack_t.transposed | 2)
-    t = 1 if transposed else (2 if _lib.lib().hgn_get_matmul_products() == 2 else 0)
     for b in range(nb1):
         d = arr[b]
         d.W = w.w1.data_ptr() + 4 * LAT * b; d.ldw = w.w1.shape[1]; d.n_out = LAT
@@ -234,13 +325,8 @@ def _zero_unaccumulated(bufs, accs):
 # Deferred node-level weight gradients.  A node MLP hands over 4 tasks of N rows, the pre-projection of an edge block 2 more:
 # launched one by one that is ~33 launches per step of a kernel whose fixed costs (slab reduction, tail of a 200 k-row grid)
 # are a third of its time.  Weight gradients are consumed by nobody before the optimiser, so tasks that ACCUMULATE into a flat
-# gradient buffer (parallel.FlatParams) are queued per row count and launched 16 at a time; whatever is left goes out when the
-# autograd engine finishes the backward pass (queue_callback), i.e. before `backward()` returns -- also under HIP-graph capture.
-_DEFER_NODE_WGRAD = not bool(__import__('os').environ.get('HGN_NO_DEFERRED_WGRAD'))
-_wq = {}                      # (M, device) -> [tasks, tensors kept alive, set of queued dW / db target addresses]
-_wq_graph_task = -1           # id of the autograd engine run whose final callback will flush the queue (-1: none armed)
-
-
+# gradient buffer (parallel.FlatParams) are queued per row count (Context.wq) and launched 16 at a time; whatever is left goes out
+# when the autograd engine finishes the backward pass (queue_callback), i.e. before `backward()` returns -- also under HIP-graph capture.
 def _graph_task_id() -> int:
     try:
         return int(torch._C._current_graph_task_id())
@@ -248,27 +334,27 @@ def _graph_task_id() -> int:
         return -1
 
 
-def flush_wgrad() -> None:
-    """Launch every queued weight-gradient task now."""
-    global _wq_graph_task
-    _wq_graph_task = -1
+def flush_wgrad(ctx: Optional[Context] = None) -> None:
+    """Launch every queued weight-gradient task of the context now."""
+    c = ctx if ctx is not None else current()
+    c.wq_graph_task = -1
     try:
-        for (M, dev), q in list(_wq.items()):
+        for (M, dev), q in list(c.wq.items()):
             if q[0]:
-                _run_wgrad_here(q[0], M, dev, False)
+                _run_wgrad_here(c, q[0], M, dev, False)
     finally:
-        _wq.clear()
+        c.wq.clear()
 
 
-def discard_stale_wgrad() -> int:
+def discard_stale_wgrad(ctx: Optional[Context] = None) -> int:
     """Drop queued tasks without launching them and disarm the callback.  Tasks can only be left over when a backward pass
     raised after queueing them (the engine then drops its callbacks): their operand pointers belong to that failed step and
     must not be launched into the next step's gradient buffer.  -> number of tasks dropped.  Called at the start of every
     trainer step (parallel.DataParallelTrainer, graphs.*) and whenever a task is queued from a different engine run."""
-    global _wq_graph_task
-    n = sum(len(q[0]) for q in _wq.values())
-    _wq.clear()
-    _wq_graph_task = -1
+    c = ctx if ctx is not None else current()
+    n = sum(len(q[0]) for q in c.wq.values())
+    c.wq.clear()
+    c.wq_graph_task = -1
     return n
 
 
@@ -276,53 +362,54 @@ def _wtask_targets(t):
     return [p for p in (t.dW, t.db) if p]
 
 
-def _defer_wgrad(tasks, M, dev, keep):
-    global _wq_graph_task
+def _defer_wgrad(c: Context, tasks, M, dev, keep):
     gid = _graph_task_id()
     if gid < 0:                              # backward driven by hand, outside an engine run: nothing will call back
-        _run_wgrad_here(tasks, M, dev, False)
+        _run_wgrad_here(c, tasks, M, dev, False)
         return
-    if gid != _wq_graph_task:
+    if gid != c.wq_graph_task:
         # first task of THIS engine run.  Anything still queued was left by a run that raised: never launch it.
-        discard_stale_wgrad()
-        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad)
-        _wq_graph_task = gid
-    q = _wq.setdefault((M, dev), [[], [], set()])
+        discard_stale_wgrad(c)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_wgrad(c))
+        c.wq_graph_task = gid
+    q = c.wq.setdefault((M, dev), [[], [], set()])
     tg = [p for t in tasks for p in _wtask_targets(t)]
     # wgrad_reduce_kernel adds one task's result onto its target without atomics, one grid slice per task: two tasks of ONE
     # launch must never share a dW / db target (the same MLP applied twice at one row count: `repeated` blocks, the cross
     # model and the mesh-edge model of `multiscale`).  Launch what is queued first; stream order then serialises the two.
     if len(q[0]) + len(tasks) > _lib.HGN_MAX_WTASK or any(p in q[2] for p in tg) or len(set(tg)) != len(tg):
         if q[0]:
-            _run_wgrad_here(q[0], M, dev, False)
+            _run_wgrad_here(c, q[0], M, dev, False)
         q[0], q[1], q[2] = [], [], set()
     if len(set(tg)) != len(tg):              # the hand-over itself repeats a target: one launch per task
         for t in tasks:
-            _run_wgrad_here([t], M, dev, False)
+            _run_wgrad_here(c, [t], M, dev, False)
         return
     q[0] += tasks
     q[1] += list(keep)
     q[2].update(tg)
 
 
-def _run_wgrad(tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False, keep=(), defer: bool = False):
+def _run_wgrad(c: Context, tasks: List[_lib.WTask], M: int, dev, edge_level: bool = False, keep=(), defer: bool = False):
     if M == 0:          # operands of an empty set have null data pointers; the callers zero what the launch would have written
         return
-    side = _WGRAD_STREAM
+    for t in tasks:
+        c.stamp(t)
+    side = c.wgrad_stream
     if defer and _DEFER_NODE_WGRAD and side is None and all(t.accumulate for t in tasks):
-        _defer_wgrad(tasks, M, dev, keep)
+        _defer_wgrad(c, tasks, M, dev, keep)
         return
     if side is not None:
         side.wait_stream(torch.cuda.current_stream())
         for t in keep:                       # operands were allocated on the main stream: keep them alive for the side stream
             t.record_stream(side)
         with torch.cuda.stream(side):
-            _run_wgrad_here(tasks, M, dev, edge_level)
+            _run_wgrad_here(c, tasks, M, dev, edge_level)
         return
-    _run_wgrad_here(tasks, M, dev, edge_level)
+    _run_wgrad_here(c, tasks, M, dev, edge_level)
 
 
-def _run_wgrad_here(tasks: List[_lib.WTask], M: int, dev, edge_level: bool):
+def _run_wgrad_here(c: Context, tasks: List[_lib.WTask], M: int, dev, edge_level: bool):
     L = _lib.lib()
     L.hgn_prof_tag(0 if edge_level else 1)
     for i in range(0, len(tasks), _lib.HGN_MAX_WTASK):
@@ -330,14 +417,14 @@ def _run_wgrad_here(tasks: List[_lib.WTask], M: int, dev, edge_level: bool):
         arr = (_lib.WTask * len(chunk))(*chunk)
         nb = C.c_size_t(0)
         _lib.check(L.hgn_wgrad_workspace_bytes(M, len(chunk), C.byref(nb)), 'hgn_wgrad_workspace_bytes')
-        ws = _workspace(dev, nb.value)
+        ws = c.workspace(dev, nb.value)
         _lib.check(L.hgn_mlp_wgrad(arr, len(chunk), M, ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'hgn_mlp_wgrad')
 
 
-def _ln_workspace(M: int, dev) -> torch.Tensor:
+def _ln_workspace(c: Context, M: int, dev) -> torch.Tensor:
     nb = C.c_size_t(0)
     _lib.check(_lib.lib().hgn_mlp_bwd_ln_workspace_bytes(M, C.byref(nb)), 'hgn_mlp_bwd_ln_workspace_bytes')
-    return _workspace(dev, nb.value, 'ln')
+    return c.workspace(dev, nb.value, 'ln')
 
 
 def _grad_targets(wt):
@@ -384,6 +471,7 @@ class MLPFn(torch.autograd.Function):
     def forward(ctx, meta, *tensors):
         n_src, idxs, residual, has_ln, train = meta[:5]
         post = meta[5] if len(meta) > 5 else None          # (packed next-block weights, zero-fill wanted): inference only, see fused_mlp
+        c = current()
         srcs = [_rowmajor(t) for t in tensors[:n_src]]
         wt = tensors[n_src:]
         w = MLPWeights(*wt)
@@ -395,12 +483,13 @@ class MLPFn(torch.autograd.Function):
         out_w = w.w3.shape[0]
         out = torch.empty(M, out_w, device=dev)
         a = _lib.MlpFwd()
+        c.stamp(a)
         a.M = M
         a.n_src = n_src
         col = 0
         cols = []
         # every source must start on a 128-column boundary of W1 (all but the last a multiple of 128 wide)
-        pk = packs_of(w) if all(s.shape[1] % LAT == 0 for s in srcs[:-1]) else None
+        pk = packs_of(w, ctx=c) if all(s.shape[1] % LAT == 0 for s in srcs[:-1]) else None
         nb1 = (w.w1.shape[1] + LAT - 1) // LAT
         for i, s in enumerate(srcs):
             e = a.src[i]
@@ -420,7 +509,6 @@ class MLPFn(torch.autograd.Function):
         res = srcs[residual] if residual >= 0 else None
         _fill_common_fwd(a, w, out, res, saves)
         if post is not None and not train:
-            global _post_result
             pk_next, want_zero = post
             P = torch.empty(M, 2 * LAT, device=dev)
             zero = torch.empty(M, LAT, device=dev) if want_zero else None
@@ -429,10 +517,10 @@ class MLPFn(torch.autograd.Function):
             if zero is not None:
                 a.post_zero = zero.data_ptr(); a.ld_post_zero = LAT
             if M > 0 and _lib.lib().hgn_mlp_fwd_post_eligible(C.byref(a)):
-                _post_result = (P, zero)
+                c.post_result = (P, zero)
             else:                                            # bigger launches: the pre-projection stays a launch of its own
                 a.n_post = 0; a.post_out = None; a.post_zero = None
-                _post_result = None
+                c.post_result = None
         if M > 0:
             _lib.check(_lib.lib().hgn_mlp_fwd(C.byref(a), _lib.stream_ptr()), 'hgn_mlp_fwd')
         if train and _GATE_LOG is not None:
@@ -441,13 +529,15 @@ class MLPFn(torch.autograd.Function):
             ctx.meta = (n_src, idxs, residual, has_ln, cols, M)
             ctx.saves = saves
             ctx.targets = _grad_targets(wt)
-            ctx.pk_t = packs_of(w, transposed=True) if pk is not None else None
+            ctx.pk_t = packs_of(w, transposed=True, ctx=c) if pk is not None else None
+            ctx.hgn = c
             ctx.save_for_backward(*srcs, *wt)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         n_src, idxs, residual, has_ln, cols, M = ctx.meta
+        c = ctx.hgn                                      # (the engine runs this on a thread of its own: the context comes with the node)
         pk_t = ctx.pk_t
         saved = ctx.saved_tensors
         srcs, wt = saved[:n_src], saved[n_src:]
@@ -461,6 +551,7 @@ class MLPFn(torch.autograd.Function):
         dz2 = torch.empty(M, LAT, device=dev)
         dz1 = torch.empty(M, LAT, device=dev)
         b = _lib.MlpBwd()
+        c.stamp(b)
         b.M = M
         b.d_out = d_out.data_ptr(); b.ld_dout = _ld(d_out); b.out_w = out_w
         if has_ln:
@@ -489,7 +580,7 @@ class MLPFn(torch.autograd.Function):
         bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
         if has_ln:           # LayerNorm-affine gradients come out of the same pass
             b.d_gamma = bufs[6].data_ptr(); b.d_beta = bufs[7].data_ptr(); b.ln_accumulate = accs[6]
-            b.ln_ws = _ln_workspace(M, dev).data_ptr()
+            b.ln_ws = _ln_workspace(c, M, dev).data_ptr()
         if M > 0:
             _lib.check(L.hgn_mlp_bwd(C.byref(b), _lib.stream_ptr()), 'hgn_mlp_bwd')
         elif has_ln and not accs[6]:
@@ -511,7 +602,7 @@ class MLPFn(torch.autograd.Function):
         if M == 0:
             _zero_unaccumulated(bufs[:6], accs[:6])
         # (gathered / narrow sources = encoders: few launches, operands of E rows: not worth keeping alive)
-        _run_wgrad(tasks, M, dev, keep=[z1, z2, dz1, dz2, dz3, *srcs], defer=all(i is None for i in idxs) and pk_t is not None)
+        _run_wgrad(c, tasks, M, dev, keep=[z1, z2, dz1, dz2, dz3, *srcs], defer=all(i is None for i in idxs) and pk_t is not None)
         # ---- un-gather source gradients -----------------------------------------------------------------------
         for i in range(n_src):
             if dxs[i] is not None and idxs[i] is not None:
@@ -519,9 +610,6 @@ class MLPFn(torch.autograd.Function):
                 full.index_add_(0, idxs[i].long(), dxs[i])
                 dxs[i] = full
         return (None, *dxs, *grads_w)
-
-
-_post_result = None
 
 
 def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequence[Optional[torch.Tensor]]] = None,
@@ -535,10 +623,10 @@ def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequen
     if post is None or train:
         out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train), *srcs, *wt)
         return out if post is None else (out, None)
-    global _post_result
-    _post_result = None
+    c = current()
+    c.post_result = None
     out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, post), *srcs, *wt)
-    got, _post_result = _post_result, None
+    got, c.post_result = c.post_result, None
     return out, got
 
 
@@ -562,11 +650,12 @@ class EdgeBlockFn(torch.autograd.Function):
         dev = e.device
         L = _lib.lib()
         st = _lib.stream_ptr()
+        c = current()
         E, N = topo.num_edges, topo.num_nodes
         if e.shape[0] != E or h_all.shape[0] != N:
             raise _lib.HgnError(f'edge block: got {e.shape[0]} edge rows / {h_all.shape[0]} node rows, topology has {E} / {N}')
         P = torch.empty(N, 2 * LAT, device=dev)
-        pk = packs_of(w) if (_ld(h_all) % 4 == 0 and h_all.data_ptr() % 16 == 0 and not _FP32_ONLY) else None
+        pk = packs_of(w, ctx=c) if (_ld(h_all) % 4 == 0 and h_all.data_ptr() % 16 == 0 and not c.fp32_only()) else None
         # the `sum` aggregate formed inside the edge kernel needs a zero-filled [N, 128] buffer: filled by the pre-projection launch,
         # which passes over the same node rows anyway (hgn_linear_fwd6z), instead of a launch of its own
         agg_zeroed = None
@@ -577,12 +666,13 @@ class EdgeBlockFn(torch.autograd.Function):
             if agg_ops == ('sum',) and 0 < E and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS:
                 agg_zeroed = torch.empty(N, LAT, device=dev)
             _lib.check(L.hgn_linear_fwd6z(h_all.data_ptr(), _ld(h_all), N, pb, 2, P.data_ptr(), 2 * LAT,
-                                          agg_zeroed.data_ptr() if agg_zeroed is not None else None, LAT, st), 'hgn_linear_fwd6z')
+                                          agg_zeroed.data_ptr() if agg_zeroed is not None else None, LAT, c.products(), st), 'hgn_linear_fwd6z')
         else:
             wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
             _lib.check(L.hgn_linear_fwd(h_all.data_ptr(), _ld(h_all), N, wb, 2, 3 * LAT, P.data_ptr(), 2 * LAT, st), 'hgn_linear_fwd')
         out = torch.empty(E, LAT, device=dev)
         a = _lib.MlpFwd()
+        c.stamp(a)
         a.M = E
         a.n_src = 1
         s = a.src[0]
@@ -629,7 +719,8 @@ class EdgeBlockFn(torch.autograd.Function):
             ctx.saves = saves
             ctx.agg = (agg_ops, amax, amin)
             ctx.targets = _grad_targets(wt)
-            ctx.pk_t = packs_of(w, transposed=True) if pk is not None else None
+            ctx.pk_t = packs_of(w, transposed=True, ctx=c) if pk is not None else None
+            ctx.hgn = c
             ctx.save_for_backward(h_all, e, *wt)
         return (out, agg) if agg_ops is not None else out
 
@@ -643,6 +734,7 @@ class EdgeBlockFn(torch.autograd.Function):
         L = _lib.lib()
         E, N = topo.num_edges, topo.num_nodes
         st = _lib.stream_ptr()
+        c = ctx.hgn
         if d_out is None and d_agg is None:
             return (None,) * (6 + len(wt))
         dev = (d_out if d_out is not None else d_agg).device
@@ -650,6 +742,7 @@ class EdgeBlockFn(torch.autograd.Function):
         dz1 = torch.empty((E + 63) // 64 * 64, LAT, device=dev)[:E]      # whole 64-row tiles: hgn_edge_bwd_fused stores the padding rows too
         de = torch.empty(E, LAT, device=dev)
         b = _lib.MlpBwd()
+        c.stamp(b)
         b.M = E
         b.out_w = LAT
         if d_out is not None:
@@ -680,12 +773,12 @@ class EdgeBlockFn(torch.autograd.Function):
         bufs, accs, grads_w = _grad_bufs(wt, ctx.targets)
         dw1, db1, dw2, db2, dw3, db3, dg, dbt = bufs
         b.d_gamma = dg.data_ptr(); b.d_beta = dbt.data_ptr(); b.ln_accumulate = accs[6]
-        b.ln_ws = _ln_workspace(E, dev).data_ptr()
+        b.ln_ws = _ln_workspace(c, E, dev).data_ptr()
         # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]; the receiver half comes out of the
         # backward kernel itself when the segments are short (include/hgn_mp.h: seg_dz1)
         dP = torch.empty(N, 2 * LAT, device=dev)
         # One pass for data gradients AND weight gradients (include/hgn_mp.h: hgn_edge_bwd_fused): dz3 / dz2 never reach memory.
-        may_fuse = _FUSED_EDGE_BWD and pk_t is not None and E > 0 and _WGRAD_STREAM is None and accs[2] == accs[4]
+        may_fuse = c.fused() and pk_t is not None and E > 0 and c.wgrad_stream is None and accs[2] == accs[4]
         fused = may_fuse and bool(L.hgn_edge_bwd_fused_eligible(C.byref(b)))      # (dW3 / dW2 share one accumulate flag in hgn_wfuse_t)
         if may_fuse and not fused and d_agg is not None and (d_out is None or _ld(d_out) == LAT):
             # Several aggregates (pna) or arg-routed ones: the fused kernel gathers ONE `sum` row per edge.  The gradient that reaches e'
@@ -717,10 +810,10 @@ class EdgeBlockFn(torch.autograd.Function):
             wf.accumulate = accs[2]
             nb = C.c_size_t(0)
             _lib.check(L.hgn_edge_bwd_fused_workspace_bytes(E, C.byref(nb)), 'hgn_edge_bwd_fused_workspace_bytes')
-            ws = _workspace(dev, nb.value, 'fused')
+            ws = c.workspace(dev, nb.value, 'fused')
             _lib.check(L.hgn_edge_bwd_fused(C.byref(b), C.byref(wf), ws.data_ptr(), ws.numel(), st), 'hgn_edge_bwd_fused')
             # dW1's edge block: dz1 is in memory anyway (the sender / receiver sums read it), one streaming task
-            _run_wgrad([_wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
+            _run_wgrad(c, [_wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
                                db1.data_ptr(), accs[0])], E, dev, edge_level=True, keep=[e, dz1])
         else:
             dz3 = torch.empty(E, LAT, device=dev)
@@ -736,7 +829,7 @@ class EdgeBlockFn(torch.autograd.Function):
                             db1.data_ptr(), accs[0])]
             if E == 0:      # dW1's node-row column blocks are written by the node-level launch below (from dP = 0)
                 _zero_unaccumulated(bufs[:6], accs[:6])
-            _run_wgrad(tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
+            _run_wgrad(c, tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
         ops = (C.c_int32 * 1)(0)
         _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N,
                                             ops, 1, dP.data_ptr(), 2 * LAT, None, None, st), 'segment_reduce(senders)')
@@ -747,13 +840,13 @@ class EdgeBlockFn(torch.autograd.Function):
                         accs[0]),
                  _wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr() + 4 * LAT, 2 * LAT, LAT,
                         dw1.data_ptr() + 4 * LAT, 3 * LAT, None, accs[0])]
-        _run_wgrad(tasks, N, dev, keep=[h_all, dP], defer=True)
+        _run_wgrad(c, tasks, N, dev, keep=[h_all, dP], defer=True)
         dh = None
         if ctx.needs_input_grad[4]:                      # h_all (inputs: topo, train, agg_ops, pre, h_all, e, *weights)
             dh = torch.empty(N, LAT, device=dev)
             if pk_t is not None:
                 pb = (C.c_void_p * 2)(pk_t.data_ptr(), pk_t.data_ptr() + _lib.PACK_BLOCK_BYTES)
-                _lib.check(L.hgn_linear_bwd6(dP.data_ptr(), 2 * LAT, N, pb, 2, dh.data_ptr(), LAT, st), 'hgn_linear_bwd6')
+                _lib.check(L.hgn_linear_bwd6(dP.data_ptr(), 2 * LAT, N, pb, 2, dh.data_ptr(), LAT, c.products(), st), 'hgn_linear_bwd6')
             else:
                 wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
                 _lib.check(L.hgn_linear_bwd(dP.data_ptr(), 2 * LAT, N, wb, 2, 3 * LAT, dh.data_ptr(), LAT, st), 'hgn_linear_bwd')

@@ -181,6 +181,8 @@ class DataParallelTrainer:
                  device_step: bool = False, wgrad_stream: bool = False, buckets: int = 4, bucket_after=None,
                  force_collectives: bool = False):
         self.model = model
+        from . import ops as _ops
+        self.ctx = getattr(model, '_hgn_ctx', None) or _ops.default_context()      # the launch context of the model it trains (ops.Context)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -247,7 +249,7 @@ class DataParallelTrainer:
             return
         if self.fp.flat.is_cuda:
             from . import ops
-            ops.flush_wgrad()                                      # queued node-level weight-gradient tasks of these layers
+            ops.flush_wgrad(self.ctx)                              # queued node-level weight-gradient tasks of these layers
             if self.side is not None:
                 torch.cuda.current_stream().wait_stream(self.side)
         self._pending.append(dist.all_reduce(self.fp.grad_ext[start:end], group=self.group, async_op=True))
@@ -259,11 +261,11 @@ class DataParallelTrainer:
         self._pending, self._done_upto = [], None
         if self.fp.flat.is_cuda:
             from . import ops
-            ops.discard_stale_wgrad()                                # tasks a failed backward pass left queued belong to no step
+            ops.discard_stale_wgrad(self.ctx)                        # tasks a failed backward pass left queued belong to no step
         if self.side is not None:
             from . import ops
             self.side.wait_stream(torch.cuda.current_stream())      # the zeroed gradient buffer is visible to the side stream
-            ops.set_wgrad_stream(self.side)
+            self.ctx.wgrad_stream = self.side
         # (the count rides in the LAST range: written before the backward pass, reduced after it)
         self.fp.count.copy_(mask.sum().to(torch.float32).reshape(1))
         out = self.model(graph)
@@ -271,7 +273,7 @@ class DataParallelTrainer:
         sq = diff.square().sum()                                      # local SUM; scaled to the global mean after the collective
         sq.backward()
         if self.side is not None:
-            ops.set_wgrad_stream(None)
+            self.ctx.wgrad_stream = None
             torch.cuda.current_stream().wait_stream(self.side)      # join: all weight gradients are in the flat buffer
         return self.reduce_and_update(sq.detach(), out.shape[1])
 
@@ -296,7 +298,7 @@ class DataParallelTrainer:
             self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
         if self.fp.flat.is_cuda:
             from . import ops
-            ops.invalidate_packs()                  # the Adam kernel rewrote the parameters behind torch's version counters
+            self.ctx.invalidate_packs()             # the Adam kernel rewrote the parameters behind torch's version counters
         return (sq_local * inv).squeeze(0)
 
 

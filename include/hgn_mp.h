@@ -35,6 +35,8 @@ extern "C" {
 #define HGN_OP_MEAN 1
 #define HGN_OP_MAX 2
 #define HGN_OP_MIN 3
+#define HGN_F_FP32_MFMA 1
+#define HGN_F_GENERAL_FWD 2
 
 #define HGN_MAX_SRC 8
 #define HGN_MAX_ADD 2
@@ -153,6 +155,13 @@ typedef struct {
    * sender / receiver column blocks of its first Linear), formed while the rows are still in registers --, and, when
    * post_zero is given, post_zero[i][0..128) = 0 (that block's aggregate buffer, see seg_out). */
   const void* post_pk[4]; int32_t n_post; float* post_out; int64_t ld_post; float* post_zero; int64_t ld_post_zero;
+  /* per-call options (the library keeps no mutable state a call depends on except the DEFAULT below):
+   *   products: 0 = the process default (hgn_set_matmul_products), or 6 / 1 / 2 for THIS call -- two models with different precisions,
+   *             or two threads, never see each other's setting; packed images must have been built for the same mode;
+   *   flags:    HGN_F_FP32_MFMA = the plain fp32-MFMA kernels even where the split-bf16 ones are eligible (what the environment
+   *             variable HGN_FP32_MFMA selects for a whole process: the Python host reads it once and passes the flag);
+   *             HGN_F_GENERAL_FWD = never the specialised training-edge-block kernel (A/B tests: bit-identical results). */
+  int32_t products; int32_t flags;
 } hgn_mlp_fwd_t;
 
 int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
@@ -163,7 +172,7 @@ int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
  * with i+j <= 4; fp32 accumulation): at least fp32-accurate (2.6e-7 vs 4.5e-7 max relative error of a plain fp32 product
  * on these shapes) at 2.7x the fp32 MFMA rate.  hgn_pack_bf16x3 packs blocks of at most 128 x 128 (element (o,i) at
  * W[o*ldw+i], zero padded) into HGN_PACK_BLOCK_BYTES each.  Packs must be refreshed whenever the weights change.
- * Setting the environment variable HGN_FP32_MFMA forces the plain fp32 kernels. */
+ * The flag HGN_F_FP32_MFMA of a call forces the plain fp32 kernels for that call. */
 #define HGN_PACK_BLOCK_BYTES 98304
 #define HGN_MAX_PACK 32
 typedef struct {
@@ -174,7 +183,7 @@ typedef struct {
   void* out;                       /* HGN_PACK_BLOCK_BYTES, 16-byte aligned                                 */
 } hgn_pack_t;
 int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* stream);   /* one launch for up to HGN_MAX_PACK blocks */
-/* Precision of the split-bf16 kernels, process wide.  6 (default): the six products above, fp32 accurate -- the mode every
+/* DEFAULT precision of the split-bf16 kernels: what a call with `products` = 0 gets.  6 (default): the six products above, fp32 accurate -- the mode every
  * parity claim of this library refers to.  1: ONE bf16 MFMA per product (both operands rounded to bf16, fp32 accumulation,
  * relative error ~4e-3 per product; a third of the weight traffic, a sixth of the MFMAs).  2: the FORWARD products as ONE fp16
  * MFMA (v_mfma_f32_16x16x32_f16: 11 significant bits, ~5e-4 per product; the forward-form packs must then be built with
@@ -186,12 +195,12 @@ int hgn_get_matmul_products(void);
 int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd will take the split-bf16 kernel */
 int hgn_mlp_fwd_post_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd accepts these args WITH their post_* fields */
 int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
-                    float* out, int64_t ld_out, void* stream);
+                    float* out, int64_t ld_out, int products /*0 = process default, or 6 / 1 / 2*/, void* stream);
 /* The same launch, which also sets zero_rows[i][0..128) = 0 for i < M (nullable; leading dimension ld_zero >= 128, a multiple of
  * 4; 16-byte aligned): an edge block needs its node-level pre-projection AND a zero-filled aggregate buffer over the same node
  * rows (hgn_mlp_fwd_t.seg_out) -- one pass over the rows instead of a launch of its own for the fill. */
 int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
-                     float* out, int64_t ld_out, float* zero_rows, int64_t ld_zero, void* stream);
+                     float* out, int64_t ld_out, float* zero_rows, int64_t ld_zero, int products, void* stream);
 
 /* Backward data-gradient chain of the same MLP (LayerNorm bwd -> W3^T -> relu' -> W2^T -> relu' -> W1^T).
  * Writes dz3, dz2, dz1 ([M,128], consumed by hgn_mlp_wgrad and, for the pre-projected addends, by the
@@ -229,13 +238,14 @@ typedef struct {
   /* optional, split-bf16 kernel only: seg_dz1[seg_ids[i]][0..128) += dz1[i]  (same contract as hgn_mlp_fwd_t.seg_out): the
    * receiver half of the pre-projection gradient of the split edge layer, without re-reading dz1 */
   float* seg_dz1; int64_t ld_seg_dz1; const int32_t* seg_ids;
+  int32_t products; int32_t flags;          /* per-call options, as in hgn_mlp_fwd_t (backward products: 6, or 1 in both reduced modes) */
 } hgn_mlp_bwd_t;
 
 int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes /*host*/);
 int hgn_mlp_bwd(const hgn_mlp_bwd_t* args /*host*/, void* stream);
 int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* args /*host*/);   /* 1 if hgn_mlp_bwd will take the split-bf16 kernel */
 int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* packed_blocks_t /*host array, transposed form*/,
-                    int n_blocks, float* dx, int64_t ld_dx, void* stream);
+                    int n_blocks, float* dx, int64_t ld_dx, int products, void* stream);
 
 /* Edge-block backward with the weight gradients of the two inner layers in the SAME pass (csrc/fused_bwd.hip): autograd of
  * GraphNet._update_edge_features (graphnet.py:22-32) for one edge set -- everything hgn_mlp_bwd computes for an edge block
@@ -272,6 +282,7 @@ typedef struct {
   float* dW; int64_t ldw;   /* type 0: &dW1[0][col0], leading dim; type 1: dgamma        */
   float* db;                /* nullable; type 1: dbeta                                   */
   int32_t accumulate;       /* 0: dW = result, 1: dW += result                           */
+  int32_t products; int32_t flags;   /* per-call options as in hgn_mlp_fwd_t; all tasks of one launch must agree (task 0 decides)  */
 } hgn_wtask_t;
 
 int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes /*host*/);

@@ -191,7 +191,7 @@ def test_latency_form_forward_equals_the_throughput_kernels_bit_for_bit(widths):
 
 
 @pytest.mark.parametrize('agg', [('sum',), ('sum', 'mean', 'max', 'min'), None], ids=['sum_in_kernel', 'pna', 'no_aggregate'])
-def test_training_edge_forward_kernel_equals_the_general_kernel_bit_for_bit(agg, monkeypatch):
+def test_training_edge_forward_kernel_equals_the_general_kernel_bit_for_bit(agg):
     """Training edge blocks of >= 98 304 rows run mlp6_fwd_edge_kernel (csrc/mlp6.hip): the general 128-row kernel with everything it
     decides at run time decided at launch (32-bit row offsets from scalar bases, no per-row store tests except in the launch's last
     tile, three-instruction ReLU + sign words).  Same products, same order, same row sums: outputs, in-kernel segment sums, every
@@ -223,9 +223,8 @@ def test_training_edge_forward_kernel_equals_the_general_kernel_bit_for_bit(agg,
         return [y.detach(), a_.detach() if a_ is not None else None] + saves + [h.grad, e.grad] + [p_.grad.clone() for p_ in w.tensors()]
 
     fast = run()
-    monkeypatch.setenv('HGN_NO_EDGE_FWD', '1')
-    general = run()
-    monkeypatch.delenv('HGN_NO_EDGE_FWD')
+    with ops.using(ops.Context(general_fwd=True)):              # hgn_mlp_fwd_t.flags: HGN_F_GENERAL_FWD for these calls only
+        general = run()
     assert len(fast) == len(general) and len(fast) >= 2 + 5 + 2 + 8
     for i, (a_, b_) in enumerate(zip(fast, general)):
         assert (a_ is None) == (b_ is None), i
@@ -269,7 +268,7 @@ def test_pre_projection_forms_agree_bit_for_bit():
     outs = {}
     for N in (1000, 4096, 9000, 20000):
         P = torch.empty(N, 256, device='cuda')
-        _lib.check(L.hgn_linear_fwd6(h.data_ptr(), 128, N, pb, 2, P.data_ptr(), 256, _lib.stream_ptr()), 'hgn_linear_fwd6')
+        _lib.check(L.hgn_linear_fwd6(h.data_ptr(), 128, N, pb, 2, P.data_ptr(), 256, 0, _lib.stream_ptr()), 'hgn_linear_fwd6')
         outs[N] = P
     for N in (4096, 9000, 20000):
         assert torch.equal(outs[N][:1000], outs[1000]), N
@@ -1270,7 +1269,7 @@ def test_deferred_node_level_weight_gradients_match_immediate_launches():
         finally:
             ops.prof_enable(False)
             ops._DEFER_NODE_WGRAD = old
-        assert not ops._wq                                   # nothing left behind after backward()
+        assert not tr.ctx.wq                                 # nothing left behind after backward()
         grads[defer], launches[defer] = tr.fp.grad.clone(), k['wgrad_node']['count']
     assert launches[True] * 2 <= launches[False], launches
     assert H.rel_err(grads[True], grads[False]) <= 1e-6
@@ -1309,7 +1308,7 @@ def test_shared_weight_gradient_targets_through_the_flat_gradient_trainer(arch):
             tr.step(G, target.cuda(), mask.cuda())
         finally:
             ops._DEFER_NODE_WGRAD = old
-        assert not ops._wq
+        assert not tr.ctx.wq
         runs.append(tr.fp.grad.clone())
     assert torch.equal(runs[0], runs[1])
     assert H.rel_err(runs[0], runs[2]) <= 1e-6
@@ -1354,10 +1353,50 @@ def test_failed_backward_leaves_no_stale_weight_gradient_tasks():
     out = tr.model(hgn_amd.MultiGraph(feats, G.edge_sets))
     with pytest.raises(RuntimeError, match='boom'):
         ((out - target) * mask.unsqueeze(1)).square().sum().backward()
-    assert sum(len(q[0]) for q in ops._wq.values()) > 0          # the failed run left its tasks behind
+    assert sum(len(q[0]) for q in tr.ctx.wq.values()) > 0        # the failed run left its tasks behind
     for x in G.node_features:
         x.requires_grad_(False)
     tr.step(G, target, mask)
-    assert not ops._wq
+    assert not tr.ctx.wq
     torch.cuda.synchronize()
     assert torch.equal(tr.fp.grad, good)
+
+
+def test_two_models_with_different_precisions_interleaved_equal_their_solo_runs():
+    """Two models in one process, one fp32-accurate and one in the reduced 'bf16' mode, trained step by step IN TURN: every launch
+    carries its model's own precision and flags in its argument struct and its own ops.Context holds queue / packs / workspaces, so
+    each model's losses and parameters equal, bit for bit, those of the same model trained alone."""
+    import hgn_amd
+    from hgn_amd import parallel
+    graph = synth.grid_graph(seed=5, nx=14, ny=11, clusters=3)
+    sets = [e.name for e in graph.edge_sets]
+    shapes = O.param_shapes('hyper', 'pna', 2, sets, 5, {n: 7 for n in sets}, 8, 3, 128)
+    G = hgn_amd.MultiGraph([x.cuda() for x in graph.node_features],
+                           [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in graph.edge_sets])
+    N = graph.node_features[0].shape[0]
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    mask = torch.ones(N, dtype=torch.bool).cuda()
+
+    def make(seed, mode):
+        m = H.hip_model('hyper', 'pna', 2, sets, O.init_state_dict_like(shapes, seed=seed))
+        m.set_matmul_precision(mode)
+        return parallel.DataParallelTrainer(m, lr=1e-3)
+
+    def solo(seed, mode, steps=3):
+        tr = make(seed, mode)
+        losses = [tr.step(G, target, mask).clone() for _ in range(steps)]
+        return losses, tr.fp.flat.clone()
+
+    solo_a, solo_b = solo(1, None), solo(2, 'bf16')
+    ta, tb = make(1, None), make(2, 'bf16')
+    la, lb = [], []
+    for _ in range(3):
+        la.append(ta.step(G, target, mask).clone())
+        lb.append(tb.step(G, target, mask).clone())
+    assert all(torch.equal(x, y) for x, y in zip(la, solo_a[0])) and torch.equal(ta.fp.flat, solo_a[1])
+    assert all(torch.equal(x, y) for x, y in zip(lb, solo_b[0])) and torch.equal(tb.fp.flat, solo_b[1])
+    assert not torch.equal(solo_a[0][0], solo_b[0][0])
+    assert hgn_amd.get_matmul_precision() == 'fp32'            # the process default was never touched
+    # ... and the reduced mode really was in effect for model b only: a's result equals the fp32-accurate run of the same weights
+    tc = make(2, None)
+    assert not torch.equal(tc.step(G, target, mask), solo_b[0][0])

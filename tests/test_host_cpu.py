@@ -34,10 +34,10 @@ def test_abi_struct_sizes_match_header_layout():
     """ctypes mirrors of the C structs: sizes follow the header's field lists under the x86-64 SysV ABI."""
     from hgn_amd import _lib
     assert C.sizeof(_lib.Src) == 48 and C.sizeof(_lib.Add) == 24 and C.sizeof(_lib.Dx) == 48
-    assert C.sizeof(_lib.WTask) == 96
-    assert C.sizeof(_lib.MlpFwd) == 8 + 8 + 8 * 48 + 8 + 2 * 24 + 8 * 6 + 8 + 8 * 2 + 8 * 2 + 8 * 2 + 8 * 4 + 8 * 2 + 8 + 24 + (4 * 8 + 8 + 8 + 8 + 8 + 8)
+    assert C.sizeof(_lib.WTask) == 96 + 8                 # + per-call options: products, flags
+    assert C.sizeof(_lib.MlpFwd) == 8 + 8 + 8 * 48 + 8 + 2 * 24 + 8 * 6 + 8 + 8 * 2 + 8 * 2 + 8 * 2 + 8 * 4 + 8 * 2 + 8 + 24 + (4 * 8 + 8 + 8 + 8 + 8 + 8) + 8
     assert C.sizeof(_lib.Pack) == 40
-    assert C.sizeof(_lib.MlpBwd) == 8 + 8 + 8 + 8 + 8 * 7 + 8 + 8 * 3 + 8 + 8 * 48 + (8 + 8 + 4 + 16 + 4) + 8 * 4 + 8 * 3 + 8 + 8 * 2 + 8 + 24
+    assert C.sizeof(_lib.MlpBwd) == 8 + 8 + 8 + 8 + 8 * 7 + 8 + 8 * 3 + 8 + 8 * 48 + (8 + 8 + 4 + 16 + 4) + 8 * 4 + 8 * 3 + 8 + 8 * 2 + 8 + 24 + 8
 
 
 def test_abi_argument_validation_without_gpu():
@@ -587,3 +587,61 @@ def test_hdbscan_clustering_host_logic():
     cfg['rmp']['intra_cluster_sampling']['enabled'] = True
     with pytest.raises(NotImplementedError, match='condensed tree'):
         rmp.get_clustering_algorithm('hdbscan', cfg).run(graph)
+
+
+def test_two_contexts_with_different_precisions_from_two_threads_through_the_abi():
+    """"no global mutable state, re-entrant".  Precision and kernel-selection flags travel IN every argument
+    struct (hgn_mlp_fwd_t / hgn_mlp_bwd_t / hgn_wtask_t: products, flags; hgn_linear_*6: a parameter); what a launch depends on
+    besides its arguments lives in a per-model ops.Context (deferred weight-gradient queue, pack epoch, workspaces).  Two threads
+    drive two contexts with different precisions through the ABI's validation path at the same time (no GPU: every call stops at
+    argument validation, AFTER the per-call options were read): each sees its own products / flags, its own error text, and the
+    process default is untouched."""
+    import threading
+    from hgn_amd import _lib, ops
+    lib = _lib.lib()
+    assert lib.hgn_get_matmul_products() == 6
+    results, errors = {}, []
+
+    def drive(name, ctx, want_products, n=300):
+        try:
+            with ops.using(ctx):
+                for i in range(n):
+                    c = ops.current()
+                    assert c is ctx
+                    a = _lib.MlpFwd()
+                    c.stamp(a)
+                    assert (a.products, a.flags) == (want_products, ctx.flags())
+                    a.M = 5
+                    a.out_w = 500                                   # invalid on purpose: the call answers with a status code
+                    assert lib.hgn_mlp_fwd(C.byref(a), None) == -1 and b'out_w' in lib.hgn_last_error()      # thread-local text
+                    a.products = 3                                  # not a mode: refused before anything else
+                    assert lib.hgn_mlp_fwd(C.byref(a), None) == -1 and b'products' in lib.hgn_last_error()
+                    t = _lib.WTask()
+                    c.stamp(t)
+                    assert t.products == want_products
+                    b = _lib.MlpBwd()
+                    c.stamp(b)
+                    b.M = 4; b.products = 7
+                    assert lib.hgn_mlp_bwd(C.byref(b), None) == -1 and b'products' in lib.hgn_last_error()
+                    assert lib.hgn_linear_fwd6(None, 128, 4, None, 2, None, 128, 9, None) == -1
+                    c.invalidate_packs()
+            results[name] = (ctx.pack_epoch, ctx.products())
+        except Exception as ex:            # noqa: BLE001 -- reported by the main thread
+            errors.append((name, repr(ex)))
+
+    a_ctx, b_ctx = ops.Context(precision='fp16'), ops.Context(precision='bf16', fp32_mfma=False, general_fwd=True)
+    ts = [threading.Thread(target=drive, args=('a', a_ctx, 2)), threading.Thread(target=drive, args=('b', b_ctx, 1))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert results == {'a': (300, 2), 'b': (300, 1)}
+    assert ops.current() is ops.default_context() and ops.default_context().products() == 6 and lib.hgn_get_matmul_products() == 6
+    assert b_ctx.flags() == _lib.F_GENERAL_FWD and a_ctx.flags() == ops.default_context().flags()
+    import hgn_amd
+    m1 = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges'])
+    m2 = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges'])
+    assert m1._hgn_ctx is not m2._hgn_ctx and m1._hgn_ctx.wq is not m2._hgn_ctx.wq
+    m2.set_matmul_precision('bf16')
+    assert (m1._hgn_ctx.products(), m2._hgn_ctx.products()) == (6, 1)

@@ -41,6 +41,5 @@ def run(tag):
 for rep in range(a.reps):
     run('dbg ' + os.environ.get('HGN_FUSED_DBG', '0'))
     if a.ab_edge_fwd:                    # the general forward kernel on the same box, same process (csrc/mlp6.hip: edge_block_shape)
-        os.environ['HGN_NO_EDGE_FWD'] = '1'
-        run('general-forward-kernel')
-        del os.environ['HGN_NO_EDGE_FWD']
+        with ops.using(ops.Context(general_fwd=True)):
+            run('general-forward-kernel')

@@ -494,7 +494,7 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   fa.tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   fa.dbg = 0;
   ProfScope ps(14, (double)a->M, stream);
-  if (bwd_products() == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  if (bwd_products(a->products) == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1, 0>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
   else {
 #if HGN_LAB   // laboratory build only: compile-time ablation instantiations (HGN_FUSED_DBG), one ablation each
     static const int dbg = getenv("HGN_FUSED_DBG") ? atoi(getenv("HGN_FUSED_DBG")) : 0;

@@ -360,7 +360,7 @@ static bool ws_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 // pre-projections, packed W2 / W3, LayerNorm, 128-wide output, six-product arithmetic.
 extern "C" int hgn_mlp_fwd_ws_eligible(const hgn_mlp_fwd_t* a) {
   static const bool off = getenv("HGN_NO_WS_FWD") != nullptr || getenv("HGN_FP32_MFMA") != nullptr;
-  if (off || !a || !hgn_mlp_fwd6_eligible(a) || matmul_products() != 6) return 0;
+  if (off || !a || !hgn_mlp_fwd6_eligible(a) || matmul_products(a->products) != 6) return 0;
   if (a->n_src != 1 || a->src[0].K != 128 || a->src[0].idx || (a->src[0].ld & 3) || !ws_aligned16(a->src[0].x)) return 0;
   if (a->n_add < 0 || a->n_add > 2 || !a->ln_g || !a->ln_b || a->out_w != 128) return 0;
   for (int i = 0; i < a->n_add; ++i)
