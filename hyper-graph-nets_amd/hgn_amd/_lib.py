@@ -198,3 +198,19 @@ def require_gpu(t):
     if not t.is_cuda:
         raise HgnError('the hgn_amd product path runs on an MI355X (HIP) device only; got a CPU tensor. '
                        'There is no CPU fallback.')
+
+
+def _nothing():
+    return None
+
+
+class Volatile(tuple):
+    """A cache entry hung on a tensor as an attribute (topologies on index tensors, packed weight images on parameters).  Tensor
+    attributes travel in pickles (the reference checkpoints with pickle.dump of the whole model, MeshSimulator.py:492-493): an entry
+    of this type pickles as None -- the copy rebuilds its caches -- instead of dragging device buffers, or failing on a weakref."""
+
+    def __reduce__(self):
+        return (_nothing, ())
+
+    def __deepcopy__(self, memo):
+        return None

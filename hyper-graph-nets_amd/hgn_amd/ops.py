@@ -281,7 +281,7 @@ def packs_of(w: MLPWeights, transposed: bool = False, ctx: Optional[Context] = N
         _lib.check(_lib.lib().hgn_pack_bf16x3(C.cast(C.byref(arr, i0 * C.sizeof(_lib.Pack)), C.POINTER(_lib.Pack)), cnt,
                                               _lib.stream_ptr()), 'hgn_pack_bf16x3')
     try:
-        setattr(w.w1, attr, (key, buf))
+        setattr(w.w1, attr, _lib.Volatile((key, buf)))
     except Exception:
         pass
     return buf

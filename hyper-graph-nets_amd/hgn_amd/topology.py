@@ -161,7 +161,7 @@ def edge_topology(senders: torch.Tensor, receivers: torch.Tensor, num_nodes: int
         if pkey is not None:
             _store(pkey, topo)
     try:
-        setattr(receivers, _CACHE_ATTR, (okey, topo, weakref.ref(senders)))
+        setattr(receivers, _CACHE_ATTR, _lib.Volatile((okey, topo, weakref.ref(senders))))
     except Exception:
         pass
     return topo
@@ -174,7 +174,7 @@ def segment_csr(segment_ids: torch.Tensor, num_segments: int, device) -> CSR:
         return cached[1]
     csr = CSR(segment_ids.to(device), num_segments)
     try:
-        setattr(segment_ids, '_hgn_csr', (key, csr))
+        setattr(segment_ids, '_hgn_csr', _lib.Volatile((key, csr)))
     except Exception:
         pass
     return csr
