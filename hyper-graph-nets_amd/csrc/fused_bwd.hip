@@ -99,14 +99,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) { return opaque_u(v); }
 // statement outside the compiler's s_waitcnt bookkeeping; completion: a counted vmcnt of the issuing wave, then a barrier)
 
 __device__ __forceinline__ void split3v8(const float (&v)[8], bf16x8 (&s)[3]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)v[j];
-    const float r1 = v[j] - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    s[0][j] = h; s[1][j] = m; s[2][j] = (__bf16)r2;
-  }
+  hgn_split::eight(v, s);
 }
 
 // ---- the G image (dz3 / dz2 as weight-gradient operand): ROW-MAJOR bf16, [split][row 0..63][feature 0..127], 256-byte rows whose
@@ -296,7 +289,7 @@ template <int NP> struct Ring { static constexpr int DPW = NP == 1 ? 2 : 6; };
 
 template <int Q, int NP>
 __device__ __forceinline__ void dma_piece(const __bf16* __restrict__ pk3, const __bf16* __restrict__ pk2, const __bf16* __restrict__ pk1,
-                                          unsigned lds_base, unsigned ww, unsigned voff /*16 * lane*/) {
+                                          unsigned lds_base, unsigned ww, unsigned voff /*dma_lane_off*/) {
   constexpr int layer = Q / 4, c = Q % 4, half = c >> 1, cl = c & 1, slot = Q % 3;
   const __bf16* blk = layer == 0 ? pk3 : (layer == 1 ? pk2 : pk1);
   // tile (split 0, output block ww) of contraction block c: uniform -> a scalar register pair
@@ -390,7 +383,7 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
     if constexpr (P == 1 || P == 6) publish(xb);
     if constexpr (P == 4 || P == 11) publish(xa);
     FSTAMP(1, 4 * P + 2);
-    dma_piece<(P + 2) % 12, NP>(pk3, pk2, pk1, lds_base, ww, opaque((unsigned)lane * 16u));
+    dma_piece<(P + 2) % 12, NP>(pk3, pk2, pk1, lds_base, ww, dma_lane_off((unsigned)lane));
     if constexpr (P == 1 && !(HGN_FEXP & 2)) fetch(xb, 1, tile, 1);
     if constexpr (P == 4 && !(HGN_FEXP & 2)) fetch(xa, 0, tile + 1, 0);     // (past the last tile: clamped rows -- keeps the operation counts static)
     if constexpr (P == 6 && !(HGN_FEXP & 2)) fetch(xb, 0, tile + 1, 1);
@@ -405,9 +398,9 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
   // fetch z1 rows 0-31 (so that the first barrier's count is the steady-state one)
   fetch(xa, 0, t_beg, 0);
   fetch(xb, 0, t_beg, 1);
-  dma_piece<0, NP>(pk3, pk2, pk1, lds_base, ww, (unsigned)lane * 16u);
+  dma_piece<0, NP>(pk3, pk2, pk1, lds_base, ww, dma_lane_off((unsigned)lane));
   publish(xa);
-  dma_piece<1, NP>(pk3, pk2, pk1, lds_base, ww, (unsigned)lane * 16u);
+  dma_piece<1, NP>(pk3, pk2, pk1, lds_base, ww, dma_lane_off((unsigned)lane));
   fetch(xa, 1, t_beg, 0);
   bar_lds();                                          // (S)
   for (long tile = t_beg; tile < t_end; ++tile) {

@@ -391,18 +391,12 @@ __global__ __launch_bounds__(WG, 2) void mlp6_fwd_edge_kernel(const hgn_mlp_fwd_
 // that need either take mlp6_fwd_kernel<1, NP, 4 + LAT_LOADERS>.
 template <int NP>
 __device__ __forceinline__ void cs_split8(const f32x4& v0, const f32x4& v1, bf16x8 (&o)[3]) {
+  const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  if constexpr (NP == 2) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = j < 4 ? v0[j & 3] : v1[j & 3];
-    if constexpr (NP == 2) {
-      o[0][j] = __builtin_bit_cast(__bf16, (_Float16)v);
-    } else {
-      const __bf16 h = (__bf16)v;
-      const float r1 = v - (float)h;
-      const __bf16 m = (__bf16)r1;
-      const float r2 = r1 - (float)m;
-      o[0][j] = h; o[1][j] = m; o[2][j] = (__bf16)r2;
-    }
+    for (int j = 0; j < 8; ++j) o[0][j] = __builtin_bit_cast(__bf16, (_Float16)v[j]);
+  } else {
+    hgn_split::eight(v, o);
   }
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include "hgn_device.h"
 #include "mlp_common.h"
+#include "split_bf16.h"
 
 // Diagnostic builds only (tools/build_ablations.sh): compile-time ablation mask of the split-bf16 edge kernels.
 //   1 no weight DMA   2 no MFMA   4 no stores of saved activations / intermediate gradients   8 no row loads
@@ -45,16 +46,13 @@ constexpr int BLOCK_BF16 = 2 * HALF_BF16;          // one packed 128 x 128 block
 // ----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void split3(const Act& x, bf16x8 (&s)[3][4]) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = x.v[2 * c + (j >> 2)][j & 3];
-      const __bf16 h = (__bf16)v;
-      const float r1 = v - (float)h;
-      const __bf16 m = (__bf16)r1;
-      const float r2 = r1 - (float)m;
-      s[0][c][j] = h; s[1][c][j] = m; s[2][c][j] = (__bf16)r2;
-    }
+  for (int c = 0; c < 4; ++c) {                     // csrc/split_bf16.h: two values per instruction
+    const f32x4 &q0 = x.v[2 * c], &q1 = x.v[2 * c + 1];
+    const float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+    bf16x8 t[3];
+    hgn_split::eight(v, t);
+    s[0][c] = t[0]; s[1][c] = t[1]; s[2][c] = t[2];
+  }
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -294,26 +292,31 @@ __device__ __forceinline__ void wait_vm_keep() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
 }
 
-// The LDS-DMA of one piece by one of the four waves that share it (global_load_lds_dwordx4: lane l copies 16 bytes from sbase + voff(l)
-// to M0 + 16 l; 1 KiB per instruction).  Wave ww copies operand tiles ww + 4 k, k = 0..5, i.e. split k / 2, output block ww + 4 (k & 1):
-// in the packed block those lie (16 (k / 2) + 4 (k & 1)) KiB behind tile (split 0, output block ww), in the slot 4 k KiB.  M0 is written
-// in the statement that reads it and declared clobbered, like SCC (s_add_u32).  NP != 6: only the leading split is staged.
+// The LDS-DMA of one piece by one of the four waves that share it (global_load_lds_dwordx4: lane l copies 16 bytes from
+// sbase + voff(l) + imm to M0 + imm + 16 l; 1 KiB per instruction -- the immediate offset applies to BOTH addresses).  Wave ww copies
+// operand tiles ww + 4 k, k = 0..5, i.e. split k / 2, output block ww + 4 (k & 1): in the packed block those lie
+// (16 (k / 2) + 4 (k & 1)) KiB behind tile (split 0, output block ww), in the slot 4 k KiB.  The two tiles of a split are 4 KiB apart
+// on both sides, so one M0 and one scalar base serve both with immediates -2 KiB / +2 KiB around a lane offset that carries +2 KiB
+// (dma_lane_off): no vector instruction per DMA.  M0 is written in the statement that reads it and declared clobbered, like SCC
+// (s_add_u32); one wait state between an M0 write and the DMA that reads it.  NP != 6: only the leading split is staged.
+__device__ __forceinline__ unsigned dma_lane_off(unsigned lane) { return opaque_u(lane * 16u + 0x800u); }
+
 template <int NP>
-__device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: source of tile (0, ww)*/, unsigned voff /*16 * lane*/,
+__device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: source of tile (0, ww)*/, unsigned voff /*dma_lane_off*/,
                                            unsigned lds_dst /*wave-uniform: LDS byte address of tile (0, ww) in the slot*/) {
-  unsigned t;
-  if (NP != 6)
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
-                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc", "m0");
-  else
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x1000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x4000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x5000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x8000, %1\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %0, 0x9000, %1\n\tglobal_load_lds_dwordx4 %0, %2"
-                 : "=&v"(t) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "scc", "m0");
+  const unsigned m0v = lds_dst + 0x800u;
+  if (NP != 6) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
+                 : : "v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
+  } else {
+    asm volatile("" : "+s"(sbase));                  // the two bases below are made here (four scalar adds), not kept in registers per piece
+    const void* s1 = static_cast<const unsigned char*>(sbase) + 0x4000;
+    const void* s2 = static_cast<const unsigned char*>(sbase) + 0x8000;
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:-2048\n\tglobal_load_lds_dwordx4 %0, %2 offset:2048\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3 offset:-2048\n\tglobal_load_lds_dwordx4 %0, %3 offset:2048"
+                 : : "v"(voff), "s"(sbase), "s"(s1), "s"(s2), "s"(m0v) : "memory", "scc", "m0");
+  }
 }
 // piece c (contraction block) of the packed block `blk` -> ring slot `slot` of the ring at LDS byte address lds_base
 template <int NP>
@@ -406,29 +409,29 @@ __device__ __forceinline__ void gemm6q(Act (&acc)[NS], Act (&b)[NS], __bf16* __r
   const unsigned char* ring = reinterpret_cast<const unsigned char*>(lds);
   if (first) {
     wg_barrier_lds();
-    dma_piece6<NP>(pk, 0, lds_base, 0, ww, opaque_u(lane * 16u));
+    dma_piece6<NP>(pk, 0, lds_base, 0, ww, dma_lane_off(lane));
   }
   between();
   if constexpr (!PREWAITED) gemm6q_landed<NS, 0>(acc, b);
   __builtin_amdgcn_s_barrier();                     // ---- piece 0 has landed for every wave; slot 1 is free
-  dma_piece6<NP>(pk, 1, lds_base, 1, ww, opaque_u(lane * 16u));
+  dma_piece6<NP>(pk, 1, lds_base, 1, ww, dma_lane_off(lane));
 #pragma unroll
   for (int u = 0; u < NS; ++u) split_np<NP>(b[u], xs[u]);
   at_piece(0, b);
   sweep_piece6<0, NS, NP>(acc, xs, ring + opaque_u(lane * 16u));
   wait_vm_keep<KEEP1>();
   __builtin_amdgcn_s_barrier();                     // ---- piece 1 landed; every wave is done with slot 0
-  dma_piece6<NP>(pk, 2, lds_base, 0, ww, opaque_u(lane * 16u));
+  dma_piece6<NP>(pk, 2, lds_base, 0, ww, dma_lane_off(lane));
   at_piece(1, b);
   sweep_piece6<1, NS, NP>(acc, xs, ring + opaque_u(lane * 16u + PIECE_BYTES6));
   wait_vm_keep<KEEP2>();
   __builtin_amdgcn_s_barrier();                     // ---- piece 2 landed; slot 1 free
-  dma_piece6<NP>(pk, 3, lds_base, 1, ww, opaque_u(lane * 16u));
+  dma_piece6<NP>(pk, 3, lds_base, 1, ww, dma_lane_off(lane));
   at_piece(2, b);
   sweep_piece6<2, NS, NP>(acc, xs, ring + opaque_u(lane * 16u));
   wait_vm_keep<KEEP3>();
   __builtin_amdgcn_s_barrier();                     // ---- piece 3 landed; slot 0 free
-  if (pk_next) dma_piece6<NP>(pk_next, 0, lds_base, 0, ww, opaque_u(lane * 16u));
+  if (pk_next) dma_piece6<NP>(pk_next, 0, lds_base, 0, ww, dma_lane_off(lane));
   at_piece(3, b);
   sweep_piece6<3, NS, NP>(acc, xs, ring + opaque_u(lane * 16u + PIECE_BYTES6));
 }

@@ -1,0 +1,38 @@
+// The three-term bf16 split of fp32 operands (x = hi + mid + lo, each term round-to-nearest-even of the remainder before it), two
+// values at a time: v_cvt_pk_bf16_f32 converts a pair, the pair's fp32 images come back with one shift and one mask, and the
+// remainders are one v_pk_add_f32.  Nine VALU instructions per pair (4.5 per value; the element-wise form the compiler was given
+// before cost 6.7), same bits: the conversions are the same RNE conversions and the subtractions are exact in fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hgn_split {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const f2 x = {x0, x1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, b2));
+  const f2 h = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  const f2 r1 = x - h;
+  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, b2));
+  const f2 m = {__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
+  const f2 r2 = r1 - m;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b2));
+}
+
+// eight values -> the three operand vectors (element j of each vector belongs to v[j])
+__device__ __forceinline__ void eight(const float (&v)[8], b8 (&s)[3]) {
+  u4 w[3];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned a, b, c;
+    pair(v[2 * p], v[2 * p + 1], a, b, c);
+    w[0][p] = a; w[1][p] = b; w[2][p] = c;
+  }
+  s[0] = __builtin_bit_cast(b8, w[0]); s[1] = __builtin_bit_cast(b8, w[1]); s[2] = __builtin_bit_cast(b8, w[2]);
+}
+
+}  // namespace hgn_split

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "hgn_host.h"
+#include "split_bf16.h"
 
 namespace hgn {
 
@@ -251,14 +252,7 @@ __device__ __forceinline__ void wg_dma_issue6(float* __restrict__ slotA, float* 
 }
 
 __device__ __forceinline__ void split3v(const float (&v)[8], bf16x8 (&s)[3]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)v[j];
-    const float r1 = v[j] - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    s[0][j] = h; s[1][j] = m; s[2][j] = (__bf16)r2;
-  }
+  hgn_split::eight(v, s);
 }
 
 #if HGN_LAB   // the previous split-bf16 weight-gradient kernel: laboratory build only (HGN_WGRAD_RESPLIT=1)
