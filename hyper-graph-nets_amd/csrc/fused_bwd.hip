@@ -536,15 +536,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
         }
         HGN_FOR_B(fb) g.v[fb] = geff.v[fb] * *reinterpret_cast<const f32x4*>(lng + 16 * fb + 4 * kq);
         const float m1 = row_sum(g) * (1.f / LAT);
-        float q0 = 0.f, q1 = 0.f;
-        HGN_FOR_B(fb) {
-          q0 += g.v[fb][0] * xh.v[fb][0] + g.v[fb][1] * xh.v[fb][1];
-          q1 += g.v[fb][2] * xh.v[fb][2] + g.v[fb][3] * xh.v[fb][3];
-        }
-        float qs = q0 + q1;
-        qs += __shfl_xor(qs, 16);
-        qs += __shfl_xor(qs, 32);
-        const float m2 = qs * (1.f / LAT);
+        const float m2 = row_dot(g, xh) * (1.f / LAT);
         const float r = pf_rstd;
         HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - xh.v[fb] * m2);
       }

@@ -294,10 +294,10 @@ __device__ __forceinline__ void t_zero(Act& a) {
 // Sum of x over the 16 lanes of a DPP row (= the 16 rows n of one k-quarter): four rotate-and-add steps on the VALU
 // (v_add_f32 with row_ror DPP control), no LDS crossbar traffic; every lane of the row ends with the full sum.
 __device__ __forceinline__ float row16_sum(float x) {
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));   // row_ror:4
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false));   // row_ror:2
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false));   // row_ror:1
+  x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x128, 0xf, 0xf, true));   // row_ror:8
+  x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x124, 0xf, 0xf, true));   // row_ror:4
+  x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x122, 0xf, 0xf, true));   // row_ror:2
+  x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x121, 0xf, 0xf, true));   // row_ror:1
   return x;
 }
 
@@ -305,31 +305,49 @@ __device__ __forceinline__ float row16_sum(float x) {
 // of four steps a lane keeps half of its values, hands the other half to a partner lane and adds what the partner hands back, so that
 // afterwards lane n holds 2 of the 32 sums -- those of values j = 2 n, 2 n + 1 of the numbering j = 4 fb + w, i.e. of
 //   fb = n >> 1,  w = 2 (n & 1) + {0, 1}      (feature 16 fb + 4 kq + w).
-// 3 instructions per output (two selects by a lane-bit mask, one add with a DPP operand): 90 for the 32 sums, against 8 per VALUE
-// (row16_sum on every value, 256 + moves) for sums that every lane then holds sixteen-fold.  Partners: lane ^ 8 (row_ror:8), 7 - lane
-// within the half (row_half_mirror), lane ^ 2, lane ^ 1 (quad_perm) -- each flips the bit the step selects by and keeps the higher ones.
+// Partners: lane ^ 8 (row_ror:8), 7 - lane within the half (row_half_mirror), lane ^ 2, lane ^ 1 (quad_perm) -- each flips the bit the
+// step selects by and keeps the higher ones.  Steps 1 and 2 select by lane bits 3 and 2, which the DPP bank mask can express (a bank =
+// four lanes of a row): out = lo + partner's lo, written in the lanes whose bit is 0, then out = hi + partner's hi in the others -- two
+// write-masked v_add_f32_dpp per output and no select (bfly8, inline assembly: the compiler has no form for a DPP add that keeps other
+// lanes of its destination).  Steps 3 and 4 select inside a quad: two v_cndmask and one add with a DPP operand per output.
+// 50 + 18 instructions for the 32 sums, against 8 per VALUE (row16_sum on every value) for sums that every lane then holds sixteen-fold.
+// The assembly's operands must be VALU results (the hazard recogniser does not look into inline assembly: the block opens with the two
+// wait states a DPP read of a fresh VALU result needs; a matrix-pipe result would need more).
+#define HGN_BFLY_ROW(o, a, CTRL, MASK) "v_add_f32_dpp %" #o ", %" #a ", %" #a " " CTRL " row_mask:0xf bank_mask:" MASK "\n\t"
+#define HGN_BFLY8(CTRL, MLO, MHI)                                                                                              \
+  asm("s_nop 1\n\t"                                                                                                            \
+      HGN_BFLY_ROW(0, 8, CTRL, MLO) HGN_BFLY_ROW(1, 9, CTRL, MLO) HGN_BFLY_ROW(2, 10, CTRL, MLO) HGN_BFLY_ROW(3, 11, CTRL, MLO)     \
+      HGN_BFLY_ROW(4, 12, CTRL, MLO) HGN_BFLY_ROW(5, 13, CTRL, MLO) HGN_BFLY_ROW(6, 14, CTRL, MLO) HGN_BFLY_ROW(7, 15, CTRL, MLO)   \
+      HGN_BFLY_ROW(0, 16, CTRL, MHI) HGN_BFLY_ROW(1, 17, CTRL, MHI) HGN_BFLY_ROW(2, 18, CTRL, MHI) HGN_BFLY_ROW(3, 19, CTRL, MHI)   \
+      HGN_BFLY_ROW(4, 20, CTRL, MHI) HGN_BFLY_ROW(5, 21, CTRL, MHI) HGN_BFLY_ROW(6, 22, CTRL, MHI) HGN_BFLY_ROW(7, 23, CTRL, MHI)   \
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])                 \
+      : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]),                        \
+        "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]))
+// o[k] = lo[k] + partner's lo[k] in the lanes whose selecting bit is 0, hi[k] + partner's hi[k] in the others
+template <int BIT>
+__device__ __forceinline__ void bfly8(const float (&lo)[8], const float (&hi)[8], float (&o)[8]) {
+  static_assert(BIT == 3 || BIT == 2, "bank masks select by lane bits 3 and 2 only");
+  if constexpr (BIT == 3) HGN_BFLY8("row_ror:8", "0x3", "0xc");
+  else HGN_BFLY8("row_half_mirror", "0x5", "0xa");
+}
+
 __device__ __forceinline__ void row16_sums_transposed(const Act& a, float (&out)[2]) {
   const int lane = threadIdx.x & 63;
-  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
-  auto dpp = [](float x, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false)); };
-  float s16[4][4], s8[2][4], s4[4];
+  const bool b1 = lane & 2, b0 = lane & 1;
+  // (every lane has a partner under these controls: no `old` value to keep, so none is materialised)
+  auto dpp = [](float x, auto ctrl) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true)); };
+  float s16[2][8], s8[8], s4[4];
 #pragma unroll
-  for (int fb = 0; fb < 4; ++fb)
+  for (int h = 0; h < 2; ++h) {                       // values of feature blocks 2 h, 2 h + 1 with those of 2 h + 4, 2 h + 5
+    float lo[8], hi[8];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float lo = a.v[fb][w], hi = a.v[fb + 4][w];
-      s16[fb][w] = (b3 ? hi : lo) + dpp(b3 ? lo : hi, std::integral_constant<int, 0x128>{});      // row_ror:8
-    }
-#pragma unroll
-  for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float lo = s16[fb][w], hi = s16[fb + 2][w];
-      s8[fb][w] = (b2 ? hi : lo) + dpp(b2 ? lo : hi, std::integral_constant<int, 0x141>{});        // row_half_mirror
-    }
+    for (int k = 0; k < 8; ++k) { lo[k] = a.v[2 * h + (k >> 2)][k & 3]; hi[k] = a.v[2 * h + 4 + (k >> 2)][k & 3]; }
+    bfly8<3>(lo, hi, s16[h]);
+  }
+  bfly8<2>(s16[0], s16[1], s8);                       // s8[4 fb + w], fb < 2
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    const float lo = s8[0][w], hi = s8[1][w];
+    const float lo = s8[w], hi = s8[4 + w];
     s4[w] = (b1 ? hi : lo) + dpp(b1 ? lo : hi, std::integral_constant<int, 0x4E>{});               // quad_perm [2,3,0,1]
   }
 #pragma unroll
@@ -343,8 +361,26 @@ __device__ __forceinline__ void row16_sums_transposed(const Act& a, float (&out)
 __device__ __forceinline__ float row_sum(const Act& a) {
   float s0 = 0.f, s1 = 0.f;
   HGN_FOR_B(fb) {
-    s0 += a.v[fb][0] + a.v[fb][1];
-    s1 += a.v[fb][2] + a.v[fb][3];
+    float p = a.v[fb][0] + a.v[fb][1], q = a.v[fb][2] + a.v[fb][3];
+    asm("" : "+v"(p), "+v"(q));      // four scalar adds per block: packed adds would pair (0, 2) with (1, 3) and pay four moves to get there
+    s0 += p;
+    s1 += q;
+  }
+  float t = s0 + s1;
+  t += __shfl_xor(t, 16);
+  t += __shfl_xor(t, 32);
+  return t;
+}
+
+// Sum over the row of a * b, the products rounded on their own (no fused multiply-add), in the summation order of row_sum.
+__device__ __forceinline__ float row_dot(const Act& a, const Act& b) {
+  float s0 = 0.f, s1 = 0.f;
+  HGN_FOR_B(fb) {
+    float p = __fmul_rn(a.v[fb][0], b.v[fb][0]) + __fmul_rn(a.v[fb][1], b.v[fb][1]);
+    float q = __fmul_rn(a.v[fb][2], b.v[fb][2]) + __fmul_rn(a.v[fb][3], b.v[fb][3]);
+    asm("" : "+v"(p), "+v"(q));
+    s0 += p;
+    s1 += q;
   }
   float t = s0 + s1;
   t += __shfl_xor(t, 16);

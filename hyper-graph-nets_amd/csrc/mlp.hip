@@ -147,15 +147,7 @@ __global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
       }
       HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
       const float m1 = row_sum(g) * (1.f / LAT);
-      float q0 = 0.f, q1 = 0.f;
-      HGN_FOR_B(fb) {
-        q0 += g.v[fb][0] * t.v[fb][0] + g.v[fb][1] * t.v[fb][1];
-        q1 += g.v[fb][2] * t.v[fb][2] + g.v[fb][3] * t.v[fb][3];
-      }
-      float qs = q0 + q1;
-      qs += __shfl_xor(qs, 16);
-      qs += __shfl_xor(qs, 32);
-      const float m2 = qs * (1.f / LAT);
+      const float m2 = row_dot(g, t) * (1.f / LAT);
       const float r = a.rstd[rc];
       HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - t.v[fb] * m2);
     }

@@ -671,15 +671,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
       }
       HGN_FOR_B(fb) g[u].v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
       const float m1 = row_sum(g[u]) * (1.f / LAT);
-      float q0 = 0.f, q1 = 0.f;
-      HGN_FOR_B(fb) {
-        q0 += g[u].v[fb][0] * xh.v[fb][0] + g[u].v[fb][1] * xh.v[fb][1];
-        q1 += g[u].v[fb][2] * xh.v[fb][2] + g[u].v[fb][3] * xh.v[fb][3];
-      }
-      float qs = q0 + q1;
-      qs += __shfl_xor(qs, 16);
-      qs += __shfl_xor(qs, 32);
-      const float m2 = qs * (1.f / LAT);
+      const float m2 = row_dot(g[u], xh) * (1.f / LAT);
       const float r = a.rstd[R.rc[u]];
       HGN_FOR_B(fb) g[u].v[fb] = r * (g[u].v[fb] - m1 - xh.v[fb] * m2);
       if (!(HGN_ABL & 4) && a.dz3 && R.valid[u]) t_store(g[u], a.dz3 + R.row[u] * LAT, kq);
