@@ -81,9 +81,10 @@ def weights_of(module: nn.Module, in_features: int) -> ops.MLPWeights:
     return w
 
 
-def fused_apply(module: nn.Module, srcs: Sequence[Tensor], idxs=None, residual: int = -1, post=None):
-    width = sum(s.shape[1] for s in srcs)
-    return ops.fused_mlp(srcs, weights_of(module, width), idxs, residual, post)
+def fused_apply(module: nn.Module, srcs: Sequence[Tensor], idxs=None, residual: int = -1, post=None, cols=None, width=None):
+    """`cols` / `width`: first input column of every source and the full input width, when column ranges are left out (ops.fused_mlp)."""
+    width = sum(s.shape[1] for s in srcs) if width is None else width
+    return ops.fused_mlp(srcs, weights_of(module, width), idxs, residual, post, cols)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -115,13 +116,22 @@ class _SplitRows(torch.autograd.Function):
         return out, None
 
 
+class _Agg:
+    """Aggregate of one edge set over its receivers: rows of node part `part` (0 mesh, 1 hyper) only, or of all node rows (None)."""
+    __slots__ = ('t', 'part')
+
+    def __init__(self, t: Tensor, part: Optional[int]):
+        self.t, self.part = t, part
+
+
 class _Latent:
-    __slots__ = ('nodes', 'edges', 'topo', 'splits', 'pre')
+    __slots__ = ('nodes', 'edges', 'topo', 'splits', 'pre', '_cat')
 
     def __init__(self, nodes: List[Tensor], edges: 'OrderedDict[str, Tensor]', topo: Dict[str, topology.EdgeTopology]):
         self.nodes, self.edges, self.topo = nodes, edges, topo
         self.splits = {}
         self.pre = {}       # edge-set name -> (P, zero-filled aggregate buffer) formed by the node kernel of the block before (inference)
+        self._cat = None
 
     def split_rows(self, a: Tensor):
         """(mesh rows, hyper rows) of an [N_tot, .] tensor; one autograd node per tensor however often it is consumed."""
@@ -132,7 +142,13 @@ class _Latent:
         return hit[1]
 
     def h_all(self) -> Tensor:
-        return self.nodes[0] if len(self.nodes) == 1 else torch.cat(tuple(self.nodes), dim=0)
+        """All node rows as ONE tensor -- only for edge sets whose senders or receivers lie in both parts (topology.parts is None):
+        the sets of the reference's hierarchies read one part per side and never come here."""
+        if len(self.nodes) == 1:
+            return self.nodes[0]
+        if self._cat is None or any(a is not b for a, b in zip(self._cat[0], self.nodes)):
+            self._cat = (tuple(self.nodes), torch.cat(tuple(self.nodes), dim=0))
+        return self._cat[1]
 
     @property
     def n_mesh(self):
@@ -183,28 +199,47 @@ class GraphNet(nn.Module):
     def _ops(self) -> Tuple[str, ...]:
         return PNA if self.message_passing_aggregator == 'pna' else (self.message_passing_aggregator,)
 
-    def _edge(self, lat: _Latent, feats: Tensor, name: str, h_all: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-        """-> (updated edge latents, their aggregates over receivers [N_tot, k*128]); one autograd node for both."""
-        h_all = lat.h_all() if h_all is None else h_all
-        return ops.edge_block(h_all, feats, lat.topo[name], weights_of(self.edge_models[name], 3 * ops.LAT), self._ops(),
-                              pre=lat.pre.get(name))
+    def _edge(self, lat: _Latent, feats: Tensor, name: str) -> Tuple[Tensor, _Agg]:
+        """-> (updated edge latents, their aggregates over receivers [rows, k*128]); one autograd node for both.
+        Mesh rows and hyper rows stay two tensors: a set whose senders lie in one part and whose receivers lie in one part (all sets
+        of the reference's hierarchies: mesh->mesh, mesh->hyper, hyper->hyper, hyper->mesh) hands over just those, and its aggregate
+        has the receiver part's rows (graphnet.py:25-26 indexes ONE concatenated tensor; same values, no concatenation)."""
+        t = lat.topo[name]
+        w = weights_of(self.edge_models[name], 3 * ops.LAT)
+        pp = t.parts(lat.n_mesh) if len(lat.nodes) == 2 else None
+        if pp is not None:
+            ps, pr = pp
+            offs = (0, lat.n_mesh)
+            e2, agg = ops.edge_block(lat.nodes[ps], feats, t, w, self._ops(), parts=(offs[ps], offs[pr]),
+                                     h_r=None if pr == ps else lat.nodes[pr])
+            return e2, _Agg(agg, pr)
+        e2, agg = ops.edge_block(lat.h_all(), feats, t, w, self._ops(), pre=lat.pre.get(name))
+        return e2, _Agg(agg, None)
 
-    def _node(self, lat: _Latent, aggs: Sequence[Tensor], model: nn.Module, which: int):
+    def _node(self, lat: _Latent, aggs: Sequence[_Agg], model: nn.Module, which: int):
         """nodes[which] += LN(MLP([h ; agg_1 ; agg_2 ...][rows of `which`]))   (graphnet.py:47-48,107-108,123-124).
-        The concatenation is never materialised: every aggregate is its own K-segment of the first Linear."""
+        The concatenation is never materialised: every aggregate is its own K-segment of the first Linear -- and an aggregate over
+        edges that all arrive in the OTHER part is zero for these rows: its K-segment is left out (ops.fused_mlp: cols)."""
         n_mesh = lat.n_mesh
-        # (no slice when there are no hyper rows: its backward would zero-fill and copy a full [N, k*128] gradient)
-        srcs = [lat.nodes[which]] + [a if (which == 0 and a.shape[0] == n_mesh) else lat.split_rows(a)[which] for a in aggs]
-        lat.nodes[which] = fused_apply(model, srcs, residual=0)
+        srcs, cols, col = [lat.nodes[which]], [0], lat.nodes[which].shape[1]
+        for a in aggs:
+            if a.part is None:
+                # (no slice when there are no hyper rows: its backward would zero-fill and copy a full [N, k*128] gradient)
+                srcs.append(a.t if (which == 0 and a.t.shape[0] == n_mesh) else lat.split_rows(a.t)[which])
+                cols.append(col)
+            elif a.part == which:
+                srcs.append(a.t)
+                cols.append(col)
+            col += a.t.shape[1]
+        lat.nodes[which] = fused_apply(model, srcs, residual=0, cols=cols if len(srcs) <= len(aggs) else None, width=col)
 
     # -- GraphNet.forward (graphnet.py:72-84) --------------------------------------------------------------------
     def _forward_latent(self, lat: _Latent, nxt: Optional['GraphNet'] = None) -> _Latent:
-        h_all = lat.h_all()
         new_edges, aggs = OrderedDict(), OrderedDict()
         for name, feats in lat.edges.items():
             if name not in self.edge_models:
                 raise KeyError(name)                                           # graphnet.py:32
-            new_edges[name], aggs[name] = self._edge(lat, feats, name, h_all)
+            new_edges[name], aggs[name] = self._edge(lat, feats, name)
         out = _Latent(list(lat.nodes), new_edges, lat.topo)
         if nxt is not None:                                                     # (plain blocks only: Processor.forward)
             self._update_nodes(out, aggs, nxt)
@@ -225,7 +260,7 @@ class GraphNet(nn.Module):
         if post is None:
             self._node(lat, list(aggs.values()), self.node_model_cross, 0)   # graph order (graphnet.py:43)
             return
-        srcs = [lat.nodes[0]] + list(aggs.values())
+        srcs = [lat.nodes[0]] + [a.t for a in aggs.values()]
         lat.nodes[0], got = fused_apply(self.node_model_cross, srcs, residual=0, post=post)
         if got is not None:
             lat.pre = {next(iter(lat.edges)): got}

@@ -471,6 +471,7 @@ class MLPFn(torch.autograd.Function):
     def forward(ctx, meta, *tensors):
         n_src, idxs, residual, has_ln, train = meta[:5]
         post = meta[5] if len(meta) > 5 else None          # (packed next-block weights, zero-fill wanted): inference only, see fused_mlp
+        given = meta[6] if len(meta) > 6 else None         # first W1 column of every source (fused_mlp: cols), or None: back to back
         c = current()
         srcs = [_rowmajor(t) for t in tensors[:n_src]]
         wt = tensors[n_src:]
@@ -489,9 +490,17 @@ class MLPFn(torch.autograd.Function):
         col = 0
         cols = []
         # every source must start on a 128-column boundary of W1 (all but the last a multiple of 128 wide)
-        pk = packs_of(w, ctx=c) if all(s.shape[1] % LAT == 0 for s in srcs[:-1]) else None
+        if given is not None:
+            pk = packs_of(w, ctx=c) if all(g % LAT == 0 for g in given) else None
+        else:
+            pk = packs_of(w, ctx=c) if all(s.shape[1] % LAT == 0 for s in srcs[:-1]) else None
         nb1 = (w.w1.shape[1] + LAT - 1) // LAT
         for i, s in enumerate(srcs):
+            if given is not None:
+                if given[i] < col or given[i] + s.shape[1] > w.w1.shape[1]:
+                    raise _lib.HgnError(f'MLP source {i}: columns [{given[i]}, {given[i] + s.shape[1]}) overlap the source before or exceed '
+                                        f'in_features {w.w1.shape[1]}')
+                col = given[i]
             e = a.src[i]
             e.x = s.data_ptr(); e.ld = _ld(s); e.K = s.shape[1]
             e.idx = idxs[i].data_ptr() if idxs[i] is not None else None
@@ -503,7 +512,7 @@ class MLPFn(torch.autograd.Function):
         if pk is not None:
             a.W2pk = pk.data_ptr() + nb1 * _lib.PACK_BLOCK_BYTES
             a.W3pk = pk.data_ptr() + (nb1 + 1) * _lib.PACK_BLOCK_BYTES
-        if col != w.w1.shape[1]:
+        if given is None and col != w.w1.shape[1]:
             raise _lib.HgnError(f'MLP input width {col} does not match weight in_features {w.w1.shape[1]}')
         saves = _alloc_saves(M, has_ln, dev) if train else None
         res = srcs[residual] if residual >= 0 else None
@@ -527,6 +536,7 @@ class MLPFn(torch.autograd.Function):
             _GATE_LOG.append((wt[0].data_ptr(), saves[4], idxs[0]))
         if train:
             ctx.meta = (n_src, idxs, residual, has_ln, cols, M)
+            ctx.gaps = sum(s.shape[1] for s in srcs) != w.w1.shape[1]      # W1 columns no source feeds: their gradient is zero
             ctx.saves = saves
             ctx.targets = _grad_targets(wt)
             ctx.pk_t = packs_of(w, transposed=True, ctx=c) if pk is not None else None
@@ -601,6 +611,8 @@ class MLPFn(torch.autograd.Function):
                 first = False
         if M == 0:
             _zero_unaccumulated(bufs[:6], accs[:6])
+        elif ctx.gaps and not accs[0]:
+            dw1.zero_()
         # (gathered / narrow sources = encoders: few launches, operands of E rows: not worth keeping alive)
         _run_wgrad(c, tasks, M, dev, keep=[z1, z2, dz1, dz2, dz3, *srcs], defer=all(i is None for i in idxs) and pk_t is not None)
         # ---- un-gather source gradients -----------------------------------------------------------------------
@@ -613,19 +625,23 @@ class MLPFn(torch.autograd.Function):
 
 
 def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequence[Optional[torch.Tensor]]] = None,
-              residual: int = -1, post=None):
-    """`post` (inference only): (packs_of(weights of the NEXT edge block), zero-fill wanted) -- when the launch is small enough for
+              residual: int = -1, post=None, cols: Optional[Sequence[int]] = None):
+    """`cols`: first W1 column of every source when the sources do NOT cover the input back to back -- column ranges left out stand for
+    inputs that are zero for every row of this launch (an aggregate over edges none of which arrive at these rows): no operand, no
+    product, a zero weight gradient.
+    `post` (inference only): (packs_of(weights of the NEXT edge block), zero-fill wanted) -- when the launch is small enough for
     the column-split form the node-level pre-projection of that block (its P = [h W1s^T | h W1r^T]) and the zero fill of its
     aggregate buffer come out of the same launch: -> (out, (P, zeros) or None)."""
     idxs = tuple(idxs) if idxs is not None else (None,) * len(srcs)
     wt = w.tensors()
     train = torch.is_grad_enabled() and any(t.requires_grad for t in list(srcs) + wt)
+    cols = tuple(int(x) for x in cols) if cols is not None else None
     if post is None or train:
-        out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train), *srcs, *wt)
+        out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, None, cols), *srcs, *wt)
         return out if post is None else (out, None)
     c = current()
     c.post_result = None
-    out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, post), *srcs, *wt)
+    out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, post, cols), *srcs, *wt)
     got, c.post_result = c.post_result, None
     return out, got
 
@@ -636,15 +652,23 @@ def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequen
 class EdgeBlockFn(torch.autograd.Function):
     """e' = e + LN(MLP([h[snd] ; h[rcv] ; e])) with e, e' in receiver-sorted order, optionally followed IN THE SAME
     autograd node by the aggregation of e' over receivers (so that the backward adds d(e') and the scattered d(agg)
-    inside the segment-reduce kernel instead of in a separate pass)."""
+    inside the segment-reduce kernel instead of in a separate pass).
+
+    Node rows.  ``parts is None``: ``h_s`` holds all ``topo.num_nodes`` rows (``h_r`` is None).  ``parts = (off_s, off_r)``: the set's
+    senders all lie in rows [off_s, off_s + len(h_s)) and its receivers in [off_r, off_r + len(h_r)) of the node numbering -- the mesh rows
+    and the hyper rows of a hierarchical graph live in tensors of their own and are never concatenated (hypergraphnet.py:21-54 reads
+    ``graph.node_features`` as a list; only the gather indices are global).  ``h_r is None``: the same tensor serves both.  Then only
+    those rows are projected, summed over and given a gradient, and the aggregate has one row per RECEIVER-part row."""
 
     @staticmethod
-    def forward(ctx, topo, train, agg_ops, pre, h_all, e, *wt):
+    def forward(ctx, topo, train, agg_ops, pre, parts, h_s, h_r, e, *wt):
         w = MLPWeights(*wt)
         w.check()
         if w.w1.shape[1] != 3 * LAT or w.ln_w is None:
             raise _lib.HgnError('edge model must be Linear(384,128)...+LayerNorm')
-        h_all = _rowmajor(h_all)
+        h_s = _rowmajor(h_s)
+        same = h_r is None
+        h_r = h_s if same else _rowmajor(h_r)
         e = _rowmajor(e)
         _lib.require_gpu(e)
         dev = e.device
@@ -652,24 +676,38 @@ class EdgeBlockFn(torch.autograd.Function):
         st = _lib.stream_ptr()
         c = current()
         E, N = topo.num_edges, topo.num_nodes
-        if e.shape[0] != E or h_all.shape[0] != N:
-            raise _lib.HgnError(f'edge block: got {e.shape[0]} edge rows / {h_all.shape[0]} node rows, topology has {E} / {N}')
-        P = torch.empty(N, 2 * LAT, device=dev)
-        pk = packs_of(w, ctx=c) if (_ld(h_all) % 4 == 0 and h_all.data_ptr() % 16 == 0 and not c.fp32_only()) else None
+        off_s, off_r = parts if parts is not None else (0, 0)
+        Ns, Nr = h_s.shape[0], h_r.shape[0]
+        if e.shape[0] != E or (parts is None and Ns != N) or off_s + Ns > N or off_r + Nr > N or (same and off_s != off_r):
+            raise _lib.HgnError(f'edge block: got {e.shape[0]} edge rows / node rows [{off_s}, {off_s + Ns}) and [{off_r}, {off_r + Nr}), '
+                                f'topology has {E} / {N}')
+        # P = [h W1s^T | h W1r^T] of the rows the set touches: one [Ns, 256] array, or one 128-wide array per part
+        if same:
+            P = torch.empty(Ns, 2 * LAT, device=dev)
+            Ps, Pr, ldp = P.data_ptr(), P.data_ptr() + 4 * LAT, 2 * LAT
+        else:
+            P = (torch.empty(Ns, LAT, device=dev), torch.empty(Nr, LAT, device=dev))
+            Ps, Pr, ldp = P[0].data_ptr(), P[1].data_ptr(), LAT
+        pk = packs_of(w, ctx=c) if (all(_ld(h) % 4 == 0 and h.data_ptr() % 16 == 0 for h in (h_s, h_r)) and not c.fp32_only()) else None
         # the `sum` aggregate formed inside the edge kernel needs a zero-filled [N, 128] buffer: filled by the pre-projection launch,
         # which passes over the same node rows anyway (hgn_linear_fwd6z), instead of a launch of its own
         agg_zeroed = None
-        if pre is not None and not train and pk is not None and tuple(pre[0].shape) == (N, 2 * LAT):
+        if pre is not None and not train and pk is not None and parts is None and tuple(pre[0].shape) == (N, 2 * LAT):
             P, agg_zeroed = pre                              # formed by the node kernel of the block before (fused_mlp: post)
-        elif pk is not None:
-            pb = (C.c_void_p * 2)(pk.data_ptr(), pk.data_ptr() + _lib.PACK_BLOCK_BYTES)
-            if agg_ops == ('sum',) and 0 < E and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS:
-                agg_zeroed = torch.empty(N, LAT, device=dev)
-            _lib.check(L.hgn_linear_fwd6z(h_all.data_ptr(), _ld(h_all), N, pb, 2, P.data_ptr(), 2 * LAT,
-                                          agg_zeroed.data_ptr() if agg_zeroed is not None else None, LAT, c.products(), st), 'hgn_linear_fwd6z')
+            Ps, Pr = P.data_ptr(), P.data_ptr() + 4 * LAT
         else:
-            wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
-            _lib.check(L.hgn_linear_fwd(h_all.data_ptr(), _ld(h_all), N, wb, 2, 3 * LAT, P.data_ptr(), 2 * LAT, st), 'hgn_linear_fwd')
+            if pk is not None and agg_ops == ('sum',) and 0 < E and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS:
+                agg_zeroed = torch.empty(Nr, LAT, device=dev)
+            # (rows, first W1 column block, blocks, output): both halves in one launch when one tensor serves senders and receivers
+            for h, n, b0, nb, optr, zero in (((h_s, Ns, 0, 2, Ps, agg_zeroed),) if same else
+                                            ((h_s, Ns, 0, 1, Ps, None), (h_r, Nr, 1, 1, Pr, agg_zeroed))):
+                if pk is not None:
+                    pb = (C.c_void_p * 2)(*[pk.data_ptr() + (b0 + j) * _lib.PACK_BLOCK_BYTES for j in range(nb)], *([None] * (2 - nb)))
+                    _lib.check(L.hgn_linear_fwd6z(h.data_ptr(), _ld(h), n, pb, nb, optr, ldp, zero.data_ptr() if zero is not None else None,
+                                                  LAT, c.products(), st), 'hgn_linear_fwd6z')
+                else:
+                    wb = (C.c_void_p * 2)(*[w.w1.data_ptr() + 4 * LAT * (b0 + j) for j in range(nb)], *([None] * (2 - nb)))
+                    _lib.check(L.hgn_linear_fwd(h.data_ptr(), _ld(h), n, wb, nb, 3 * LAT, optr, ldp, st), 'hgn_linear_fwd')
         out = torch.empty(E, LAT, device=dev)
         a = _lib.MlpFwd()
         c.stamp(a)
@@ -682,8 +720,9 @@ class EdgeBlockFn(torch.autograd.Function):
             a.W2pk = pk.data_ptr() + 3 * _lib.PACK_BLOCK_BYTES
             a.W3pk = pk.data_ptr() + 4 * _lib.PACK_BLOCK_BYTES
         a.n_add = 2
-        a.add[0].P = P.data_ptr(); a.add[0].ld = 2 * LAT; a.add[0].idx = topo.snd.data_ptr()
-        a.add[1].P = P.data_ptr() + 4 * LAT; a.add[1].ld = 2 * LAT; a.add[1].idx = topo.rcv.data_ptr()
+        # (the indices are global row numbers: the bases are those of row 0, which only exists when the part starts there)
+        a.add[0].P = Ps - 4 * ldp * off_s; a.add[0].ld = ldp; a.add[0].idx = topo.snd.data_ptr()
+        a.add[1].P = Pr - 4 * ldp * off_r; a.add[1].ld = ldp; a.add[1].idx = topo.rcv.data_ptr()
         saves = _alloc_saves(E, True, dev) if train else None
         _fill_common_fwd(a, w, out, e, saves)
         agg, amax, amin = None, None, None
@@ -692,27 +731,27 @@ class EdgeBlockFn(torch.autograd.Function):
         fuse_agg = (agg_ops == ('sum',) and pk is not None and 0 < E and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
                     and L.hgn_mlp_fwd6_eligible(C.byref(a)))
         if fuse_agg:
-            agg = agg_zeroed if agg_zeroed is not None else torch.zeros(N, LAT, device=dev)
-            a.seg_out = agg.data_ptr(); a.ld_seg_out = LAT; a.seg_ids = topo.rcv.data_ptr()
+            agg = agg_zeroed if agg_zeroed is not None else torch.zeros(Nr, LAT, device=dev)
+            a.seg_out = agg.data_ptr() - 4 * LAT * off_r; a.ld_seg_out = LAT; a.seg_ids = topo.rcv.data_ptr()
         if E > 0:
             _lib.check(L.hgn_mlp_fwd(C.byref(a), st), 'hgn_mlp_fwd')
         if agg_ops is not None and not fuse_agg:
             arr, codes = _ops_array(agg_ops)
             k = len(codes)
-            agg = torch.empty(N, k * LAT, device=dev)
+            agg = torch.empty(Nr, k * LAT, device=dev)
             if train and 2 in codes:
-                amax = torch.empty(N, LAT, dtype=torch.int32, device=dev)
+                amax = torch.empty(Nr, LAT, dtype=torch.int32, device=dev)
             if train and 3 in codes:
-                amin = torch.empty(N, LAT, dtype=torch.int32, device=dev)
+                amin = torch.empty(Nr, LAT, dtype=torch.int32, device=dev)
             L.hgn_prof_tag(2)
-            _lib.check(L.hgn_segment_reduce_fwd(out.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr(), N, arr, k,
+            _lib.check(L.hgn_segment_reduce_fwd(out.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr() + 4 * off_r, Nr, arr, k,
                                                 agg.data_ptr(), k * LAT, amax.data_ptr() if amax is not None else None,
                                                 amin.data_ptr() if amin is not None else None, st), 'hgn_segment_reduce_fwd')
             L.hgn_prof_tag(0)
         if train and _GATE_LOG is not None:
             _GATE_LOG.append((wt[0].data_ptr(), saves[4], topo.r.perm))
         if train and _ARG_LOG is not None and (amax is not None or amin is not None):
-            _ARG_LOG.append((wt[0].data_ptr(), amax, amin, topo.r.perm))
+            _ARG_LOG.append((wt[0].data_ptr(), amax, amin, topo.r.perm, off_r, N))
         if train:
             ctx.set_materialize_grads(False)
             ctx.topo = topo
@@ -721,13 +760,18 @@ class EdgeBlockFn(torch.autograd.Function):
             ctx.targets = _grad_targets(wt)
             ctx.pk_t = packs_of(w, transposed=True, ctx=c) if pk is not None else None
             ctx.hgn = c
-            ctx.save_for_backward(h_all, e, *wt)
+            ctx.rows = (same, off_s, off_r)
+            ctx.save_for_backward(h_s, None if same else h_r, e, *wt)
         return (out, agg) if agg_ops is not None else out
 
     @staticmethod
     def backward(ctx, d_out, d_agg=None):
         topo = ctx.topo
-        h_all, e, *wt = ctx.saved_tensors
+        h_s, h_r, e, *wt = ctx.saved_tensors
+        same, off_s, off_r = ctx.rows
+        if same:
+            h_r = h_s
+        Ns, Nr = h_s.shape[0], h_r.shape[0]
         w = MLPWeights(*wt)
         z1, z2, xhat, rstd, bits = ctx.saves
         agg_ops, amax, amin = ctx.agg
@@ -736,7 +780,7 @@ class EdgeBlockFn(torch.autograd.Function):
         st = _lib.stream_ptr()
         c = ctx.hgn
         if d_out is None and d_agg is None:
-            return (None,) * (6 + len(wt))
+            return (None,) * (8 + len(wt))
         dev = (d_out if d_out is not None else d_agg).device
         dz3 = dz2 = None              # [E,128] each, only on the two-launch path (the fused kernel keeps them on chip)
         dz1 = torch.empty((E + 63) // 64 * 64, LAT, device=dev)[:E]      # whole 64-row tiles: hgn_edge_bwd_fused stores the padding rows too
@@ -752,12 +796,13 @@ class EdgeBlockFn(torch.autograd.Function):
             # d(e') + the aggregation backward are summed inside the kernel's load of d_out (no dE tensor, no extra pass)
             d_agg = _rowmajor(d_agg)
             arr, codes = _ops_array(agg_ops)
-            b.agg_dout = d_agg.data_ptr(); b.ld_agg = _ld(d_agg); b.n_agg_ops = len(codes)
+            # (per-receiver arrays have one row per row of the receiver part; the kernels index them by global row number)
+            b.agg_dout = d_agg.data_ptr() - 4 * _ld(d_agg) * off_r; b.ld_agg = _ld(d_agg); b.n_agg_ops = len(codes)
             for i, cde in enumerate(codes):
                 b.agg_ops[i] = cde
             b.agg_seg = topo.rcv.data_ptr(); b.agg_rowptr = topo.r.rowptr.data_ptr()
-            b.agg_argmax = amax.data_ptr() if amax is not None else None
-            b.agg_argmin = amin.data_ptr() if amin is not None else None
+            b.agg_argmax = amax.data_ptr() - 4 * LAT * off_r if amax is not None else None
+            b.agg_argmin = amin.data_ptr() - 4 * LAT * off_r if amin is not None else None
         b.ln_g = w.ln_w.data_ptr(); b.xhat = xhat.data_ptr(); b.rstd = rstd.data_ptr()
         b.z2 = z2.data_ptr(); b.z1 = z1.data_ptr(); b.relu_bits = bits.data_ptr()
         b.W3 = w.w3.data_ptr(); b.W2 = w.w2.data_ptr(); b.ldw1 = 3 * LAT
@@ -776,7 +821,12 @@ class EdgeBlockFn(torch.autograd.Function):
         b.ln_ws = _ln_workspace(c, E, dev).data_ptr()
         # dP = [sum over edges sent by n of dz1 | sum over edges received by n of dz1]; the receiver half comes out of the
         # backward kernel itself when the segments are short (include/hgn_mp.h: seg_dz1)
-        dP = torch.empty(N, 2 * LAT, device=dev)
+        if same:
+            dP = torch.empty(Ns, 2 * LAT, device=dev)
+            dPs, dPr, ldd = dP.data_ptr(), dP.data_ptr() + 4 * LAT, 2 * LAT
+        else:
+            dP = (torch.empty(Ns, LAT, device=dev), torch.empty(Nr, LAT, device=dev))
+            dPs, dPr, ldd = dP[0].data_ptr(), dP[1].data_ptr(), LAT
         # One pass for data gradients AND weight gradients (include/hgn_mp.h: hgn_edge_bwd_fused): dz3 / dz2 never reach memory.
         may_fuse = c.fused() and pk_t is not None and E > 0 and c.wgrad_stream is None and accs[2] == accs[4]
         fused = may_fuse and bool(L.hgn_edge_bwd_fused_eligible(C.byref(b)))      # (dW3 / dW2 share one accumulate flag in hgn_wfuse_t)
@@ -791,9 +841,10 @@ class EdgeBlockFn(torch.autograd.Function):
             if L.hgn_edge_bwd_fused_eligible(C.byref(b2)):
                 g_eff = torch.empty(E, LAT, device=dev)
                 arr, codes = _ops_array(agg_ops)
-                _lib.check(L.hgn_segment_reduce_bwd(d_agg.data_ptr(), _ld(d_agg), LAT, None, topo.rcv.data_ptr(), topo.r.rowptr.data_ptr(), E,
-                                                    arr, len(codes), amax.data_ptr() if amax is not None else None,
-                                                    amin.data_ptr() if amin is not None else None,
+                _lib.check(L.hgn_segment_reduce_bwd(d_agg.data_ptr() - 4 * _ld(d_agg) * off_r, _ld(d_agg), LAT, None, topo.rcv.data_ptr(),
+                                                    topo.r.rowptr.data_ptr(), E,
+                                                    arr, len(codes), amax.data_ptr() - 4 * LAT * off_r if amax is not None else None,
+                                                    amin.data_ptr() - 4 * LAT * off_r if amin is not None else None,
                                                     d_out.data_ptr() if d_out is not None else None, g_eff.data_ptr(), LAT, st),
                            'hgn_segment_reduce_bwd')
                 b2.d_out = g_eff.data_ptr()
@@ -801,8 +852,8 @@ class EdgeBlockFn(torch.autograd.Function):
         fuse_seg = (not fused and pk_t is not None and E > 0 and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
                     and L.hgn_mlp_bwd6_eligible(C.byref(b)))
         if fuse_seg:
-            dP[:, LAT:].zero_()
-            b.seg_dz1 = dP.data_ptr() + 4 * LAT; b.ld_seg_dz1 = 2 * LAT; b.seg_ids = topo.rcv.data_ptr()
+            (dP[:, LAT:] if same else dP[1]).zero_()
+            b.seg_dz1 = dPr - 4 * ldd * off_r; b.ld_seg_dz1 = ldd; b.seg_ids = topo.rcv.data_ptr()
         if fused:
             wf = _lib.WFuse()
             wf.z2 = z2.data_ptr(); wf.z1 = z1.data_ptr()
@@ -831,33 +882,43 @@ class EdgeBlockFn(torch.autograd.Function):
                 _zero_unaccumulated(bufs[:6], accs[:6])
             _run_wgrad(c, tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
         ops = (C.c_int32 * 1)(0)
-        _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N,
-                                            ops, 1, dP.data_ptr(), 2 * LAT, None, None, st), 'segment_reduce(senders)')
+        _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr() + 4 * off_s, Ns,
+                                            ops, 1, dPs, ldd, None, None, st), 'segment_reduce(senders)')
         if not fuse_seg:
-            _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr(), N, ops, 1,
-                                                dP.data_ptr() + 4 * LAT, 2 * LAT, None, None, st), 'segment_reduce(receivers)')
-        tasks = [_wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr(), 2 * LAT, LAT, dw1.data_ptr(), 3 * LAT, None,
-                        accs[0]),
-                 _wtask(0, h_all.data_ptr(), _ld(h_all), LAT, None, dP.data_ptr() + 4 * LAT, 2 * LAT, LAT,
-                        dw1.data_ptr() + 4 * LAT, 3 * LAT, None, accs[0])]
-        _run_wgrad(c, tasks, N, dev, keep=[h_all, dP], defer=True)
-        dh = None
-        if ctx.needs_input_grad[4]:                      # h_all (inputs: topo, train, agg_ops, pre, h_all, e, *weights)
-            dh = torch.empty(N, LAT, device=dev)
+            _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr() + 4 * off_r, Nr, ops, 1,
+                                                dPr, ldd, None, None, st), 'segment_reduce(receivers)')
+        task_s = _wtask(0, h_s.data_ptr(), _ld(h_s), LAT, None, dPs, ldd, LAT, dw1.data_ptr(), 3 * LAT, None, accs[0])
+        task_r = _wtask(0, h_r.data_ptr(), _ld(h_r), LAT, None, dPr, ldd, LAT, dw1.data_ptr() + 4 * LAT, 3 * LAT, None, accs[0])
+        if same:
+            _run_wgrad(c, [task_s, task_r], Ns, dev, keep=[h_s, dP], defer=True)
+        else:
+            _run_wgrad(c, [task_s], Ns, dev, keep=[h_s, dP[0]], defer=True)
+            _run_wgrad(c, [task_r], Nr, dev, keep=[h_r, dP[1]], defer=True)
+        # inputs: topo, train, agg_ops, pre, parts, h_s, h_r, e, *weights
+        dhs = [None, None]
+        for slot, (need, n, b0, nb, gptr) in enumerate(((ctx.needs_input_grad[5], Ns, 0, 2 if same else 1, dPs),
+                                                         (not same and ctx.needs_input_grad[6], Nr, 1, 1, dPr))):
+            if not need:
+                continue
+            dh = torch.empty(n, LAT, device=dev)
             if pk_t is not None:
-                pb = (C.c_void_p * 2)(pk_t.data_ptr(), pk_t.data_ptr() + _lib.PACK_BLOCK_BYTES)
-                _lib.check(L.hgn_linear_bwd6(dP.data_ptr(), 2 * LAT, N, pb, 2, dh.data_ptr(), LAT, c.products(), st), 'hgn_linear_bwd6')
+                pb = (C.c_void_p * 2)(*[pk_t.data_ptr() + (b0 + j) * _lib.PACK_BLOCK_BYTES for j in range(nb)], *([None] * (2 - nb)))
+                _lib.check(L.hgn_linear_bwd6(gptr, ldd, n, pb, nb, dh.data_ptr(), LAT, c.products(), st), 'hgn_linear_bwd6')
             else:
-                wb = (C.c_void_p * 2)(w.w1.data_ptr(), w.w1.data_ptr() + 4 * LAT)
-                _lib.check(L.hgn_linear_bwd(dP.data_ptr(), 2 * LAT, N, wb, 2, 3 * LAT, dh.data_ptr(), LAT, st), 'hgn_linear_bwd')
-        return (None, None, None, None, dh, de, *grads_w)
+                wb = (C.c_void_p * 2)(*[w.w1.data_ptr() + 4 * LAT * (b0 + j) for j in range(nb)], *([None] * (2 - nb)))
+                _lib.check(L.hgn_linear_bwd(gptr, ldd, n, wb, nb, 3 * LAT, dh.data_ptr(), LAT, st), 'hgn_linear_bwd')
+            dhs[slot] = dh
+        return (None, None, None, None, None, dhs[0], dhs[1], de, *grads_w)
 
 
-def edge_block(h_all: torch.Tensor, e_sorted: torch.Tensor, topo, w: MLPWeights, agg_ops=None, pre=None):
-    """-> e'   or, with ``agg_ops`` (e.g. ('sum',) or the four PNA ops),  (e', agg[N, len(ops)*128])."""
+def edge_block(h_all: torch.Tensor, e_sorted: torch.Tensor, topo, w: MLPWeights, agg_ops=None, pre=None, parts=None, h_r=None):
+    """-> e'   or, with ``agg_ops`` (e.g. ('sum',) or the four PNA ops),  (e', agg[N, len(ops)*128]).
+    ``parts = (off_s, off_r)`` [+ ``h_r``]: node rows by part (EdgeBlockFn); the aggregate then has the receiver part's rows only."""
     wt = w.tensors()
-    train = torch.is_grad_enabled() and any(t.requires_grad for t in [h_all, e_sorted] + wt)
-    return EdgeBlockFn.apply(topo, train, tuple(agg_ops) if agg_ops is not None else None, None if train else pre, h_all, e_sorted, *wt)
+    hs = [h_all, e_sorted] + ([h_r] if h_r is not None else [])
+    train = torch.is_grad_enabled() and any(t.requires_grad for t in hs + wt)
+    return EdgeBlockFn.apply(topo, train, tuple(agg_ops) if agg_ops is not None else None, None if train else pre, parts, h_all, h_r,
+                             e_sorted, *wt)
 
 
 # ------------------------------------------------------------------------------------------------------------

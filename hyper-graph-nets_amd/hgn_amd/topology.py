@@ -57,7 +57,7 @@ class EdgeTopology:
     snd : senders in receiver-sorted order (int32);  rcv = r.seg
     s   : CSR by sender over the *receiver-sorted* order (used only by the backward sender scatter)
     """
-    __slots__ = ('r', 'snd', 'rcv', 's', 'num_nodes', 'num_edges', 'inv_perm', '__weakref__')
+    __slots__ = ('r', 'snd', 'rcv', 's', 'num_nodes', 'num_edges', 'inv_perm', 'span', '__weakref__')
 
     def __init__(self, senders: torch.Tensor, receivers: torch.Tensor, num_nodes: int, device):
         L = _lib.lib()
@@ -74,6 +74,19 @@ class EdgeTopology:
                                            _lib.stream_ptr()), 'hgn_narrow_gather_i64')
         self.s = CSR(self.snd, num_nodes)     # also range-checks the senders
         self.inv_perm = None
+        # lowest / highest sender and receiver row (one 32-byte read-back per topology BUILD): which node parts the set touches
+        self.span = (tuple(int(x) for x in torch.stack([self.snd.min(), self.snd.max(), self.rcv[0], self.rcv[-1]]).tolist())
+                     if E > 0 else None)
+
+    def parts(self, n_mesh: int):
+        """(sender part, receiver part) of a graph whose node rows are [mesh rows | hyper rows] split at ``n_mesh`` -- 0 / 1 -- or None
+        when the set is empty or either side has rows in both parts (the caller then hands over all rows as one tensor)."""
+        if self.span is None:
+            return None
+        s0, s1, r0, r1 = self.span
+        ps = 0 if s1 < n_mesh else (1 if s0 >= n_mesh else None)
+        pr = 0 if r1 < n_mesh else (1 if r0 >= n_mesh else None)
+        return None if ps is None or pr is None else (ps, pr)
 
     def inverse_perm(self):
         if self.inv_perm is None:

@@ -189,13 +189,15 @@ def hip_winners(model, log):
         if '.edge_models.' in k and k.startswith('processor.') and k.endswith('.layers.linear_0.weight'):
             name_of[p.data_ptr()] = k.split('.edge_models.')[1].split('.')[0]
     out = {}
-    for ptr, amax, amin, perm in log:
+    for ptr, amax, amin, perm, off, n_rows in log:      # (arg arrays cover the receiver part's rows [off, off + len) of n_rows node rows)
         p = perm.detach().cpu().long()
         rec = {}
         for op, a in (('max', amax), ('min', amin)):
             if a is not None:
                 a = a.detach().cpu().long()
-                rec[op] = torch.where(a >= 0, p[a.clamp(min=0)], torch.full_like(a, -1))
+                part = torch.where(a >= 0, p[a.clamp(min=0)], torch.full_like(a, -1))
+                rec[op] = torch.full((n_rows, part.shape[1]), -1, dtype=part.dtype)
+                rec[op][off:off + part.shape[0]] = part
         out.setdefault(name_of[ptr], []).append(rec)
     return out
 

@@ -275,7 +275,7 @@ def test_flag_training_step_end_to_end_against_oracle():
     out64 = O.mesh_graph_net(sd, m64, 'hyper', 'pna')
     mask = fr['node_type'][:, 0] == 0
     loss64 = O.masked_mse(out64, ff.get_target(fr, True), mask)
-    assert abs(float(loss) - float(loss64)) <= 2e-5 * abs(float(loss64)), (float(loss), float(loss64))
+    assert abs(float(loss.detach()) - float(loss64)) <= 2e-5 * abs(float(loss64)), (float(loss.detach()), float(loss64))
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.learned_model.parameters())
 
 
@@ -792,7 +792,12 @@ def test_get_model_constructs_from_every_reference_config(name):
     #  the reference as well -- heterographnet.py:29-32 + meshgraphnet.py:50)
     named = list(model.learned_model.named_parameters())
     assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for _, p in named)
-    last = f'graphnet_blocks.{cfg["model"]["message_passing_steps"] - 1}.hyper_node_model_cross'
-    assert all(p.grad is not None for k, p in named if last not in k), [k for k, p in named if p.grad is None and last not in k]
+    #  Edge sets that arrive at hyper rows only feed, in that last block, nothing but this update: the reference hands their edge
+    #  models a gradient of exact zeros (their aggregate is a zero block of the mesh-row MLP's input); here that block is left out
+    #  of the launch (ops.fused_mlp: cols) and the parameters get None -- the same Adam step: none.)
+    lb = f'graphnet_blocks.{cfg["model"]["message_passing_steps"] - 1}.'
+    dead = [lb + 'hyper_node_model_cross'] + [lb + 'edge_models.' + n for n in ('intra_cluster_to_cluster', 'inter_cluster', 'inter_cluster_world')]
+    live = [(k, p) for k, p in named if not any(d in k for d in dead)]
+    assert all(p.grad is not None for k, p in live), [k for k, p in live if p.grad is None]
     if name in REF_PARAM_COUNTS:
         assert sum(p.numel() for p in model.learned_model.parameters()) == REF_PARAM_COUNTS[name]
