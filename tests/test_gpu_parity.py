@@ -402,6 +402,101 @@ def test_edge_block_vs_oracle(nx, ny):
         assert H.rel_err(t.grad, sdo[n].grad) <= TOL_GRAD, n
 
 
+@pytest.mark.parametrize('kind', ['mesh_to_hyper', 'hyper_to_mesh', 'hyper_to_hyper', 'mesh_to_mesh'])
+@pytest.mark.parametrize('agg', [('sum',), ('sum', 'mean', 'max', 'min')])
+def test_edge_block_by_node_part_equals_the_concatenated_form_bit_for_bit(kind, agg):
+    """Hierarchical graphs keep mesh rows and hyper rows in two tensors (modules.GraphNet._edge): an edge set whose senders lie in
+    one part and whose receivers lie in one part hands over those parts only (ops.edge_block: parts, h_r).  Same bits as the one
+    concatenated tensor the reference indexes (graphnet.py:25-26, hypergraphnet.py:21-54): outputs, the receiver part's rows of the
+    aggregate (the other rows of the full aggregate are zero), every gradient -- and the untouched part gets NO gradient where the
+    concatenated form hands back zeros."""
+    from hgn_amd import ops, topology
+    gen = torch.Generator().manual_seed(11)
+    n_mesh, n_hyper, E = 700, 37, 5000
+    N = n_mesh + n_hyper
+    lo = {'m': (0, n_mesh), 'h': (n_mesh, N)}
+    sp, rp = {'mesh_to_hyper': 'mh', 'hyper_to_mesh': 'hm', 'hyper_to_hyper': 'hh', 'mesh_to_mesh': 'mm'}[kind]
+    senders = torch.randint(*lo[sp], (E,), generator=gen)
+    receivers = torch.randint(*lo[rp], (E,), generator=gen)
+    topo = topology.EdgeTopology(senders, receivers, N, torch.device('cuda'))
+    ps, pr = topo.parts(n_mesh)
+    assert (ps, pr) == ('mh'.index(sp), 'mh'.index(rp))
+    sd = _mlp_sd(384, 128, True, seed=3)
+    w, wts = _weights(sd, True)
+    hm0, hh0 = torch.randn(n_mesh, 128, generator=gen).cuda(), torch.randn(n_hyper, 128, generator=gen).cuda()
+    e0 = torch.randn(E, 128, generator=gen).cuda()
+    k = len(agg)
+    w_y, w_a = torch.randn(E, 128, generator=gen).cuda(), torch.randn(N, k * 128, generator=gen).cuda()
+    offs = (0, n_mesh)
+
+    def run(by_part):
+        for t in wts:
+            t.grad = None
+        hm, hh, e = hm0.clone().requires_grad_(True), hh0.clone().requires_grad_(True), e0.clone().requires_grad_(True)
+        nodes = (hm, hh)
+        if by_part:
+            y, a = ops.edge_block(nodes[ps], e, topo, w, agg, parts=(offs[ps], offs[pr]), h_r=None if ps == pr else nodes[pr])
+            assert a.shape[0] == nodes[pr].shape[0]
+            wa = w_a[offs[pr]:offs[pr] + a.shape[0]]
+        else:
+            y, a = ops.edge_block(torch.cat(nodes), e, topo, w, agg)
+            wa = w_a
+        ((y * w_y).sum() + (a * wa).sum()).backward()
+        return y.detach(), a.detach(), hm.grad, hh.grad, e.grad, [t.grad.clone() for t in wts]
+
+    y1, a1, gm1, gh1, ge1, gw1 = run(True)
+    y0, a0, gm0, gh0, ge0, gw0 = run(False)
+    assert torch.equal(y1, y0)
+    r0 = offs[pr]
+    assert torch.equal(a1, a0[r0:r0 + a1.shape[0]])
+    rest = torch.ones(N, dtype=torch.bool); rest[r0:r0 + a1.shape[0]] = False
+    assert not bool(a0[rest.cuda()].any())
+    assert torch.equal(ge1, ge0)
+    for part, (g1, g0) in enumerate(((gm1, gm0), (gh1, gh0))):
+        if part in (ps, pr):
+            assert torch.equal(g1, g0)
+        else:
+            assert g1 is None and not bool(g0.any())
+    # (dW1's node-row blocks are sums over the rows of the launch in chunks whose size follows the row count: same terms, other
+    #  partial sums -- every other parameter gradient is formed over the same E edge rows)
+    assert H.rel_err(gw1[0], gw0[0]) <= 1e-6 and torch.equal(gw1[0][:, 256:], gw0[0][:, 256:])
+    for a, b in zip(gw1[1:], gw0[1:]):
+        assert torch.equal(a, b)
+
+
+def test_fused_mlp_with_left_out_input_blocks_equals_zero_sources():
+    """ops.fused_mlp(cols=...): an input block that is zero for every row of the launch (the aggregate of an edge set that arrives in
+    the other node part, heterographnet.py:17-33) is left out -- same output and source gradients as feeding zeros; its W1 columns
+    get a zero gradient."""
+    from hgn_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    M = 333
+    sd = _mlp_sd(128 + 512 + 128 + 512, 128, True, seed=9)
+    w, wts = _weights(sd, True)
+    x0 = [torch.randn(M, 128, generator=gen).cuda(), torch.randn(M, 128, generator=gen).cuda(), torch.randn(M, 512, generator=gen).cuda()]
+    w_o = torch.randn(M, 128, generator=gen).cuda()
+
+    def run(skip):
+        for t in wts:
+            t.grad = None
+        h, a1, a3 = [t.clone().requires_grad_(True) for t in x0]
+        if skip:      # columns: h 0..128 | (zeros) 128..640 | a1 640..768 | a3 768..1280
+            out = ops.fused_mlp([h, a1, a3], w, residual=0, cols=(0, 640, 768))
+        else:
+            out = ops.fused_mlp([h, torch.zeros(M, 512, device='cuda'), a1, a3], w, residual=0)
+        (out * w_o).sum().backward()
+        return out.detach(), h.grad, a1.grad, a3.grad, [t.grad.clone() for t in wts]
+
+    o1, gh1, ga1, gb1, gw1 = run(True)
+    o0, gh0, ga0, gb0, gw0 = run(False)
+    assert torch.equal(o1, o0) and torch.equal(gh1, gh0) and torch.equal(ga1, ga0) and torch.equal(gb1, gb0)
+    for a, b in zip(gw1, gw0):
+        assert torch.equal(a, b)
+    assert not bool(gw1[0][:, 128:640].any())
+    with pytest.raises(Exception):
+        ops.fused_mlp([x0[0], x0[1]], w, residual=0, cols=(0, 64))          # overlapping the source before
+
+
 @pytest.mark.parametrize('N,max_deg,seed', [(50, 65, 0), (700, 20, 1), (3, 65, 2), (1200, 9, 3), (300, 17, 4), (5, 3, 5), (200000, 12, 6)])
 def test_edge_block_fused_segment_sums(N, max_deg, seed):
     """The `sum` aggregation of e' and the receiver half of the pre-projection gradient come out of the edge kernels themselves

@@ -645,3 +645,15 @@ def test_two_contexts_with_different_precisions_from_two_threads_through_the_abi
     assert m1._hgn_ctx is not m2._hgn_ctx and m1._hgn_ctx.wq is not m2._hgn_ctx.wq
     m2.set_matmul_precision('bf16')
     assert (m1._hgn_ctx.products(), m2._hgn_ctx.products()) == (6, 1)
+
+
+def test_topology_parts_of_a_hierarchical_graph():
+    """topology.EdgeTopology.parts: which node part (0 mesh rows, 1 hyper rows) the senders / the receivers of a set lie in, from the
+    lowest / highest index of each side; None when the set is empty or a side straddles the split (the caller then concatenates)."""
+    from hgn_amd import topology
+    t = object.__new__(topology.EdgeTopology)
+    for span, n_mesh, want in (((0, 99, 0, 99), 100, (0, 0)), ((0, 99, 100, 115), 100, (0, 1)), ((100, 115, 100, 115), 100, (1, 1)),
+                               ((100, 115, 3, 99), 100, (1, 0)), ((0, 100, 0, 99), 100, None), ((0, 99, 99, 100), 100, None),
+                               (None, 100, None)):
+        t.span = span
+        assert t.parts(n_mesh) == want, (span, want)
