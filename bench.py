@@ -55,6 +55,7 @@ def parse():
     ap.add_argument('--no-cold', action='store_true', help='skip the cold-step (fresh index tensors) figures')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary configurations (pna; plate-shape hetero K=31)')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-kernel HIP events in the timed region')
+    ap.add_argument('--no-pack-plan', action='store_true', help='A/B: one pack launch per MLP and form instead of the one-launch table (ops.PackPlan)')
     ap.add_argument('--eager', action='store_true',
                     help='N=1: launch every kernel from the host in the timed region (per-kernel HIP events recorded live). '
                          'Default at N=1 is to replay the whole training step from one HIP graph, which keeps the measurement '
@@ -442,6 +443,8 @@ def main():
     torch.cuda.synchronize()
     log('first forward done')
     use_graph = not args.eager
+    if args.no_pack_plan:
+        ops.begin_step_packs = lambda c: None
     trainer = parallel.DataParallelTrainer(model, lr=1e-4, device_step=use_graph, wgrad_stream=args.side_stream, buckets=args.buckets,
                                            force_collectives=args.dp_rehearsal)
     n_params = trainer.fp.numel

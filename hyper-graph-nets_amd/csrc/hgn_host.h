@@ -18,7 +18,7 @@ extern thread_local int g_prof_tag;           // hipGetLastError() -> HGN_OK / H
 struct SlabReduceTask { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; long chunk_stride; };
 int launch_slab_reduce(const SlabReduceTask* tasks, int n_tasks, hipStream_t stream);                 // n_tasks <= HGN_MAX_WTASK
 //   LayerNorm-affine gradients from n_slabs per-workgroup slabs of 256 floats; `part`: LN_PARTS * 256 floats of scratch
-int launch_ln_reduce(const float* ws, long n_slabs, float* part, float* d_gamma, float* d_beta, int accumulate, hipStream_t stream);
+int launch_ln_reduce(float* ws, long n_slabs, float* part, float* d_gamma, float* d_beta, int accumulate, hipStream_t stream);
 
 // Records a HIP event pair around the launches issued in its scope when profiling is enabled.
 struct ProfScope {

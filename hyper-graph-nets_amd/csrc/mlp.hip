@@ -183,15 +183,19 @@ __global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
 #pragma unroll
     for (int w = 0; w < WG / 64; ++w) sum += lnl[w * 256 + threadIdx.x];
     a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;      // ticket of ln_reduce_kernel
   }
 }
 
 // Fixed-order column sum of the per-workgroup LayerNorm slabs [n_wg][256] -> dgamma[128], dbeta[128].
 // Two steps, both with whole 1 KiB slabs read by 256 consecutive threads: LN_PARTS blocks add the slabs b, b + LN_PARTS, ...
-// (eight loads in flight) into one partial slab each (stored behind the workgroup slabs), one block adds the partials in
-// fixed order.
+// (eight loads in flight) into one partial slab each (stored behind the workgroup slabs); the block that finishes LAST (a ticket
+// in the workspace's header slab, zeroed by the kernel that wrote the slabs) adds the partials in fixed order -- one launch, and the
+// result does not depend on which block that is.  (Two launches before: 64 of them per training step, 9 % of a one-graph step.)
 constexpr int LN_PARTS = 128;
-__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ ws, long n_wg, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ ws, long n_wg, float* part, unsigned* ticket,
+                                                        float* __restrict__ dg, float* __restrict__ db, int acc) {
+  __shared__ int is_last;
   const int c = threadIdx.x;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   long w = blockIdx.x;
@@ -201,15 +205,17 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
   }
   for (int u = 0; w < n_wg; w += LN_PARTS, ++u) s[u & 7] += ws[w * 256 + c];
   part[blockIdx.x * 256 + c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-}
-__global__ __launch_bounds__(256) void ln_final_kernel(const float* __restrict__ part, float* __restrict__ dg, float* __restrict__ db,
-                                                       int acc) {
-  const int c = threadIdx.x;
+  __threadfence();                                 // release: this thread's partial is visible device-wide before the ticket moves
+  __syncthreads();
+  if (c == 0) is_last = atomicAdd(ticket, 1u) == (unsigned)(LN_PARTS - 1);
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();                                 // acquire: the other blocks' partials
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 4
   for (int b = 0; b < LN_PARTS; b += 4) {
-    s0 += part[(b + 0) * 256 + c]; s1 += part[(b + 1) * 256 + c];
-    s2 += part[(b + 2) * 256 + c]; s3 += part[(b + 3) * 256 + c];
+    s0 += __builtin_nontemporal_load(part + (b + 0) * 256 + c); s1 += __builtin_nontemporal_load(part + (b + 1) * 256 + c);
+    s2 += __builtin_nontemporal_load(part + (b + 2) * 256 + c); s3 += __builtin_nontemporal_load(part + (b + 3) * 256 + c);
   }
   const float t = (s0 + s1) + (s2 + s3);
   float* dst = c < 128 ? dg + c : db + (c - 128);
@@ -255,9 +261,10 @@ __global__ __launch_bounds__(WG, 4) void linear_bwd_kernel(const LinArgs a) {
   if (valid) t_store(acc, a.out + row * a.ld_out, kq);
 }
 
-int launch_ln_reduce(const float* ws, long n_slabs, float* part, float* d_gamma, float* d_beta, int accumulate, hipStream_t stream) {
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3(LN_PARTS), dim3(256), 0, stream, ws, n_slabs, part);
-  hipLaunchKernelGGL(ln_final_kernel, dim3(1), dim3(256), 0, stream, part, d_gamma, d_beta, accumulate);
+// `ws`: the slabs as the kernels see them, i.e. one slab behind the start of the caller's ln_ws (its first slab is the header)
+int launch_ln_reduce(float* ws, long n_slabs, float* part, float* d_gamma, float* d_beta, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(LN_PARTS), dim3(256), 0, stream, ws, n_slabs, part, reinterpret_cast<unsigned*>(ws - 256),
+                     d_gamma, d_beta, accumulate);
   return hgn_check_launch("LayerNorm gradient reduce");
 }
 
@@ -327,7 +334,7 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
 extern "C" int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes) {
   if (!bytes || M < 0) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd_ln_workspace_bytes: bad argument");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
-  *bytes = ((size_t)tiles + LN_PARTS) * 256 * sizeof(float) + 256;      // workgroup slabs + the partial slabs of ln_reduce
+  *bytes = ((size_t)tiles + LN_PARTS + 1) * 256 * sizeof(float) + 256;  // header slab (ticket) + workgroup slabs + the partial slabs of ln_reduce
   return HGN_OK;
 }
 
@@ -358,16 +365,17 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
   if (a->seg_dz1 && (!a->seg_ids || a->ld_seg_dz1 < 128 || !hgn_mlp_bwd6_eligible(a)))
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: seg_dz1 needs seg_ids and the split-bf16 kernel");
+  hgn_mlp_bwd_t b = *a;
+  if (b.ln_ws) b.ln_ws += 256;                          // the kernels' slab 0 lies behind the header slab (ticket of ln_reduce_kernel)
   if (hgn_mlp_bwd6_eligible(a)) {
-    if (launch_mlp6_bwd(a, stream, &tiles) != HGN_OK) return HGN_E_LAUNCH;
+    if (launch_mlp6_bwd(&b, stream, &tiles) != HGN_OK) return HGN_E_LAUNCH;
   } else {
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, b);
   }
-  if (a->ln_ws) {
+  if (b.ln_ws) {
     // partial slabs live behind the slabs of a 64-row tiling (hgn_mlp_bwd_ln_workspace_bytes), whatever tiling ran
-    float* part = a->ln_ws + ((a->M + TILE_ROWS - 1) / TILE_ROWS) * 256;
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3(LN_PARTS), dim3(256), 0, (hipStream_t)stream, a->ln_ws, tiles, part);
-    hipLaunchKernelGGL(ln_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, a->d_gamma, a->d_beta, a->ln_accumulate);
+    float* part = b.ln_ws + ((a->M + TILE_ROWS - 1) / TILE_ROWS) * 256;
+    if (launch_ln_reduce(b.ln_ws, tiles, part, a->d_gamma, a->d_beta, a->ln_accumulate, (hipStream_t)stream) != HGN_OK) return HGN_E_LAUNCH;
   }
   return hgn_check_launch("hgn_mlp_bwd");
 }

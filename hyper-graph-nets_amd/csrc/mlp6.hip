@@ -25,8 +25,10 @@ namespace hgn {
 // ----------------------------------------------------------------------------------------------------------
 struct PackArgs { hgn_pack_t d[HGN_MAX_PACK]; };
 
-__global__ void pack_bf16x3_kernel(const PackArgs a) {
-  const hgn_pack_t d = a.d[blockIdx.y];
+__device__ __forceinline__ void pack_block(const hgn_pack_t& d);
+__global__ void pack_bf16x3_kernel(const PackArgs a) { pack_block(a.d[blockIdx.y]); }
+__global__ void pack_bf16x3_table_kernel(const hgn_pack_t* __restrict__ table) { pack_block(table[blockIdx.y]); }
+__device__ __forceinline__ void pack_block(const hgn_pack_t& d) {
   const float* __restrict__ W = d.W;
   const long ldw = d.ldw;
   const int n_out = d.n_out, n_in = d.n_in, transposed = d.transposed & 1, f16 = d.transposed & 2;
@@ -723,6 +725,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
 #pragma unroll
   for (int w = 0; w < WG / 64; ++w) sum += lnl[w * 256 + threadIdx.x];
   a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;        // ticket of ln_reduce_kernel (csrc/mlp.hip)
 }
 
 template <int NP>
@@ -766,6 +769,17 @@ extern "C" int hgn_pack_bf16x3(const hgn_pack_t* blocks, int n, void* stream) {
   }
   hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(2 * 2 * 8 * 64 * 8 / 256, n), dim3(256), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_pack_bf16x3");
+}
+
+extern "C" int hgn_pack_bf16x3_table(const hgn_pack_t* blocks, const hgn_pack_t* blocks_dev, int n, void* stream) {
+  if (!blocks || !blocks_dev || n < 1 || n > 65535) return hgn_fail(HGN_E_INVALID, "hgn_pack_bf16x3_table: 1..65535 blocks, host copy and device table");
+  for (int i = 0; i < n; ++i) {
+    const hgn_pack_t& d = blocks[i];
+    if (!d.W || !d.out || d.ldw < 1 || d.n_out < 1 || d.n_out > 128 || d.n_in < 1 || d.n_in > 128 || !aligned16(d.out))
+      return hgn_fail(HGN_E_INVALID, "hgn_pack_bf16x3_table: bad block (at most 128 x 128, 16-byte aligned output)");
+  }
+  hipLaunchKernelGGL(pack_bf16x3_table_kernel, dim3(2 * 2 * 8 * 64 * 8 / 256, n), dim3(256), 0, (hipStream_t)stream, blocks_dev);
+  return hgn_check_launch("hgn_pack_bf16x3_table");
 }
 
 // Eligibility of the split-bf16 forward: every source with a packed image (narrow sources: zero-padded blocks), 128-wide

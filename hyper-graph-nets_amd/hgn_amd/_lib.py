@@ -97,6 +97,7 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     'hgn_mlp_fwd': (C.c_int, [C.POINTER(MlpFwd), C.c_void_p]),
     'hgn_pack_bf16x3': (C.c_int, [C.POINTER(Pack), C.c_int, C.c_void_p]),
+    'hgn_pack_bf16x3_table': (C.c_int, [C.POINTER(Pack), C.c_void_p, C.c_int, C.c_void_p]),
     'hgn_set_matmul_products': (C.c_int, [C.c_int]),
     'hgn_get_matmul_products': (C.c_int, []),
     'hgn_mlp_fwd6_eligible': (C.c_int, [C.POINTER(MlpFwd)]),

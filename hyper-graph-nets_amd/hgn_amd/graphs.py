@@ -111,6 +111,8 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 trainer.step(self.static, self.target, self.mask)
         torch.cuda.current_stream().wait_stream(side)
+        if trainer.ctx.pack_plan is not None:
+            trainer.ctx.pack_plan.prepare(trainer.ctx)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = trainer.step(self.static, self.target, self.mask)
@@ -146,6 +148,8 @@ class GraphedShardStep:
             for _ in range(warmup):
                 self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
+        if trainer.ctx.pack_plan is not None:
+            trainer.ctx.pack_plan.prepare(trainer.ctx)        # (its descriptor table is written eagerly, never inside a capture)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: calls made by other threads of the process (the collective backend's watchdog) must not abort the capture
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
@@ -160,10 +164,12 @@ class GraphedShardStep:
         if tr.side is not None:
             tr.side.wait_stream(torch.cuda.current_stream())
             tr.ctx.wgrad_stream = tr.side
+        ops.begin_step_packs(tr.ctx)
         out = tr.model(self.static)
         self.width = out.shape[1]
         s = ((out - self.target) * self.maskf).square().sum()
         s.backward()
+        ops.end_step_packs(tr.ctx)
         if tr.side is not None:
             tr.ctx.wgrad_stream = None
             torch.cuda.current_stream().wait_stream(tr.side)

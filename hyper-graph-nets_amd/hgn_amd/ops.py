@@ -49,6 +49,9 @@ class Context:
         self.pack_epoch = 0
         self.pack_in_capture = True       # graphs.GraphedForward keeps the pack launches out of its captured graph
         self.pack_recorder = None         # list that collects the (weights, form) pairs a forward pass packs
+        self.pack_plan = None             # PackPlan of a trainer's step: every image the step uses, refreshed by ONE launch
+        self.plan_epoch = -1              # pack_epoch at which the plan last ran: packs_of then trusts its cache, also during a capture
+        self._plan_rec = None
         self.ws_cache = {}
         self.post_result = None
 
@@ -246,6 +249,45 @@ def storage_signature(pairs) -> tuple:
     return (_storage_epoch,) + tuple(w.w1.data_ptr() for w, _ in pairs)
 
 
+def _pack_form(transposed: bool, c: Context) -> int:
+    # forward-form images of the fp16 mode carry fp16 bit patterns in their leading third (hgn_pack_t.transposed | 2)
+    return 1 if transposed else (2 if c.products() == 2 else 0)
+
+
+def _pack_key(w: MLPWeights, t: int, c: Context) -> tuple:
+    return (_defaults_epoch, c.pack_epoch, t, w.w1._version, w.w2._version, w.w3._version, w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr())
+
+
+def _pack_buffer(w: MLPWeights, transposed: bool) -> torch.Tensor:
+    nb1 = (w.w1.shape[1] + LAT - 1) // LAT
+    st = getattr(w.w1, '_hgn_pk_t' if transposed else '_hgn_pk', None)
+    if st is not None and st[1].numel() == (nb1 + 2) * _lib.PACK_BLOCK_BYTES and st[1].device == w.w1.device:
+        return st[1]
+    return torch.empty((nb1 + 2) * _lib.PACK_BLOCK_BYTES, dtype=torch.uint8, device=w.w1.device)
+
+
+def _pack_descs(w: MLPWeights, t: int, buf: torch.Tensor, arr, at: int) -> int:
+    """Fill arr[at ...] with the descriptors of [W1 block 0 .. nb1-1, W2, W3] -> their number."""
+    nb1 = (w.w1.shape[1] + LAT - 1) // LAT
+    for b in range(nb1):
+        d = arr[at + b]
+        d.W = w.w1.data_ptr() + 4 * LAT * b; d.ldw = w.w1.shape[1]; d.n_out = LAT
+        d.n_in = min(LAT, w.w1.shape[1] - LAT * b); d.transposed = t
+        d.out = buf.data_ptr() + b * _lib.PACK_BLOCK_BYTES
+    for i, m in enumerate((w.w2, w.w3)):
+        d = arr[at + nb1 + i]
+        d.W = m.data_ptr(); d.ldw = LAT; d.n_out = m.shape[0]; d.n_in = LAT; d.transposed = t
+        d.out = buf.data_ptr() + (nb1 + i) * _lib.PACK_BLOCK_BYTES
+    return nb1 + 2
+
+
+def _pack_cache(w: MLPWeights, transposed: bool, key, buf) -> None:
+    try:
+        setattr(w.w1, '_hgn_pk_t' if transposed else '_hgn_pk', _lib.Volatile((key, buf)))
+    except Exception:
+        pass
+
+
 def packs_of(w: MLPWeights, transposed: bool = False, ctx: Optional[Context] = None):
     """-> uint8 tensor holding the packed blocks [W1 block 0 .. nb1-1, W2, W3] of this MLP (forward or transposed form; a
     first-layer width that is not a multiple of 128 gives a zero-padded last block), or None for a narrow output (decoder)."""
@@ -253,38 +295,88 @@ def packs_of(w: MLPWeights, transposed: bool = False, ctx: Optional[Context] = N
         return None
     c = ctx if ctx is not None else current()
     nb1 = (w.w1.shape[1] + LAT - 1) // LAT
-    attr = '_hgn_pk_t' if transposed else '_hgn_pk'
-    # forward-form images of the fp16 mode carry fp16 bit patterns in their leading third (hgn_pack_t.transposed | 2)
-    t = 1 if transposed else (2 if c.products() == 2 else 0)
-    key = (_defaults_epoch, c.pack_epoch, t, w.w1._version, w.w2._version, w.w3._version, w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr())
-    st = getattr(w.w1, attr, None)
+    t = _pack_form(transposed, c)
+    key = _pack_key(w, t, c)
+    st = getattr(w.w1, '_hgn_pk_t' if transposed else '_hgn_pk', None)
     if c.pack_recorder is not None:
         c.pack_recorder.append((w, transposed))
-    capturing = torch.cuda.is_current_stream_capturing() and c.pack_in_capture
+    # (a captured training step packs inside its graph -- unless its PackPlan already did, for this very epoch)
+    capturing = torch.cuda.is_current_stream_capturing() and c.pack_in_capture and c.plan_epoch != c.pack_epoch
     if st is not None and st[0] == key and not capturing:
         return st[1]
-    buf = st[1] if st is not None and st[1].numel() == (nb1 + 2) * _lib.PACK_BLOCK_BYTES else \
-        torch.empty((nb1 + 2) * _lib.PACK_BLOCK_BYTES, dtype=torch.uint8, device=w.w1.device)
+    buf = _pack_buffer(w, transposed)
     arr = (_lib.Pack * (nb1 + 2))()
-    for b in range(nb1):
-        d = arr[b]
-        d.W = w.w1.data_ptr() + 4 * LAT * b; d.ldw = w.w1.shape[1]; d.n_out = LAT
-        d.n_in = min(LAT, w.w1.shape[1] - LAT * b); d.transposed = t
-        d.out = buf.data_ptr() + b * _lib.PACK_BLOCK_BYTES
-    for i, m in enumerate((w.w2, w.w3)):
-        d = arr[nb1 + i]
-        d.W = m.data_ptr(); d.ldw = LAT; d.n_out = m.shape[0]; d.n_in = LAT; d.transposed = t
-        d.out = buf.data_ptr() + (nb1 + i) * _lib.PACK_BLOCK_BYTES
-    n = nb1 + 2
+    n = _pack_descs(w, t, buf, arr, 0)
     for i0 in range(0, n, _lib.HGN_MAX_PACK):
         cnt = min(_lib.HGN_MAX_PACK, n - i0)
         _lib.check(_lib.lib().hgn_pack_bf16x3(C.cast(C.byref(arr, i0 * C.sizeof(_lib.Pack)), C.POINTER(_lib.Pack)), cnt,
                                               _lib.stream_ptr()), 'hgn_pack_bf16x3')
-    try:
-        setattr(w.w1, attr, _lib.Volatile((key, buf)))
-    except Exception:
-        pass
+    _pack_cache(w, transposed, key, buf)
     return buf
+
+
+class PackPlan:
+    """Every packed image one training step uses -- recorded during a first step (Context.pack_recorder) -- refreshed by ONE launch
+    over a descriptor table in device memory (include/hgn_mp.h: hgn_pack_bf16x3_table) instead of one launch per MLP and form:
+    64 launches of ~4.5 us for the 15-block model, a tenth of a one-graph step.  The table is (re)built eagerly whenever an address
+    or the precision changed; a capture that finds it stale leaves the packing to packs_of."""
+
+    def __init__(self, pairs):
+        seen, self.items = set(), []
+        for w, transposed in pairs:
+            k = (w.w1.data_ptr(), bool(transposed))
+            if w.w3.shape[0] == LAT and w.w1.is_cuda and k not in seen:
+                seen.add(k)
+                self.items.append((w, bool(transposed)))
+        self.sig = self.host = self.table = self.bufs = None
+
+    def _signature(self, c: Context) -> tuple:
+        return (c.products(), _storage_epoch) + tuple(p for w, _ in self.items for p in (w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr()))
+
+    def prepare(self, c: Context) -> bool:
+        """Build the descriptor table if it is stale (eagerly: a host-to-device copy) -> whether launch() can run."""
+        if not self.items:
+            return False
+        sig = self._signature(c)
+        if sig != self.sig:
+            if torch.cuda.is_current_stream_capturing():
+                return False
+            self.bufs = [_pack_buffer(w, tr) for w, tr in self.items]
+            n = sum((w.w1.shape[1] + LAT - 1) // LAT + 2 for w, _ in self.items)
+            self.host = (_lib.Pack * n)()
+            at = 0
+            for (w, tr), buf in zip(self.items, self.bufs):
+                at += _pack_descs(w, _pack_form(tr, c), buf, self.host, at)
+            self.table = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(self.items[0][0].w1.device)
+            self.sig = sig
+        return True
+
+    def launch(self, c: Context) -> bool:
+        if not self.prepare(c):
+            return False
+        _lib.check(_lib.lib().hgn_pack_bf16x3_table(self.host, self.table.data_ptr(), len(self.host), _lib.stream_ptr()),
+                   'hgn_pack_bf16x3_table')
+        for (w, tr), buf in zip(self.items, self.bufs):
+            _pack_cache(w, tr, _pack_key(w, _pack_form(tr, c), c), buf)
+        c.plan_epoch = c.pack_epoch
+        return True
+
+
+def begin_step_packs(c: Context) -> None:
+    """First thing of a trainer's step: refresh every packed image with one launch (from the second step on; the first one records)."""
+    if c.pack_plan is not None:
+        c.pack_plan.launch(c)
+    elif c.pack_recorder is None and not torch.cuda.is_current_stream_capturing():
+        c._plan_rec = c.pack_recorder = []
+
+
+def end_step_packs(c: Context) -> None:
+    rec = c._plan_rec
+    if rec is not None:
+        if c.pack_recorder is rec:
+            c.pack_recorder = None
+        c._plan_rec = None
+        c.pack_plan = PackPlan(rec) if rec else None
 
 
 def _fill_common_fwd(a: _lib.MlpFwd, w: MLPWeights, out, res, saves):

@@ -268,10 +268,14 @@ class DataParallelTrainer:
             self.ctx.wgrad_stream = self.side
         # (the count rides in the LAST range: written before the backward pass, reduced after it)
         self.fp.count.copy_(mask.sum().to(torch.float32).reshape(1))
+        if self.fp.flat.is_cuda:
+            ops.begin_step_packs(self.ctx)                            # one launch refreshes every packed weight image of the step
         out = self.model(graph)
         diff = (out - target) * mask.unsqueeze(1).to(out.dtype)       # masked without boolean indexing: no host sync, capturable
         sq = diff.square().sum()                                      # local SUM; scaled to the global mean after the collective
         sq.backward()
+        if self.fp.flat.is_cuda:
+            ops.end_step_packs(self.ctx)
         if self.side is not None:
             self.ctx.wgrad_stream = None
             torch.cuda.current_stream().wait_stream(self.side)      # join: all weight gradients are in the flat buffer

@@ -183,6 +183,11 @@ typedef struct {
   void* out;                       /* HGN_PACK_BLOCK_BYTES, 16-byte aligned                                 */
 } hgn_pack_t;
 int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* stream);   /* one launch for up to HGN_MAX_PACK blocks */
+/* A training step re-packs EVERY weight block of the model after the optimizer moved them (src/migration/meshgraphnet.py:14-37: 2 MLPs
+ * per message-passing block + encoders, forward and transposed form: ~320 blocks for 15 blocks): ONE launch over a descriptor table
+ * that lives in device memory -- `blocks_dev` holds the same n_blocks descriptors as `blocks` (which is only validated here), written
+ * once by the caller; capturable (no host data is read at replay).  n_blocks <= 65535. */
+int hgn_pack_bf16x3_table(const hgn_pack_t* blocks /*host copy*/, const hgn_pack_t* blocks_dev /*device*/, int n_blocks, void* stream);
 /* DEFAULT precision of the split-bf16 kernels: what a call with `products` = 0 gets.  6 (default): the six products above, fp32 accurate -- the mode every
  * parity claim of this library refers to.  1: ONE bf16 MFMA per product (both operands rounded to bf16, fp32 accumulation,
  * relative error ~4e-3 per product; a third of the weight traffic, a sixth of the MFMAs).  2: the FORWARD products as ONE fp16
@@ -230,8 +235,9 @@ typedef struct {
   const float* agg_dout; int64_t ld_agg; int32_t n_agg_ops; int32_t agg_ops[4];
   const int32_t* agg_seg; const int32_t* agg_rowptr; const int32_t* agg_argmax; const int32_t* agg_argmin;
   /* Optional: LayerNorm-affine gradients  dgamma[j] = sum_i d_out_eff[i][j]*xhat[i][j],  dbeta[j] = sum_i d_out_eff[i][j]
-   * produced by the same pass (deterministic: per-wave shuffles -> per-workgroup slab -> two-level fixed-order sum).
-   * ln_ws: hgn_mlp_bwd_ln_workspace_bytes(M) bytes. */
+   * produced by the same pass (deterministic: per-wave shuffles -> per-workgroup slab -> two-level fixed-order sum, the second
+   * level by whichever block of the ONE reduction launch finishes last: same order of additions whichever it is).
+   * ln_ws: hgn_mlp_bwd_ln_workspace_bytes(M) bytes, contents arbitrary; one workspace per stream that runs backward passes. */
   float* d_gamma; float* d_beta; float* ln_ws; int32_t ln_accumulate;
   const void* W3pk_t; const void* W2pk_t;   /* optional packed images of W3 / W2 (transposed form): split-bf16 kernels */
   const uint32_t* relu_bits;                /* optional: the forward's relu_bits; z1 / z2 may be null then            */
