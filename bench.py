@@ -681,7 +681,8 @@ def main():
             s, which = k.get('seg_fwd_agg'), 'forward aggregation'
             if not s:
                 s, which = k.get('seg_fwd'), 'sender sums of dz1 (backward), rows gathered through the sender permutation'
-            if s:
+            # (one edge set only: with several sets of different sizes the mean launch time belongs to no byte count)
+            if s and len(sets) == 1:
                 n_out = 4 if (args.agg == 'pna' and which == 'forward aggregation') else 1
                 bytes_launch = 4 * 128 * E_rank + 4 * (N_nodes + 1) + 4 * 128 * N_nodes * n_out + (0 if which == 'forward aggregation' else 4 * E_rank)
                 t = s['ms'] / s['count'] * 1e-3
