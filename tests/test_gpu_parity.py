@@ -799,6 +799,54 @@ def test_state_dict_keys_and_lazy_api():
         assert torch.equal(m2(gg), m(gg))
 
 
+def test_one_launch_pack_table_equals_per_mlp_packs(monkeypatch):
+    """A trainer's step refreshes every packed weight image with ONE launch over a descriptor table in device memory
+    (include/hgn_mp.h: hgn_pack_bf16x3_table, ops.PackPlan: recorded during the first step, used from the second on) instead of one
+    launch per MLP and form.  Same images: three training steps give the same parameters bit for bit with and without the plan, the
+    plan covers every (weights, form) pair the step uses, and a moved precision rebuilds the table."""
+    from hgn_amd import ops, parallel
+    graph = synth.grid_graph(seed=3, nx=9, ny=8, clusters=4)
+    sets = [e.name for e in graph.edge_sets]
+    shapes = O.param_shapes('hyper', 'pna', 2, sets, 5, {n: 7 for n in sets}, 8, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=4)
+    N = 72
+    import hgn_amd
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    mask = torch.ones(N, dtype=torch.bool).cuda()
+    g = hgn_amd.MultiGraph([x.cuda() for x in graph.node_features],
+                           [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in graph.edge_sets])
+
+    def run(with_plan):
+        if not with_plan:
+            monkeypatch.setattr(ops, 'begin_step_packs', lambda c: None)
+        m = H.hip_model('hyper', 'pna', 2, sets, sd)
+        tr = parallel.DataParallelTrainer(m, lr=1e-3)
+        losses = [tr.step(g, target, mask).item() for _ in range(3)]
+        monkeypatch.undo()
+        return tr, losses
+
+    tr1, l1 = run(True)
+    tr0, l0 = run(False)
+    assert tr0.ctx.pack_plan is None
+    plan = tr1.ctx.pack_plan
+    assert plan is not None and plan.table is not None and len(plan.items) >= 2 * 4 * 2      # 2 blocks x (>= 4 MLPs) x 2 forms
+    assert l1 == l0 and torch.equal(tr1.fp.flat, tr0.fp.flat)
+    # every image the step asks for is the plan's, fresh for the current epoch
+    rec = []
+    tr1.ctx.pack_recorder = rec
+    ops.begin_step_packs(tr1.ctx)
+    with ops.using(tr1.ctx):
+        tr1.model(g).sum().backward()
+    tr1.ctx.pack_recorder = None
+    have = {(w.w1.data_ptr(), tr) for w, tr in plan.items}
+    assert rec and all((w.w1.data_ptr(), bool(tr)) in have for w, tr in rec)
+    table = plan.table
+    tr1.ctx.set_matmul_precision('bf16')                       # other images (forward form of the fp16 mode aside): same table layout,
+    tr1.ctx.set_matmul_precision('fp16')                       # but the descriptors' form flags change -> rebuilt
+    ops.begin_step_packs(tr1.ctx)
+    assert plan.table is not table
+
+
 def test_trainer_flat_gradients_and_adam_match_torch():
     """Flat-buffer training path (kernels accumulate straight into the flat gradient, fused HIP Adam) against plain
     autograd + torch.optim.Adam on the same model / batch: gradients after one step and weights after three."""
