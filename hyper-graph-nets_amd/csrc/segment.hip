@@ -78,12 +78,13 @@ __global__ void narrow_gather_kernel(const int64_t* __restrict__ src, const int*
 // ----------------------------------------------------------------------------------------------------------
 // forward, D == 128: half-wave per row
 // ----------------------------------------------------------------------------------------------------------
+template <bool FEW>      // FEW: few rows, possibly long ones (launch): 64-thread workgroups, 16 rows in flight; same additions in the same order
 __global__ __launch_bounds__(256) void seg_fwd128_kernel(const float* __restrict__ data, long ld,
                                                          const int* __restrict__ perm,
                                                          const int* __restrict__ rowptr, long N, Ops ops,
                                                          float* __restrict__ out, long ld_out,
                                                          int* __restrict__ argmax, int* __restrict__ argmin) {
-  const long n = ((long)blockIdx.x * 256 + threadIdx.x) >> 5;
+  const long n = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;      // (64-thread workgroups when there are few rows: see the launch)
   if (n >= N) return;
   const int c = (threadIdx.x & 31) * 4;
   const int beg = rowptr[n], end = rowptr[n + 1];
@@ -97,6 +98,29 @@ __global__ __launch_bounds__(256) void seg_fwd128_kernel(const float* __restrict
 #pragma unroll
   for (int u = 0; u < 4; ++u) { mx[u] = -INFINITY; mn[u] = INFINITY; amx[u] = -1; amn[u] = -1; }
   int j = beg;
+  // Long segments (the rows that arrive at a hyper node: ~100 per cluster): 16 rows in flight, consumed in the same order as below --
+  // the walk of one segment is a chain of memory round trips, and the few segments of such a set leave most of the chip idle.
+  for (; FEW && j + 16 <= end; j += 16) {
+    float4 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long src = perm ? perm[j + q] : (j + q);
+      v[q] = *reinterpret_cast<const float4*>(data + src * ld + c);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w;
+      const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+      if (want_max) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (e[u] > mx[u] || amx[u] < 0) { mx[u] = e[u]; amx[u] = j + q; }
+      }
+      if (want_min) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (e[u] < mn[u] || amn[u] < 0) { mn[u] = e[u]; amn[u] = j + q; }
+      }
+    }
+  }
   // 4 rows in flight per half-wave
   for (; j + 4 <= end; j += 4) {
     float4 v[4];
@@ -404,8 +428,13 @@ extern "C" int hgn_segment_reduce_fwd(const float* data, int64_t ld, int D, cons
   ProfScope ps(g_prof_tag == 2 ? 12 : 5, (double)N, (hipStream_t)stream);
   const bool fast = D == 128 && (ld & 3) == 0 && (ld_out & 3) == 0 && ((uintptr_t)data & 15) == 0 && ((uintptr_t)out & 15) == 0;
   if (fast) {
-    hipLaunchKernelGGL(seg_fwd128_kernel, dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, data,
-                       (long)ld, perm, rowptr, (long)N, o, out, (long)ld_out, argmax, argmin);
+    // few rows (a hyper part: 2 048 rows = 64 workgroups of 256 threads on 256 CUs): two rows per workgroup instead of eight
+    if (N * 32 <= 256L * 256)
+      hipLaunchKernelGGL(seg_fwd128_kernel<true>, dim3((unsigned)((N * 32 + 63) / 64)), dim3(64), 0, (hipStream_t)stream, data,
+                         (long)ld, perm, rowptr, (long)N, o, out, (long)ld_out, argmax, argmin);
+    else
+      hipLaunchKernelGGL(seg_fwd128_kernel<false>, dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, data,
+                         (long)ld, perm, rowptr, (long)N, o, out, (long)ld_out, argmax, argmin);
   } else {
     hipLaunchKernelGGL(seg_fwd_generic_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, data,
                        (long)ld, D, perm, rowptr, (long)N, o, out, (long)ld_out, argmax, argmin);
