@@ -339,6 +339,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     bar_lds();                                        // (E) every chain wave's LayerNorm partials are in LDS
     const float sum = (lnl[tid] + lnl[256 + tid]) + (lnl[512 + tid] + lnl[768 + tid]);
     a.ln_ws[(long)blockIdx.x * 256 + tid] = sum;
+    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;     // ticket of ln_reduce_kernel (csrc/mlp.hip)
   } else {
     // ================================= weight gradients of layers 3 and 2 =================================
     const int ww = wave - 4, tw = tid - 256;
@@ -488,6 +489,7 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   const long G = fused_grid(a->M);
   FusedArgs fa;
   fa.b = *a;
+  fa.b.ln_ws += 256;                                  // slab 0 lies behind the header slab (ticket of ln_reduce_kernel)
   fa.A[0] = w->z2; fa.ldA[0] = 128;
   fa.A[1] = w->z1; fa.ldA[1] = 128;
   fa.slabs = (float*)workspace;
@@ -525,6 +527,6 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   }
   if (launch_slab_reduce(rt, 2, stream) != HGN_OK) return HGN_E_LAUNCH;
   // LayerNorm partial slabs: ln_ws holds hgn_mlp_bwd_ln_workspace_bytes(M) bytes = (tiles + parts) slabs; G <= tiles
-  if (launch_ln_reduce(a->ln_ws, G, a->ln_ws + G * 256, a->d_gamma, a->d_beta, a->ln_accumulate, stream) != HGN_OK) return HGN_E_LAUNCH;
+  if (launch_ln_reduce(fa.b.ln_ws, G, fa.b.ln_ws + G * 256, a->d_gamma, a->d_beta, a->ln_accumulate, stream) != HGN_OK) return HGN_E_LAUNCH;
   return hgn_check_launch("hgn_edge_bwd_fused (reductions)");
 }
