@@ -172,16 +172,7 @@ __device__ __forceinline__ void mfma_half6_sb(Act& acc, const bf16x8 (&xs)[3][4]
   }
 }
 
-// Row access with a UNIFORM base pointer and a 32-bit per-lane byte offset (eligibility bounds the arrays to 4 GiB): the
-// address stays one VGPR next to a scalar base instead of a hoisted 64-bit pointer per array that the allocator then spills.
-__device__ __forceinline__ void t_load32(Act& a, const float* __restrict__ base, unsigned byte_off) {
-  const char* p = reinterpret_cast<const char*>(base);
-  HGN_FOR_B(fb) a.v[fb] = *reinterpret_cast<const f32x4*>(p + (byte_off + 64u * fb));
-}
-__device__ __forceinline__ void t_store32(const Act& a, float* __restrict__ base, unsigned byte_off) {
-  char* p = reinterpret_cast<char*>(base);
-  HGN_FOR_B(fb) *reinterpret_cast<f32x4*>(p + (byte_off + 64u * fb)) = a.v[fb];
-}
+// (t_load32 / t_store32: csrc/hgn_device.h)
 
 // Counted wait: everything but the `keep` most recently issued vector-memory operations has completed (they retire in order).
 template <int KEEP>
