@@ -78,6 +78,14 @@ __global__ void narrow_gather_kernel(const int64_t* __restrict__ src, const int*
 // ----------------------------------------------------------------------------------------------------------
 // forward, D == 128: half-wave per row
 // ----------------------------------------------------------------------------------------------------------
+// Rows that are read once (the edge rows of a segment sum) come in as non-temporal loads: they do not push the row pointers, the
+// permutation and what the NEXT kernel wants to find out of the caches (seg_fwd128 -4 ... -8 %, the step -0.3 ms; the same hint on the row
+// loads of the two big edge kernels costs more downstream than it gains: profiles/HISTORY.md).
+typedef float f4v_stream __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load4(const float* p) {
+  const f4v_stream v = __builtin_nontemporal_load(reinterpret_cast<const f4v_stream*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 template <bool FEW>      // FEW: few rows, possibly long ones (launch): 64-thread workgroups, 16 rows in flight; same additions in the same order
 __global__ __launch_bounds__(256) void seg_fwd128_kernel(const float* __restrict__ data, long ld,
                                                          const int* __restrict__ perm,
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void seg_fwd128_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const long src = perm ? perm[j + q] : (j + q);
-      v[q] = *reinterpret_cast<const float4*>(data + src * ld + c);
+      v[q] = stream_load4(data + src * ld + c);
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void seg_fwd128_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const long src = perm ? perm[j + q] : (j + q);
-      v[q] = *reinterpret_cast<const float4*>(data + src * ld + c);
+      v[q] = stream_load4(data + src * ld + c);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void seg_fwd128_kernel(const float* __restrict
   }
   for (; j < end; ++j) {
     const long src = perm ? perm[j] : j;
-    const float4 v = *reinterpret_cast<const float4*>(data + src * ld + c);
+    const float4 v = stream_load4(data + src * ld + c);
     sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
     const float e[4] = {v.x, v.y, v.z, v.w};
     if (want_max) {

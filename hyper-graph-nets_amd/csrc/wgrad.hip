@@ -387,7 +387,7 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long r = min(r0 + j, a.M - 1);
-      x[j] = *reinterpret_cast<const f32x4*>(src + r * ld + 4 * q);
+      x[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + r * ld + 4 * q));      // streamed once (see csrc/segment.hip: stream_load4)
     }
   };
   if (nblocks > 0) fetch(0);
