@@ -184,6 +184,47 @@ __global__ __launch_bounds__(256) void seg_fwd128_kernel(const float* __restrict
   if (argmin && want_min) *reinterpret_cast<int4*>(argmin + n * 128 + c) = make_int4(amn[0], amn[1], amn[2], amn[3]);
 }
 
+// Two segment sums of the SAME rows in one pass (D = 128): out_a[n] = sum of the rows rowptr_a[n] .. rowptr_a[n+1] (in place: the
+// rows are sorted by that key), out_b[n] = sum of the rows perm_b[rowptr_b[n] ..] (a second key, through its permutation).  The backward
+// of a split edge layer needs both over dz1 -- by receiver and by sender (graphnet.py:22-32: h[receivers], h[senders]) -- and in a mesh
+// the rows a node SENDS are rows its neighbours RECEIVE: with workgroups of one XCD on a contiguous range of nodes the second
+// visit of a row finds it in that XCD's L2 (or in the Infinity Cache) instead of reading the array from HBM a second time.  Same
+// additions in the same order as two seg_fwd128 launches.
+__global__ __launch_bounds__(256) void seg_sum_pair128_kernel(const float* __restrict__ data, long ld, const int* __restrict__ rowptr_a,
+                                                              const int* __restrict__ perm_b, const int* __restrict__ rowptr_b, long N,
+                                                              float* __restrict__ out_a, long ld_a, float* __restrict__ out_b, long ld_b) {
+  // XCD b & 7 gets one contiguous range of workgroup slots (cf. hgn_device.h: xcd_tile)
+  const long nt = gridDim.x, b = blockIdx.x;
+  const long q = nt >> 3, r = nt & 7, x = b & 7, i = b >> 3;
+  const long slot = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  const long n = (slot * 256 + threadIdx.x) >> 5;
+  if (n >= N) return;
+  const int c = (threadIdx.x & 31) * 4;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int* __restrict__ rowptr = pass ? rowptr_b : rowptr_a;
+    const int beg = rowptr[n], end = rowptr[n + 1];
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = beg;
+    for (; j + 4 <= end; j += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long src = pass ? perm_b[j + u] : (j + u);
+        v[u] = *reinterpret_cast<const float4*>(data + src * ld + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+    }
+    for (; j < end; ++j) {
+      const long src = pass ? perm_b[j] : j;
+      const float4 v = *reinterpret_cast<const float4*>(data + src * ld + c);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    *reinterpret_cast<float4*>((pass ? out_b + n * ld_b : out_a + n * ld_a) + c) = sum;
+  }
+}
+
 // forward, any D: thread per (row, d)
 __global__ void seg_fwd_generic_kernel(const float* __restrict__ data, long ld, int D, const int* __restrict__ perm,
                                        const int* __restrict__ rowptr, long N, Ops ops, float* __restrict__ out,
@@ -448,6 +489,18 @@ extern "C" int hgn_segment_reduce_fwd(const float* data, int64_t ld, int D, cons
                        (long)ld, D, perm, rowptr, (long)N, o, out, (long)ld_out, argmax, argmin);
   }
   return hgn_check_launch("hgn_segment_reduce_fwd");
+}
+
+extern "C" int hgn_segment_sum_pair(const float* data, int64_t ld, const int32_t* rowptr_a, const int32_t* perm_b, const int32_t* rowptr_b,
+                                    int64_t N, float* out_a, int64_t ld_a, float* out_b, int64_t ld_b, void* stream) {
+  if (N == 0) return HGN_OK;
+  if (!data || !rowptr_a || !perm_b || !rowptr_b || !out_a || !out_b || N < 0 || ld < 128 || ld_a < 128 || ld_b < 128 || (ld & 3) || (ld_a & 3) ||
+      (ld_b & 3) || ((uintptr_t)data & 15) || ((uintptr_t)out_a & 15) || ((uintptr_t)out_b & 15))
+    return hgn_fail(HGN_E_INVALID, "hgn_segment_sum_pair: 128-wide rows, 16-byte aligned, leading dimensions multiples of 4");
+  ProfScope ps(5, (double)N, (hipStream_t)stream);
+  hipLaunchKernelGGL(seg_sum_pair128_kernel, dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, data, (long)ld, rowptr_a,
+                     perm_b, rowptr_b, (long)N, out_a, (long)ld_a, out_b, (long)ld_b);
+  return hgn_check_launch("hgn_segment_sum_pair");
 }
 
 extern "C" int hgn_segment_reduce_bwd(const float* d_out, int64_t ld_out, int D, const int32_t* perm, const int32_t* seg,

@@ -28,6 +28,7 @@ _DEFAULTS = {'precision': 'fp32', 'fp32_mfma': bool(_ENV.get('HGN_FP32_MFMA')), 
 _defaults_epoch = 0           # bumped when a default changes: packed weight images of every context are rebuilt on their next use
 _FUSED_SEG_MAX_ROWS = 65      # a segment of <= 65 consecutive rows touches at most two 64-row tiles
 _DEFER_NODE_WGRAD = not bool(_ENV.get('HGN_NO_DEFERRED_WGRAD'))
+_SEG_PAIR = not bool(_ENV.get('HGN_NO_SEG_PAIR'))      # sender and receiver sums of dz1 in one pass (hgn_segment_sum_pair) instead of two launches
 
 
 class Context:
@@ -974,11 +975,16 @@ class EdgeBlockFn(torch.autograd.Function):
                 _zero_unaccumulated(bufs[:6], accs[:6])
             _run_wgrad(c, tasks, E, dev, edge_level=True, keep=[z1, z2, e, dz1, dz2, dz3])
         ops = (C.c_int32 * 1)(0)
-        _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr() + 4 * off_s, Ns,
-                                            ops, 1, dPs, ldd, None, None, st), 'segment_reduce(senders)')
-        if not fuse_seg:
-            _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr() + 4 * off_r, Nr, ops, 1,
-                                                dPr, ldd, None, None, st), 'segment_reduce(receivers)')
+        if _SEG_PAIR and not fuse_seg and same and dz1.data_ptr() % 16 == 0:
+            # both sums in one pass over dz1: the rows a node sends are rows its neighbours receive (include/hgn_mp.h: hgn_segment_sum_pair)
+            _lib.check(L.hgn_segment_sum_pair(dz1.data_ptr(), LAT, topo.r.rowptr.data_ptr() + 4 * off_r, topo.s.perm.data_ptr(),
+                                              topo.s.rowptr.data_ptr() + 4 * off_s, Ns, dPr, ldd, dPs, ldd, st), 'segment_sum_pair')
+        else:
+            _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr() + 4 * off_s, Ns,
+                                                ops, 1, dPs, ldd, None, None, st), 'segment_reduce(senders)')
+            if not fuse_seg:
+                _lib.check(L.hgn_segment_reduce_fwd(dz1.data_ptr(), LAT, LAT, None, topo.r.rowptr.data_ptr() + 4 * off_r, Nr, ops, 1,
+                                                    dPr, ldd, None, None, st), 'segment_reduce(receivers)')
         task_s = _wtask(0, h_s.data_ptr(), _ld(h_s), LAT, None, dPs, ldd, LAT, dw1.data_ptr(), 3 * LAT, None, accs[0])
         task_r = _wtask(0, h_r.data_ptr(), _ld(h_r), LAT, None, dPr, ldd, LAT, dw1.data_ptr() + 4 * LAT, 3 * LAT, None, accs[0])
         if same:

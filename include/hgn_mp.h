@@ -83,6 +83,12 @@ int hgn_segment_reduce_bwd(const float* d_out, int64_t ld_out, int D, const int3
                            const int32_t* argmax, const int32_t* argmin, const float* base, float* d_data,
                            int64_t ld_data, void* stream);
 
+/* Two `sum` reductions of the same [E,128] rows in one pass: out_a[n] = sum of rows rowptr_a[n] .. rowptr_a[n+1] (the rows are sorted by that
+ * key), out_b[n] = sum of rows perm_b[rowptr_b[n] ..] (a second key through its CSR permutation); n < N for both.  What the backward of
+ * the split first edge layer needs over dz1 (graphnet.py:22-32: the gradient of h[receivers] and of h[senders]); bit-identical to two
+ * hgn_segment_reduce_fwd calls, one read of the rows from HBM instead of two on mesh-like graphs. */
+int hgn_segment_sum_pair(const float* data, int64_t ld, const int32_t* rowptr_a, const int32_t* perm_b, const int32_t* rowptr_b, int64_t N,
+                         float* out_a, int64_t ld_a, float* out_b, int64_t ld_b, void* stream);
 /* The fifth operation of util.unsorted_segment_operation, 'std' (src/util.py:129-130 -> torch_scatter.scatter_std with its default
  * unbiased = True; unreachable from the reference's configs).  torch-scatter 2.0.9 (torch_scatter/composite/std.py) as published:
  *   count = max(#rows of the segment, 1);  mean = sum / count;  out = sqrt( sum (x - mean)^2 / (max(count - 1, 1) + 1e-6) )

@@ -402,6 +402,40 @@ def test_edge_block_vs_oracle(nx, ny):
         assert H.rel_err(t.grad, sdo[n].grad) <= TOL_GRAD, n
 
 
+@pytest.mark.parametrize('N,max_deg,seed', [(50, 70, 0), (1237, 9, 1), (3, 5, 2), (20000, 12, 3)])
+def test_segment_sum_pair_equals_two_segment_reduce_launches_bit_for_bit(N, max_deg, seed):
+    """include/hgn_mp.h: hgn_segment_sum_pair -- the receiver sums and the sender sums of dz1 (graphnet.py:22-32 backward) in one pass over
+    the rows: same additions in the same order as two hgn_segment_reduce_fwd launches, ragged and empty segments, rows past a multiple
+    of the workgroup size."""
+    import ctypes as C
+    from hgn_amd import _lib, topology
+    gen = torch.Generator().manual_seed(seed)
+    deg = torch.randint(0, max_deg + 1, (N,), generator=gen)
+    receivers = torch.repeat_interleave(torch.arange(N), deg)
+    E = receivers.shape[0]
+    receivers = receivers[torch.randperm(E, generator=gen)]
+    senders = torch.randint(0, N, (E,), generator=gen)
+    topo = topology.EdgeTopology(senders, receivers, N, torch.device('cuda'))
+    data = torch.randn(E, 128, generator=gen).cuda()
+    L, st = _lib.lib(), _lib.stream_ptr()
+    ops = (C.c_int32 * 1)(0)
+    ref = torch.empty(N, 256, device='cuda')
+    _lib.check(L.hgn_segment_reduce_fwd(data.data_ptr(), 128, 128, topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N, ops, 1,
+                                        ref.data_ptr(), 256, None, None, st), 'senders')
+    _lib.check(L.hgn_segment_reduce_fwd(data.data_ptr(), 128, 128, None, topo.r.rowptr.data_ptr(), N, ops, 1,
+                                        ref.data_ptr() + 512, 256, None, None, st), 'receivers')
+    got = torch.full((N, 256), float('nan'), device='cuda')
+    _lib.check(L.hgn_segment_sum_pair(data.data_ptr(), 128, topo.r.rowptr.data_ptr(), topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N,
+                                      got.data_ptr() + 512, 256, got.data_ptr(), 256, st), 'pair')
+    assert torch.equal(got, ref)
+    # against the definition
+    srt_rcv = topo.rcv.cpu().long()
+    want = torch.zeros(N, 128, dtype=torch.float64).index_add_(0, srt_rcv, data.cpu().double())
+    assert H.rel_err(got[:, 128:], want) <= 1e-6
+    assert L.hgn_segment_sum_pair(data.data_ptr(), 100, topo.r.rowptr.data_ptr(), topo.s.perm.data_ptr(), topo.s.rowptr.data_ptr(), N,
+                                  got.data_ptr() + 512, 256, got.data_ptr(), 256, st) != 0            # rows narrower than 128: refused
+
+
 @pytest.mark.parametrize('kind', ['mesh_to_hyper', 'hyper_to_mesh', 'hyper_to_hyper', 'mesh_to_mesh'])
 @pytest.mark.parametrize('agg', [('sum',), ('sum', 'mean', 'max', 'min')])
 def test_edge_block_by_node_part_equals_the_concatenated_form_bit_for_bit(kind, agg):
