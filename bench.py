@@ -679,18 +679,22 @@ def main():
             # kernel, rows gathered through the sender permutation); with pna the forward aggregation launch is reported.
             # Algorithmic bytes, sum: 4*D*E + 4*(N+1) + 4*D*N (+ 4*E for the permutation)
             s, which = k.get('seg_fwd_agg'), 'forward aggregation'
+            pair = bool(getattr(ops, '_SEG_PAIR', False)) and args.arch == 'none'
             if not s:
-                s, which = k.get('seg_fwd'), 'sender sums of dz1 (backward), rows gathered through the sender permutation'
+                s, which = k.get('seg_fwd'), ('sender AND receiver sums of dz1 (backward) in one pass over the rows: hgn_segment_sum_pair' if pair else
+                                              'sender sums of dz1 (backward), rows gathered through the sender permutation')
             # (one edge set only: with several sets of different sizes the mean launch time belongs to no byte count)
             if s and len(sets) == 1:
                 n_out = 4 if (args.agg == 'pna' and which == 'forward aggregation') else 1
                 bytes_launch = 4 * 128 * E_rank + 4 * (N_nodes + 1) + 4 * 128 * N_nodes * n_out + (0 if which == 'forward aggregation' else 4 * E_rank)
+                if pair and which != 'forward aggregation':     # rows once, two [N,128] outputs, two row-pointer arrays, one permutation
+                    bytes_launch = 4 * 128 * E_rank + 2 * 4 * (N_nodes + 1) + 2 * 4 * 128 * N_nodes + 4 * E_rank
                 t = s['ms'] / s['count'] * 1e-3
                 ach = bytes_launch / t / 1e9
                 agg_traffic, agg_note = None, None
                 try:        # PMC bytes of that launch, same stamped record as the dominant kernel's
                     pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-                    ent = pm.get('seg_fwd_agg' if which == 'forward aggregation' else 'seg_fwd')
+                    ent = pm.get('seg_fwd_agg' if which == 'forward aggregation' else ('seg_pair' if pair else 'seg_fwd'))
                     if pm.get('kernel_source_sha') != sha:
                         agg_note = f"profiles/pmc_traffic.json is for kernel sources {pm.get('kernel_source_sha')}, now {sha}: dropped as stale"
                     elif ent and int(ent.get('rows_per_launch', -1)) in (int(N_nodes), int(E_rank)):
@@ -698,7 +702,7 @@ def main():
                         agg_note = f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE at commit {pm.get('commit')}: profiles/pmc_traffic.json"
                 except Exception as ex:
                     agg_note = f'no PMC record ({type(ex).__name__})'
-                res['roofline_aggregation'] = {'kernel': f'seg_fwd128 ({which})', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
+                res['roofline_aggregation'] = {'kernel': f"{'seg_sum_pair128' if (pair and which != 'forward aggregation') else 'seg_fwd128'} ({which})", 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
                                                'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': agg_traffic, 'traffic_source': agg_note,
                                                'bytes_per_launch': bytes_launch, 'ms_per_launch': t * 1e3,
                                                'north_star_target': 'at least 0.40 of the HBM roofline on the scatter-add aggregation'}

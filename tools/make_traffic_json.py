@@ -26,7 +26,7 @@ out = {'commit': sys.argv[5] if len(sys.argv) > 5 else None, 'kernel_source_sha'
 per_step = 0.0
 fused_present = any('edge_bwd_fused_kernel' in kk[0] for kk in fetch)
 for bench_name, kern in (('mlp_fwd_edge', 'mlp6_fwd_kernel'), ('mlp_bwd_edge', 'mlp6_bwd_kernel'), ('wgrad', 'wgrad6s_kernel'),
-                         ('edge_bwd_fused', 'edge_bwd_fused_kernel'), ('seg_fwd', 'seg_fwd128_kernel')):
+                         ('edge_bwd_fused', 'edge_bwd_fused_kernel'), ('seg_fwd', 'seg_fwd128_kernel'), ('seg_pair', 'seg_sum_pair128_kernel')):
     if bench_name == 'mlp_bwd_edge' and fused_present:
         continue                                              # only the encoder's backward is left on that kernel at the edge grid
     keys = [k for k in fetch if kern in k[0]]
@@ -43,7 +43,8 @@ for bench_name, kern in (('mlp_fwd_edge', 'mlp6_fwd_kernel'), ('mlp_bwd_edge', '
                        'read_bytes_per_edge_row': 2 * f_kib * 1024 / rows, 'write_bytes_per_edge_row': w_kib * 1024 / rows}
 # launches per processor layer and step (profiles/r02_kernel_split.csv): one each; with the fused backward the sender AND the
 # receiver sums of dz1 are stand-alone launches (the two-launch backward forms the receiver sums itself)
-for bench_name in ('mlp_fwd_edge', 'mlp_bwd_edge', 'wgrad', 'edge_bwd_fused', 'seg_fwd'):
+# (round 4: ONE paired launch, seg_pair, forms both sums; seg_fwd is then absent from the sum configuration)
+for bench_name in ('mlp_fwd_edge', 'mlp_bwd_edge', 'wgrad', 'edge_bwd_fused', 'seg_fwd', 'seg_pair'):
     if bench_name in out:
         e = out[bench_name]
         e['launches_per_layer'] = 2 if (bench_name == 'seg_fwd' and fused_present) else 1
