@@ -494,7 +494,8 @@ extern "C" int hgn_segment_reduce_fwd(const float* data, int64_t ld, int D, cons
 extern "C" int hgn_segment_sum_pair(const float* data, int64_t ld, const int32_t* rowptr_a, const int32_t* perm_b, const int32_t* rowptr_b,
                                     int64_t N, float* out_a, int64_t ld_a, float* out_b, int64_t ld_b, void* stream) {
   if (N == 0) return HGN_OK;
-  if (!data || !rowptr_a || !perm_b || !rowptr_b || !out_a || !out_b || N < 0 || ld < 128 || ld_a < 128 || ld_b < 128 || (ld & 3) || (ld_a & 3) ||
+  // (data / perm_b may be null when there are no rows: every segment is then empty and neither is dereferenced)
+  if (!rowptr_a || !rowptr_b || !out_a || !out_b || N < 0 || ld < 128 || ld_a < 128 || ld_b < 128 || (ld & 3) || (ld_a & 3) ||
       (ld_b & 3) || ((uintptr_t)data & 15) || ((uintptr_t)out_a & 15) || ((uintptr_t)out_b & 15))
     return hgn_fail(HGN_E_INVALID, "hgn_segment_sum_pair: 128-wide rows, 16-byte aligned, leading dimensions multiples of 4");
   ProfScope ps(5, (double)N, (hipStream_t)stream);
