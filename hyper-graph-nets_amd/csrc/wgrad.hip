@@ -366,10 +366,12 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
   const WTaskDev t = a.t[a.task0 + blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kg = lane >> 4;
-  const long row_beg = (long)blockIdx.x * a.rows_per_chunk;
-  const long row_end = min(a.M, row_beg + a.rows_per_chunk);
+  // Workgroup x takes the 32-row blocks x, x + n_chunks, x + 2 n_chunks, ...: all workgroups sweep the two arrays TOGETHER, front to back
+  // (one coherent stream through HBM instead of 512 private ones: -3 % per launch, -0.5 ms per step against contiguous chunks).
+  const long nblk_all = (a.M + 31) / 32;
+  const long row_end = a.M;
   float* slab = t.slab + (long)blockIdx.x * SLAB;
-  const int nblocks = row_beg < row_end ? (int)((row_end - row_beg + 31) / 32) : 0;
+  const int nblocks = nblk_all > (long)blockIdx.x ? (int)((nblk_all - (long)blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
   // producer role of this lane: array (waves 0,1: A; waves 2,3: G), row group of the block, feature quad
   const int arr = wave >> 1, kgp = 2 * (wave & 1) + (lane >> 5), q = lane & 31;
   const float* src = arr ? t.G : t.A;
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
   f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};             // column sums of G (bias gradient) of this lane's quad and row group
   f32x4 x[8];
   auto fetch = [&](int p) {
-    const long r0 = row_beg + 32L * p + 8 * kgp;
+    const long r0 = ((long)p * gridDim.x + blockIdx.x) * 32 + 8 * kgp;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long r = min(r0 + j, a.M - 1);
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
   };
   if (nblocks > 0) fetch(0);
   for (int p = 0; p < nblocks; ++p) {
-    const long r0 = row_beg + 32L * p + 8 * kgp;
+    const long r0 = ((long)p * gridDim.x + blockIdx.x) * 32 + 8 * kgp;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (arr) {                                      // rows past the chunk end contribute nothing
 #pragma unroll
