@@ -187,14 +187,13 @@ __device__ __forceinline__ void wg_barrier_lds() {
   __builtin_amdgcn_s_barrier();
 }
 
-// Row tile of this workgroup.  Workgroups b and b+8 run on the same XCD (round-robin dispatch; used for speed only,
-// never for correctness): give every XCD one CONTIGUOUS range of row tiles, so that the node rows gathered by
-// neighbouring edge tiles (same graph, receiver-sorted) are served by that XCD's own 4 MiB L2.
-__device__ __forceinline__ long xcd_tile() {
-  const long nt = gridDim.x, b = blockIdx.x;
-  const long q = nt >> 3, r = nt & 7, x = b & 7, i = b >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
+// Row tile of this workgroup: the launch order.  All workgroups then sweep the row arrays front to back TOGETHER, one coherent stream
+// through HBM.  (Rounds 1-3 gave every XCD one contiguous range of tiles -- workgroups b and b + 8 share an XCD under round-robin dispatch
+// -- so that the node rows gathered by neighbouring edge tiles would be served by that XCD's own L2: eight concurrent sweeps.  Measured
+// against each other on the final kernels, A/B on one box: edge forward 1.016 -> 0.987 ms, pre-projection 0.108 -> 0.104 ms, step
+// 59.19 / 59.03 -> 58.87 / 58.82 ms in favour of the single sweep; the gathered rows come from the Infinity Cache either way.  The paired
+// segment sums, whose second visit of a row depends on L2, keep the XCD ranges: csrc/segment.hip.)
+__device__ __forceinline__ long xcd_tile() { return blockIdx.x; }
 
 // Row-tile <-> global memory.  The lane owns 16 bytes per 16-feature block: row n, columns 16*fb + 4*kq .. +3.
 #define HGN_FOR_B(fb) _Pragma("unroll") for (int fb = 0; fb < NB; ++fb)
