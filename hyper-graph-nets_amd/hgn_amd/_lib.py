@@ -91,6 +91,8 @@ _SIGS = {
     'hgn_segment_reduce_bwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'hgn_segment_reduce_bwd_sorted': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'hgn_segment_sum_pair': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_int64, C.c_void_p]),
     'hgn_segment_std_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

@@ -83,6 +83,13 @@ int hgn_segment_reduce_bwd(const float* d_out, int64_t ld_out, int D, const int3
                            const int32_t* argmax, const int32_t* argmin, const float* base, float* d_data,
                            int64_t ld_data, void* stream);
 
+/* hgn_segment_reduce_bwd for D = 128 and rows already in segment order (perm == null), parallel over the N SEGMENTS: rows
+ * rowptr[n] .. rowptr[n+1] get base + the aggregation backward of segment n; d_out / argmax / argmin are indexed by n (n < N).  Same result
+ * bit for bit; a segment's gradient and arg rows are loaded once instead of once per row. */
+int hgn_segment_reduce_bwd_sorted(const float* d_out, int64_t ld_out, const int32_t* rowptr, int64_t N, const int32_t* ops /*host*/, int n_ops,
+                                  const int32_t* argmax, const int32_t* argmin, const float* base, float* d_data, int64_t ld_data,
+                                  void* stream);
+
 /* Two `sum` reductions of the same [E,128] rows in one pass: out_a[n] = sum of rows rowptr_a[n] .. rowptr_a[n+1] (the rows are sorted by that
  * key), out_b[n] = sum of rows perm_b[rowptr_b[n] ..] (a second key through its CSR permutation); n < N for both.  What the backward of
  * the split first edge layer needs over dz1 (graphnet.py:22-32: the gradient of h[receivers] and of h[senders]); bit-identical to two
