@@ -402,6 +402,40 @@ def test_edge_block_vs_oracle(nx, ny):
         assert H.rel_err(t.grad, sdo[n].grad) <= TOL_GRAD, n
 
 
+@pytest.mark.parametrize('with_base', [True, False])
+@pytest.mark.parametrize('N,max_deg,seed', [(60, 70, 0), (1237, 9, 1), (3, 5, 2)])
+def test_segment_reduce_bwd_sorted_equals_the_edge_parallel_kernel_bit_for_bit(N, max_deg, seed, with_base):
+    """include/hgn_mp.h: hgn_segment_reduce_bwd_sorted -- the aggregation backward of the four pna aggregates (graphnet.py:50-70 under autograd)
+    for rows in receiver order, one half-wave per RECEIVER: the same bits as hgn_segment_reduce_bwd (one half-wave per row), with and without
+    the d(e') base, ragged and empty segments, ties among the winners."""
+    import ctypes as C
+    from hgn_amd import _lib, topology
+    gen = torch.Generator().manual_seed(seed)
+    deg = torch.randint(0, max_deg + 1, (N,), generator=gen)
+    receivers = torch.repeat_interleave(torch.arange(N), deg)
+    E = receivers.shape[0]
+    senders = torch.randint(0, N, (E,), generator=gen)
+    topo = topology.EdgeTopology(senders, receivers, N, torch.device('cuda'))
+    data = torch.randint(-3, 4, (E, 128), generator=gen).float().cuda()              # many ties
+    L, st = _lib.lib(), _lib.stream_ptr()
+    ops = (C.c_int32 * 4)(0, 1, 2, 3)
+    agg = torch.empty(N, 512, device='cuda')
+    amax = torch.empty(N, 128, dtype=torch.int32, device='cuda'); amin = torch.empty_like(amax)
+    _lib.check(L.hgn_segment_reduce_fwd(data.data_ptr(), 128, 128, None, topo.r.rowptr.data_ptr(), N, ops, 4, agg.data_ptr(), 512,
+                                        amax.data_ptr(), amin.data_ptr(), st), 'fwd')
+    d_agg = torch.randn(N, 512, generator=gen).cuda()
+    base = torch.randn(E, 128, generator=gen).cuda() if with_base else None
+    ref = torch.full((E, 128), float('nan'), device='cuda'); got = torch.full((E, 128), float('nan'), device='cuda')
+    bp = base.data_ptr() if base is not None else None
+    _lib.check(L.hgn_segment_reduce_bwd(d_agg.data_ptr(), 512, 128, None, topo.rcv.data_ptr(), topo.r.rowptr.data_ptr(), E, ops, 4,
+                                        amax.data_ptr(), amin.data_ptr(), bp, ref.data_ptr(), 128, st), 'edge-parallel')
+    _lib.check(L.hgn_segment_reduce_bwd_sorted(d_agg.data_ptr(), 512, topo.r.rowptr.data_ptr(), N, ops, 4, amax.data_ptr(), amin.data_ptr(), bp,
+                                               got.data_ptr(), 128, st), 'receiver-parallel')
+    assert torch.equal(got, ref)
+    assert L.hgn_segment_reduce_bwd_sorted(d_agg.data_ptr(), 512, topo.r.rowptr.data_ptr(), N, ops, 4, None, amin.data_ptr(), bp,
+                                           got.data_ptr(), 128, st) != 0                     # max without its arg rows: refused
+
+
 @pytest.mark.parametrize('N,max_deg,seed', [(50, 70, 0), (1237, 9, 1), (3, 5, 2), (20000, 12, 3)])
 def test_segment_sum_pair_equals_two_segment_reduce_launches_bit_for_bit(N, max_deg, seed):
     """include/hgn_mp.h: hgn_segment_sum_pair -- the receiver sums and the sender sums of dz1 (graphnet.py:22-32 backward) in one pass over
