@@ -108,7 +108,8 @@ def secondary_configs(args):
       * BASELINE.json configs[4] at one GPU: cylinder_flow-shape frames, hyper block, 25 MP layers, + balance set, fp16 forward
         products (`--precision fp16`: reduced precision, its own tolerance, tests/test_gpu_parity.py);
       * the plate configuration's EDGE-SET STRUCTURE on the flag grids (what round 2 reported as "plate config"): kept for
-        continuity under a name that says what it is."""
+        continuity under a name that says what it is;
+      * the headline model at the reference's own batch sizes: 1 graph and 21 graphs per step."""
     out = {}
     base = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '2', '--no-cold', '--no-cpu-baseline',
             '--no-secondary', '--batch', str(args.batch)]
@@ -121,7 +122,10 @@ def secondary_configs(args):
                          ['--workload', 'cylinder', '--arch', 'hyper', '--agg', 'pna', '--layers', '25', '--clusters', '16',
                           '--precision', 'fp16', '--no-prof']),
                         ('flag_grid_40x40_with_plate_edge_set_structure_hetero_pna_L5_K31',
-                         ['--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31', '--world-edges', '300'])):
+                         ['--arch', 'hetero', '--agg', 'pna', '--layers', '5', '--clusters', '31', '--world-edges', '300']),
+                        # the reference's own batch sizes (configs/flag.yaml:10 batch_size; one trajectory step at a time): launch-latency regime
+                        ('flag_simple_shape_1_graph_per_step', ['--batch', '1', '--steps', '40', '--warmup', '5', '--no-prof']),
+                        ('flag_simple_shape_21_graphs_per_step_reference_batch_size', ['--batch', '21', '--steps', '30', '--warmup', '5', '--no-prof'])):
         try:
             r = subprocess.run(base + extra, capture_output=True, text=True, timeout=420)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]
