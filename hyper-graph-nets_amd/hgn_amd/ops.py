@@ -934,12 +934,20 @@ class EdgeBlockFn(torch.autograd.Function):
             if L.hgn_edge_bwd_fused_eligible(C.byref(b2)):
                 g_eff = torch.empty(E, LAT, device=dev)
                 arr, codes = _ops_array(agg_ops)
-                # (rows are in receiver order: one half-wave per receiver loads its gradient / arg rows once: hgn_segment_reduce_bwd_sorted)
-                _lib.check(L.hgn_segment_reduce_bwd_sorted(d_agg.data_ptr(), _ld(d_agg), topo.r.rowptr.data_ptr() + 4 * off_r, Nr, arr, len(codes),
-                                                           amax.data_ptr() if amax is not None else None,
-                                                           amin.data_ptr() if amin is not None else None,
-                                                           d_out.data_ptr() if d_out is not None else None, g_eff.data_ptr(), LAT, st),
-                           'hgn_segment_reduce_bwd_sorted')
+                if E <= 16 * Nr:
+                    # rows are in receiver order: one half-wave per receiver loads its gradient / arg rows once (hgn_segment_reduce_bwd_sorted)
+                    _lib.check(L.hgn_segment_reduce_bwd_sorted(d_agg.data_ptr(), _ld(d_agg), topo.r.rowptr.data_ptr() + 4 * off_r, Nr, arr, len(codes),
+                                                               amax.data_ptr() if amax is not None else None,
+                                                               amin.data_ptr() if amin is not None else None,
+                                                               d_out.data_ptr() if d_out is not None else None, g_eff.data_ptr(), LAT, st),
+                               'hgn_segment_reduce_bwd_sorted')
+                else:   # few long segments (the rows that arrive at a hyper node): a half-wave per ROW keeps the chip busy, one per segment would not
+                    _lib.check(L.hgn_segment_reduce_bwd(d_agg.data_ptr() - 4 * _ld(d_agg) * off_r, _ld(d_agg), LAT, None, topo.rcv.data_ptr(),
+                                                        topo.r.rowptr.data_ptr(), E, arr, len(codes),
+                                                        amax.data_ptr() - 4 * LAT * off_r if amax is not None else None,
+                                                        amin.data_ptr() - 4 * LAT * off_r if amin is not None else None,
+                                                        d_out.data_ptr() if d_out is not None else None, g_eff.data_ptr(), LAT, st),
+                               'hgn_segment_reduce_bwd')
                 b2.d_out = g_eff.data_ptr()
                 b, fused = b2, True
         fuse_seg = (not fused and pk_t is not None and E > 0 and topo.r.max_rows <= _FUSED_SEG_MAX_ROWS
