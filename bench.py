@@ -33,6 +33,27 @@ PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix peak
 
 
+
+def limited_by(ent: dict, hbm_frac: float) -> str:
+    """The bound label of the roofline object, DERIVED from the counters of profiles/sq_counters.json (rocprofv3 SQ_* passes of the
+    same kernel sources) and the live HBM fraction: a roof binds above 70 % of it; otherwise the waves' own cycle split says whether
+    they mostly wait parked (s_waitcnt / barriers: latency) or mostly stand at issue (dependencies, a busy pipe: issue)."""
+    mp, parked = ent.get('matrix_pipe_busy_frac'), ent.get('waves_parked_frac')
+    stalled, issuing = ent.get('waves_stalled_at_issue_frac'), ent.get('waves_issuing_frac')
+    if mp is not None and mp >= 0.7:
+        label = 'mfma'
+    elif hbm_frac >= 0.7:
+        label = 'hbm'
+    elif parked is not None and stalled is not None and parked > stalled:
+        label = 'latency (waves parked at waits / barriers)'
+    elif stalled is not None:
+        label = 'issue (waves stalled at issue)'
+    else:
+        label = 'unknown (counters incomplete)'
+    return (f"{label}: matrix pipe {100 * (mp or 0):.0f} % busy, HBM {100 * hbm_frac:.0f} % of peak, waves issuing {100 * (issuing or 0):.0f} % / "
+            f"stalled at issue {100 * (stalled or 0):.0f} % / parked {100 * (parked or 0):.0f} % of their cycles")
+
+
 def log(*a):
     print('[bench]', *a, file=sys.stderr, flush=True)
 
@@ -653,7 +674,7 @@ def main():
                 ent = sq.get('kernels', {}).get(name)
                 if sq.get('kernel_source_sha') == sha and ent:
                     res['roofline']['counters'] = dict(ent, source=f"profiles/sq_counters.json (commit {sq.get('commit')}, kernel sources {sha})")
-                    res['roofline']['limited_by'] = ('issue: neither roof binds -- ' + ent.get('summary', ''))
+                    res['roofline']['limited_by'] = limited_by(ent, ach / PEAK_HBM_GBS)
                 else:
                     res['roofline']['counters'] = None
                     res['roofline']['limited_by'] = (f"(profiles/sq_counters.json is for kernel sources {sq.get('kernel_source_sha')}, now {sha}: dropped as stale)")

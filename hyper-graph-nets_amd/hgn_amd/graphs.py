@@ -92,6 +92,30 @@ class GraphedForward:
         return self.out
 
 
+class _PlanGuard:
+    """What a captured training step baked in of its context's ops.PackPlan: the device address of the descriptor table (argument of
+    the one pack launch) and the packed-image buffers (arguments of every split-product kernel).  Holds references to both -- a
+    replay never reads freed memory, whatever happened to the plan since -- and tells when the plan's CONTENT moved (a parameter
+    was re-homed, the precision changed): the captured step then holds stale addresses and must be captured again.  A bumped
+    ops storage epoch with unchanged addresses (some OTHER model's .to() / FlatParams) refreshes nothing and is not stale."""
+
+    def __init__(self, ctx):
+        self.ctx, self.plan = ctx, ctx.pack_plan
+        if self.plan is not None:
+            self.plan.prepare(ctx)
+            self.generation = self.plan.generation
+            self.keep = (self.plan.table, list(self.plan.bufs))
+
+    def stale(self) -> bool:
+        plan = self.ctx.pack_plan
+        if plan is not self.plan:
+            return True
+        if plan is None:
+            return False
+        plan.prepare(self.ctx)                                # eager: rewrites the table in place if a descriptor changed
+        return plan.generation != self.generation
+
+
 class GraphedTrainStep:
     """parallel.DataParallelTrainer.step (forward + loss + backward + fused Adam) for a fixed topology, single process.
     The trainer must have been built with ``device_step=True`` (the Adam step counter lives on the device)."""
@@ -111,17 +135,24 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 trainer.step(self.static, self.target, self.mask)
         torch.cuda.current_stream().wait_stream(side)
-        if trainer.ctx.pack_plan is not None:
-            trainer.ctx.pack_plan.prepare(trainer.ctx)
+        self.captures = 0
+        self._capture()
+
+    def _capture(self) -> None:
+        trainer = self.trainer
+        self._plan = _PlanGuard(trainer.ctx)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = trainer.step(self.static, self.target, self.mask)
+        self.captures += 1
 
     def __call__(self, node_features=None, edge_features: Optional[Dict[str, torch.Tensor]] = None, target=None) -> torch.Tensor:
         if node_features is not None:
             _copy_in(self.static, node_features, edge_features or {})
         if target is not None:
             self.target.copy_(target, non_blocking=True)
+        if self._plan.stale():
+            self._capture()
         self.graph.replay()
         self.trainer.ctx.invalidate_packs()      # the replayed Adam kernel rewrote the parameters: an eager forward must re-pack them
         return self.loss
@@ -148,12 +179,16 @@ class GraphedShardStep:
             for _ in range(warmup):
                 self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
-        if trainer.ctx.pack_plan is not None:
-            trainer.ctx.pack_plan.prepare(trainer.ctx)        # (its descriptor table is written eagerly, never inside a capture)
+        self.captures = 0
+        self._capture()
+
+    def _capture(self) -> None:
+        self._plan = _PlanGuard(self.trainer.ctx)             # (the descriptor table is written eagerly, never inside a capture)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: calls made by other threads of the process (the collective backend's watchdog) must not abort the capture
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.sq_sum = self._fwd_bwd()
+        self.captures += 1
 
     def _fwd_bwd(self) -> torch.Tensor:
         from . import ops
@@ -185,6 +220,8 @@ class GraphedShardStep:
         if mask is not None:                                  # device-side updates of the buffers the graph reads
             self.maskf.copy_(mask.to(torch.float32).unsqueeze(1))
             self.n_local.copy_(mask.sum().to(torch.float32).reshape(1))
+        if self._plan.stale():                                # an address the graph baked in has moved: capture again
+            self._capture()
         self.graph.replay()                                   # zero_grad + forward + local squared-error sum + backward
         tr.fp.count.copy_(self.n_local)
         return tr.reduce_and_update(self.sq_sum, self.width)  # one all-reduce (world > 1), global-mean scaling, Adam

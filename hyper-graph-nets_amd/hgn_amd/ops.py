@@ -330,6 +330,8 @@ class PackPlan:
                 seen.add(k)
                 self.items.append((w, bool(transposed)))
         self.sig = self.host = self.table = self.bufs = None
+        self.generation = 0               # bumped whenever the table's CONTENT (an address, the precision) changed
+        self.retired = []                 # earlier tables / image buffers: kept alive with the plan
 
     def _signature(self, c: Context) -> tuple:
         return (c.products(), _storage_epoch) + tuple(p for w, _ in self.items for p in (w.w1.data_ptr(), w.w2.data_ptr(), w.w3.data_ptr()))
@@ -342,13 +344,28 @@ class PackPlan:
         if sig != self.sig:
             if torch.cuda.is_current_stream_capturing():
                 return False
-            self.bufs = [_pack_buffer(w, tr) for w, tr in self.items]
+            bufs = [_pack_buffer(w, tr) for w, tr in self.items]
             n = sum((w.w1.shape[1] + LAT - 1) // LAT + 2 for w, _ in self.items)
-            self.host = (_lib.Pack * n)()
+            host = (_lib.Pack * n)()
             at = 0
-            for (w, tr), buf in zip(self.items, self.bufs):
-                at += _pack_descs(w, _pack_form(tr, c), buf, self.host, at)
-            self.table = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(self.items[0][0].w1.device)
+            for (w, tr), buf in zip(self.items, bufs):
+                at += _pack_descs(w, _pack_form(tr, c), buf, host, at)
+            raw = bytes(host)
+            dev = self.items[0][0].w1.device
+            # A captured step (graphs.GraphedTrainStep / GraphedShardStep) has THIS table's device address baked into its pack
+            # launch: the table is one allocation per plan for the plan's lifetime, rewritten in place (a stream-ordered copy) when
+            # the descriptor bytes changed.  A bumped storage epoch with unchanged addresses (another model moved) leaves the bytes
+            # equal: nothing is copied, nothing is freed.  `generation` counts the content changes, so that a captured step can tell
+            # that the addresses IT baked in (weights, packed images) are no longer the ones the table describes.
+            if self.table is not None and self.table.numel() == len(raw) and self.table.device == dev:
+                if self.host is None or bytes(self.host) != raw:
+                    self.table.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8), non_blocking=False)
+                    self.generation += 1
+            else:
+                self.retired.append((self.table, self.bufs))     # (never dropped while a graph may still replay against them)
+                self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+                self.generation += 1
+            self.bufs, self.host = bufs, host
             self.sig = sig
         return True
 

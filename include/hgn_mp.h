@@ -12,8 +12,10 @@
  *    reference hands over int64 ids, i.e. hgn_csr_build / hgn_narrow_gather_i64);
  *  - the library never allocates, frees or synchronises (except hgn_csr_build's range check, which is
  *    topology preprocessing); the caller owns every buffer including workspaces; all work is enqueued on
- *    the hipStream_t passed as `stream` (opaque void*); re-entrant, no global mutable state except the
- *    optional profiler;
+ *    the hipStream_t passed as `stream` (opaque void*); re-entrant; the only process-wide mutable state is the
+ *    optional profiler and ONE word, the meaning of `products == 0` in the argument structs
+ *    (hgn_set_matmul_products; every caller that fills `products` itself -- the Python host always does -- is
+ *    independent of it);
  *  - latent width is fixed at 128 (reference: src/model/flag.py:57 `latent_size=128`), MLPs have two hidden
  *    layers (flag.py:58 `num_layers=2`): Linear-ReLU-Linear-ReLU-Linear[-LayerNorm].
  */

@@ -270,3 +270,92 @@ def multigraph_connect(graph: dict, clusters, neighbors, intra: Normalizer, inte
     merged = EdgeSet('mesh_edges', torch.cat([tag(e.features, k, 4) for k, e in enumerate(parts)]),
                      torch.cat([e.senders for e in parts]), torch.cat([e.receivers for e in parts]))
     return MultiGraph([tag(nf, 0, 2), tag(hnf, 1, 2)], [merged, by['world_edges']])
+
+
+# --------------------------------------------------------------------------------------------------------
+# rollout inference: model/flag.py:194-260, cylinder.py:175-245, plate.py:264-347.
+# Pinned by tests/golden/rollout_*.pt (generator tests/golden/gen_golden_rollout.py runs the reference's own rollout).
+# `net(graph: MultiGraph) -> [N, out]` is the learned model (mgn_oracle.mesh_graph_net with a state_dict bound);
+# `expand(graph_dict, step, is_training) -> MultiGraph` stands for expand_graph (remote message passing over a GIVEN
+# clustering: the labels come from scikit-learn in the reference and are an input here); None -> the mesh graph as is.
+# --------------------------------------------------------------------------------------------------------
+def _as_multigraph(g: dict) -> MultiGraph:
+    return MultiGraph(list(g['node_features']), list(g['edge_sets']))
+
+
+def _first_frame(trajectory: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    return {k: torch.squeeze(v, 0)[0] for k, v in trajectory.items()}               # flag.py:198
+
+
+def _per_step_mse(truth: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
+    return ((truth - pred) ** 2).mean(-1).mean(-1)                                   # flag.py:221-223
+
+
+def flag_rollout(ff: FlagFeatures, net, trajectory, num_steps, expand=None):
+    """flag.py:194-246: the recorded trajectory holds the state BEFORE each step; HANDLE nodes keep their position."""
+    num_steps = trajectory['cells'].shape[0] if num_steps is None else num_steps
+    start = _first_frame(trajectory)
+    mask = (start['node_type'][:, 0] == 0).unsqueeze(1).expand(-1, 3)                # NodeType.NORMAL
+    prev, cur, visited = start['prev|world_pos'].to(ff.dtype), start['world_pos'].to(ff.dtype), []
+    for step in range(num_steps):
+        frame = {**start, 'prev|world_pos': prev, 'world_pos': cur}
+        g = ff.build_graph(frame, False)
+        graph = expand(g, step, False) if expand is not None else _as_multigraph(g)
+        pred = ff.update(frame, net(graph))
+        visited.append(cur)
+        prev, cur = cur, torch.where(mask, pred, cur)
+    predictions = torch.stack(visited)
+    return predictions, _per_step_mse(trajectory['world_pos'][:num_steps].to(ff.dtype), predictions)
+
+
+def cylinder_rollout(cf: CylinderFeatures, net, trajectory, num_steps=None, expand=None):
+    """cylinder.py:175-232: `num_steps` is overwritten by the trajectory length (:178); NORMAL and OUTFLOW nodes move; the
+    recorded trajectory holds the state AFTER each step."""
+    start = _first_frame(trajectory)
+    num_steps = trajectory['cells'].shape[0]
+    t = start['node_type'][:, 0]
+    mask = ((t == 0) | (t == 5)).unsqueeze(1).expand(-1, 2)
+    velocity, pressure = start['velocity'].to(cf.dtype), start['pressure'].to(cf.dtype)
+    vel_traj, pr_traj = [], []
+    for step in range(num_steps):
+        frame = {**start, 'velocity': velocity, 'pressure': pressure}
+        g = cf.build_graph(frame, False)
+        graph = expand(g, step, False) if expand is not None else _as_multigraph(g)
+        pred, pressure = cf.update(frame, net(graph))
+        velocity = torch.where(mask, pred, velocity)
+        vel_traj.append(velocity)
+        pr_traj.append(pressure)
+    predictions = torch.stack(vel_traj)
+    return predictions, torch.stack(pr_traj), _per_step_mse(trajectory['velocity'][:num_steps].to(cf.dtype), predictions)
+
+
+def plate_rollout(pf: PlateFeatures, net, trajectory, num_steps, expand=None):
+    """plate.py:264-334: NORMAL nodes are integrated, every other node is set to the scripted target position of the step."""
+    num_steps = trajectory['cells'].shape[0] if num_steps is None else num_steps
+    start = _first_frame(trajectory)
+    mask = (start['node_type'][:, 0] == 0).unsqueeze(1).expand(-1, 3)
+    cur = start['world_pos'].to(pf.dtype)
+    targets = trajectory['target|world_pos'].to(pf.dtype)
+    visited = []
+    for step in range(num_steps):
+        frame = {**start, 'world_pos': cur, 'target|world_pos': targets[step]}
+        g = pf.build_graph(frame, False)
+        graph = expand(g, step, False) if expand is not None else _as_multigraph(g)
+        pred = pf.update(frame, net(graph))
+        cur = torch.where(mask, pred, targets[step])
+        visited.append(cur)
+    predictions = torch.stack(visited)
+    return predictions, _per_step_mse(trajectory['world_pos'][:num_steps].to(pf.dtype), predictions)
+
+
+def n_step_computation(rollout_fn, trajectory, n_step: int, num_timesteps=None):
+    """flag.py:248-260 (identical in cylinder.py / plate.py): every window of n_step + 1 frames is rolled out from its first
+    frame; `rollout_fn(window, n_step + 1)` returns (..., per-step mse) with the mse LAST."""
+    frames = trajectory['cells'].shape[0] if num_timesteps is None else num_timesteps
+    means, lasts = [], []
+    for start in range(frames - n_step):
+        window = {k: v[start:start + n_step + 1] for k, v in trajectory.items()}
+        mse = rollout_fn(window, n_step + 1)[-1]
+        means.append(mse.mean())
+        lasts.append(mse[-1])
+    return torch.stack(means).mean(), torch.stack(lasts).mean()

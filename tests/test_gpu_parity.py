@@ -1053,6 +1053,53 @@ def test_graphed_shard_step_matches_trainer_step():
     assert int(shard.t_dev) == 4
 
 
+def test_captured_step_survives_another_models_storage_move_and_an_eager_step_in_between():
+    """A captured training step bakes in the device address of its PackPlan's descriptor table and of the packed images.  Moving
+    ANOTHER model (`.to()` bumps the process-wide storage epoch), then running an eager step of the captured trainer (which finds
+    the plan's signature moved and re-prepares it), must not free or replace what the graph replays against: the table is
+    rewritten in place and only when its bytes changed (here: not at all), the graph is not captured again, and the replays
+    continue the eager trajectory.  Re-homing the trainer's OWN parameters does change the descriptors: the next call captures again."""
+    import hgn_amd
+    from hgn_amd import graphs, parallel
+    g0 = synth.grid_graph(seed=4, nx=12, ny=10)
+    shapes = O.param_shapes('none', 'sum', 2, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=3)
+    G0 = hgn_amd.MultiGraph([x.cuda() for x in g0.node_features],
+                            [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in g0.edge_sets])
+    N = 120
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(0)).cuda()
+    mask = torch.ones(N, dtype=torch.bool).cuda()
+    mask[:5] = False
+    ref = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 2, ['mesh_edges'], sd), lr=1e-3, device_step=True)
+    tr = parallel.DataParallelTrainer(H.hip_model('none', 'sum', 2, ['mesh_edges'], sd), lr=1e-3, device_step=True)
+    gs = graphs.GraphedShardStep(tr, G0, target, mask, warmup=2)
+    l_ref = [float(ref.step(G0, target, mask)) for _ in range(5)]
+    l = [float(gs())]
+    plan = tr.ctx.pack_plan
+    assert plan is not None and plan.table is not None
+    table_ptr, gen = plan.table.data_ptr(), plan.generation
+    other = H.hip_model('none', 'sum', 1, ['mesh_edges'], O.init_state_dict_like(
+        O.param_shapes('none', 'sum', 1, ['mesh_edges'], 5, {'mesh_edges': 7}, 0, 3, 128), seed=5))
+    other.to('cuda')                                      # MeshGraphNet._apply: bumps the storage epoch of the whole process
+    other.float()
+    l.append(float(tr.step(G0, target, mask)))            # eager step of the captured trainer: PackPlan.prepare sees a moved signature
+    assert plan.table.data_ptr() == table_ptr and plan.generation == gen and not plan.retired
+    torch.cuda.empty_cache()                              # anything dropped would be unmapped now
+    l += [float(gs()) for _ in range(3)]
+    assert gs.captures == 1
+    for a, b in zip(l_ref, l):
+        assert abs(a - b) <= 5e-5 * abs(a), (l_ref, l)
+    # the trainer's own parameters re-homed: descriptors change in place, the step is captured again and stays correct
+    ref2 = [float(ref.step(G0, target, mask)) for _ in range(2)]
+    tr.model.to('cuda')
+    tr.fp = parallel.FlatParams(tr.model)                 # new flat buffers: every weight address moves
+    assert tr.fp.flat.data_ptr() != 0
+    # (the optimiser state lives in the old trainer; only the forward / backward addresses matter here)
+    before = gs.captures
+    gs()
+    assert gs.captures == before + 1 and plan.table.data_ptr() == table_ptr
+
+
 def test_split_bf16_products_are_fp32_accurate():
     """The default kernels evaluate each fp32 product as six bf16 MFMAs on 3-way bf16 splits (csrc/mlp6.hip): against fp64 they
     must be as accurate as the plain fp32-MFMA kernels (HGN_FP32_MFMA=1) on the same inputs -- forward, data gradients and
