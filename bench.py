@@ -83,7 +83,7 @@ def parse():
                          'independent of host-side launch jitter; per-kernel events are then taken in a short eager pass on the '
                          'same buffers right after the timed region (events cannot be timed inside a replayed graph).')
     ap.add_argument('--graph', action='store_true', help='(default at N=1; kept for compatibility)')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'fp16'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp32-bf16x3', 'fp32-f16x2', 'bf16', 'fp16'],
                     help="'bf16': one bf16 MFMA per product instead of the six fp32-accurate split products (reduced precision: NOT the "
                          "headline metric, outside the 1e-5 parity tolerance; BASELINE.json configs[4] asks for such an edge MLP)")
     ap.add_argument('--side-stream', action='store_true',
@@ -595,7 +595,7 @@ def main():
         res = {'metric': 'processed edges/sec (fwd+bwd) on ' + {'flag': 'flag_simple mesh', 'plate': 'deforming_plate-shape graphs', 'cylinder': 'cylinder_flow-shape graphs'}[args.workload], 'value': value, 'unit': 'edges/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
                'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-               'dtype': 'f32' if args.precision == 'fp32' else args.precision + ' (reduced precision run, not the headline metric)', 'data': 'synthetic',
+               'dtype': 'f32' if args.precision.startswith('fp32') else args.precision + ' (reduced precision run, not the headline metric)', 'data': 'synthetic',
                'config': {'workload': wk['workload'],
                           'graphs_per_gpu': B, 'global_batch': total_graphs, 'edges_per_step': E_rank * world,
                           'params': n_params, 'parallelism': f'dp{world}' + (' (one rank through the N>1 code path)' if args.dp_rehearsal and world == 1 else ''), 'loss': float(loss), 'hip_graph': bool(use_graph),

@@ -61,12 +61,13 @@ def check(text: str) -> None:
 # LDS-DMA of a ring piece -- issued BEFORE them -- must have landed.  Safe exactly when, walking back from the wait, the first N
 # vector-memory instructions are reached without passing a label (another path could join with a different count), are not LDS-DMA,
 # and the kernel has no scratch access (a spill reload is a vector-memory operation nobody counted).
-EDGE_KERNEL = '_ZN3hgn20mlp6_fwd_edge_kernelILi6EEEv13hgn_mlp_fwd_t'
+EDGE_KERNELS = ['_ZN3hgn20mlp6_fwd_edge_kernelILi%dEEEv13hgn_mlp_fwd_t' % n for n in (6, 3)]
+EDGE_KERNEL = EDGE_KERNELS[0]
 _VMEM = ('global_load', 'global_store', 'global_atomic', 'buffer_', 'flat_', 'scratch_')
 
 
-def check_edge_forward(text: str) -> int:
-    at = text.index(EDGE_KERNEL + ':')
+def check_edge_forward(text: str, kernel: str = None) -> int:
+    at = text.index((kernel or EDGE_KERNEL) + ':')
     body = text[at:text.index('.Lfunc_end', at)]
     if 'scratch_' in body:
         raise AssertionError('register spills in mlp6_fwd_edge_kernel: their reloads break the counted waits')
@@ -100,9 +101,10 @@ if __name__ == '__main__':
         if KERNEL + ':' in text:
             check(text)
             print('check_fused_counts: ok (fused backward: 12 phases, counted waits match the emitted instructions)')
-        if EDGE_KERNEL + ':' in text:
-            n = check_edge_forward(text)
-            print(f'check_fused_counts: ok (edge forward: {n} counted waits leave only younger, unconditional operations in flight; no scratch)')
+        for kernel in EDGE_KERNELS:
+            if kernel + ':' in text:
+                n = check_edge_forward(text, kernel)
+                print(f'check_fused_counts: ok (edge forward {kernel[-30:-25]}: {n} counted waits leave only younger, unconditional operations in flight; no scratch)')
     except (AssertionError, ValueError, StopIteration) as e:
         print('check_fused_counts: FAILED:', e, file=sys.stderr)
         sys.exit(1)

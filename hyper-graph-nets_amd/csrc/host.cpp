@@ -13,8 +13,8 @@ thread_local int g_prof_tag = 0;
 // the DEFAULT for calls that leave `products` at 0: one word, written by hgn_set_matmul_products only (relaxed atomic)
 static std::atomic<int> g_products{6};
 int matmul_products(int per_call) { return per_call ? per_call : g_products.load(std::memory_order_relaxed); }
-int bwd_products(int per_call) { return matmul_products(per_call) == 6 ? 6 : 1; }
-bool valid_products(int p) { return p == 0 || p == 1 || p == 2 || p == 6; }
+int bwd_products(int per_call) { const int p = matmul_products(per_call); return (p == 6 || p == 3) ? 6 : 1; }
+bool valid_products(int p) { return p == 0 || p == 1 || p == 2 || p == 3 || p == 6; }
 
 int hgn_fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -68,8 +68,8 @@ extern "C" int hgn_prof_enable(int on) {
   return HGN_OK;
 }
 extern "C" int hgn_set_matmul_products(int n) {
-  if (n != 1 && n != 2 && n != 6)
-    return hgn_fail(HGN_E_INVALID, "hgn_set_matmul_products: 6 (fp32-accurate), 1 (single bf16 product) or 2 (single fp16 product in the forward)");
+  if (n != 1 && n != 2 && n != 3 && n != 6)
+    return hgn_fail(HGN_E_INVALID, "hgn_set_matmul_products: 6 / 3 (fp32-accurate: three bf16 / two scaled fp16 terms), 1 (single bf16 product) or 2 (single fp16 product in the forward)");
   g_products.store(n, std::memory_order_relaxed);
   return HGN_OK;
 }

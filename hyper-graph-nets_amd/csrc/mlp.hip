@@ -306,7 +306,7 @@ extern "C" int hgn_mlp_fwd_post_eligible(const hgn_mlp_fwd_t* a) {
 
 extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   if (!a) return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: null args");
-  if (!valid_products(a->products)) return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: products must be 0 (process default), 6, 1 or 2");
+  if (!valid_products(a->products)) return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: products must be 0 (process default), 6, 3, 1 or 2");
   if (a->M == 0) return HGN_OK;
   if (a->M < 0 || a->n_src < 0 || a->n_src > HGN_MAX_SRC || a->n_add < 0 || a->n_add > HGN_MAX_ADD)
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: bad counts");
@@ -345,7 +345,7 @@ extern "C" int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes) {
 
 extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   if (!a) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: null args");
-  if (!valid_products(a->products)) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: products must be 0 (process default), 6, 1 or 2");
+  if (!valid_products(a->products)) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: products must be 0 (process default), 6, 3, 1 or 2");
   if (a->M == 0) return HGN_OK;
   if (a->M < 0 || a->n_dx < 0 || a->n_dx > HGN_MAX_SRC) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd: bad counts");
   if (a->out_w < 1 || a->out_w > 128 || (a->ln_g && (a->out_w != 128 || !a->xhat || !a->rstd)))

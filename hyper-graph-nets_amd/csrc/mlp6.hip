@@ -25,13 +25,38 @@ namespace hgn {
 // ----------------------------------------------------------------------------------------------------------
 struct PackArgs { hgn_pack_t d[HGN_MAX_PACK]; };
 
+// Scaled two-term fp16 images (hgn_pack_t.transposed & 4, product mode 3): the block's power-of-two scale first -- the exponent sw
+// with max|W| * 2^sw in [2^14, 2^15) (an all-zero block: 15), written to the image's header (mlp6_device.h: PK_SCALE_BYTE) by one
+// workgroup per block; the pack kernel behind it on the stream reads it.  Blocks of the other forms: nothing to do.
+__device__ __forceinline__ void pack_scale_block(const hgn_pack_t& d) {
+  if (!(d.transposed & 4)) return;
+  __shared__ float part[4];
+  const int transposed = d.transposed & 1;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < d.n_out * d.n_in; i += blockDim.x) {
+    const int o = i / d.n_in, k = i - o * d.n_in;
+    m = fmaxf(m, fabsf(d.W[(long)o * d.ldw + k]));
+  }
+  (void)transposed;                                 // (the extents name the same sub-matrix in both forms)
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) m = fmaxf(m, __shfl_xor(m, sh));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    *reinterpret_cast<int*>(reinterpret_cast<char*>(d.out) + PK_SCALE_BYTE) = scale_exp_of(m);
+  }
+}
+__global__ void pack_scale_kernel(const PackArgs a) { pack_scale_block(a.d[blockIdx.x]); }
+__global__ void pack_scale_table_kernel(const hgn_pack_t* __restrict__ table) { pack_scale_block(table[blockIdx.x]); }
+
 __device__ __forceinline__ void pack_block(const hgn_pack_t& d);
 __global__ void pack_bf16x3_kernel(const PackArgs a) { pack_block(a.d[blockIdx.y]); }
 __global__ void pack_bf16x3_table_kernel(const hgn_pack_t* __restrict__ table) { pack_block(table[blockIdx.y]); }
 __device__ __forceinline__ void pack_block(const hgn_pack_t& d) {
   const float* __restrict__ W = d.W;
   const long ldw = d.ldw;
-  const int n_out = d.n_out, n_in = d.n_in, transposed = d.transposed & 1, f16 = d.transposed & 2;
+  const int n_out = d.n_out, n_in = d.n_in, transposed = d.transposed & 1, f16 = d.transposed & 2, f16x2 = d.transposed & 4;
   __bf16* __restrict__ out = reinterpret_cast<__bf16*>(d.out);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one (half, cl, ob, lane, j)
   if (i >= 2 * 2 * 8 * 64 * 8) return;
@@ -47,6 +72,14 @@ __device__ __forceinline__ void pack_block(const hgn_pack_t& d) {
   const float r2 = r1 - (float)mi;
   const __bf16 lo = (__bf16)r2;
   __bf16* base = out + (long)half * HALF_BF16 + ((cl * 8 + ob) * 64 + l) * 8 + j;
+  if (f16x2) {                     // two fp16 terms of W * 2^sw (the third split's region holds the header: not written here)
+    const float ws = __builtin_amdgcn_ldexpf(w, pack_scale_exp(out));
+    const _Float16 hf = (_Float16)ws;
+    const _Float16 lf = (_Float16)(ws - (float)hf);
+    base[0 * 2 * 8 * TILE_BF16] = __builtin_bit_cast(__bf16, hf);
+    base[1 * 2 * 8 * TILE_BF16] = __builtin_bit_cast(__bf16, lf);
+    return;
+  }
   if (f16) {                       // reduced-precision forward (one fp16 product): the leading third holds fp16 bit patterns
     const _Float16 hf = (_Float16)w;
     base[0 * 2 * 8 * TILE_BF16] = __builtin_bit_cast(__bf16, hf);
@@ -121,7 +154,7 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
   const int grp = BIG ? (int)(threadIdx.x >> 8) : 0, ltid = BIG ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
   int ring_slot = 0;
   auto block = [&](Act (&acc_)[NS], Act (&b_)[NS], const __bf16* pk_, auto&& between_, auto&& post_) {
-    if constexpr (LATF) gemm6_lat<NP>(acc_, b_, lds, ring_slot, between_, post_);
+    if constexpr (LATF) gemm6_lat<NP>(acc_, b_, lds, ring_slot, pk_, between_, post_);
     else if constexpr (BIG) gemm6_big<NS, NP, NWV>(acc_, b_, lds, pk_, between_, post_);
     else gemm6<NS, NP>(acc_, b_, lds, pk_, between_, post_);
   };
@@ -615,7 +648,7 @@ __global__ __launch_bounds__(LATF ? 64 * (4 + LAT_LOADERS) : WG, LATF ? 1 : 3) v
       if (blk == 0) t_load(b[0], a.x + R.rc[0] * a.ldx, kq);
       t_zero(acc[0]);
     };
-    if constexpr (LATF) gemm6_lat<NP>(acc, b, lds, ring_slot, between, [](Act (&)[1]) {});
+    if constexpr (LATF) gemm6_lat<NP>(acc, b, lds, ring_slot, a.pk[blk], between, [](Act (&)[1]) {});
     else gemm6<1, NP>(acc, b, lds, a.pk[blk], between);
     if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out + 128 * blk, kq);
   }
@@ -767,6 +800,9 @@ extern "C" int hgn_pack_bf16x3(const hgn_pack_t* blocks, int n, void* stream) {
       return hgn_fail(HGN_E_INVALID, "hgn_pack_bf16x3: bad block (at most 128 x 128, 16-byte aligned output)");
     a.d[i] = d;
   }
+  bool scaled = false;
+  for (int i = 0; i < n; ++i) scaled = scaled || (blocks[i].transposed & 4);
+  if (scaled) hipLaunchKernelGGL(pack_scale_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(2 * 2 * 8 * 64 * 8 / 256, n), dim3(256), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_pack_bf16x3");
 }
@@ -778,6 +814,9 @@ extern "C" int hgn_pack_bf16x3_table(const hgn_pack_t* blocks, const hgn_pack_t*
     if (!d.W || !d.out || d.ldw < 1 || d.n_out < 1 || d.n_out > 128 || d.n_in < 1 || d.n_in > 128 || !aligned16(d.out))
       return hgn_fail(HGN_E_INVALID, "hgn_pack_bf16x3_table: bad block (at most 128 x 128, 16-byte aligned output)");
   }
+  bool scaled = false;
+  for (int i = 0; i < n; ++i) scaled = scaled || (blocks[i].transposed & 4);
+  if (scaled) hipLaunchKernelGGL(pack_scale_table_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, blocks_dev);
   hipLaunchKernelGGL(pack_bf16x3_table_kernel, dim3(2 * 2 * 8 * 64 * 8 / 256, n), dim3(256), 0, (hipStream_t)stream, blocks_dev);
   return hgn_check_launch("hgn_pack_bf16x3_table");
 }
@@ -854,7 +893,7 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
   }
 #endif
-  if (cs_eligible(a)) {
+  if (cs_eligible(a) && np_ != 3) {               // (mode 3 needs whole-row scales: its small launches take the row-per-wave latency form)
     const long wgs = (a->M + 15) / 16;               // inference on at most 16 rows per CU: the column-split latency form
     constexpr int T = 64 * (4 + CS_LOADERS);
     if (np_ == 1) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
@@ -872,17 +911,22 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     constexpr int T = 64 * (4 + LAT_LOADERS);
     if (np_ == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
     else if (np_ == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+    else if (np_ == 3) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 3, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, latency form)");
   }
-  if ((tile128() || (tile128_fwd() && a->M >= big_min_rows())) && np_ == 6 && a->M > TILE_ROWS) {
+  if ((tile128() || (tile128_fwd() && a->M >= big_min_rows())) && (np_ == 6 || np_ == 3) && a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
-    if (edge_block_shape(a)) hipLaunchKernelGGL((mlp6_fwd_edge_kernel<6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    if (np_ == 3) {
+      if (edge_block_shape(a)) hipLaunchKernelGGL((mlp6_fwd_edge_kernel<3>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+      else hipLaunchKernelGGL((mlp6_fwd_kernel<2, 3>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    } else if (edge_block_shape(a)) hipLaunchKernelGGL((mlp6_fwd_edge_kernel<6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<2, 6>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
   } else {
     const long tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
     if (np_ == 1) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 1>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else if (np_ == 2) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 2>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else if (np_ == 3) hipLaunchKernelGGL((mlp6_fwd_kernel<1, 3>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6>), dim3((unsigned)tiles), dim3(WG), lds_pad(), (hipStream_t)stream, *a);
   }
   return hgn_check_launch("hgn_mlp_fwd (split-bf16)");
@@ -978,7 +1022,7 @@ extern "C" int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const voi
 }
 extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const void* const* pk_blocks, int nb, float* out,
                                 int64_t ld_out, float* zero_rows, int64_t ld_zero, int products, void* stream) {
-  if (!valid_products(products)) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: products must be 0 (default), 6, 1 or 2");
+  if (!valid_products(products)) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: products must be 0 (default), 6, 3, 1 or 2");
   const int np_ = matmul_products(products);
   if (M == 0) return HGN_OK;
   if (!x || !pk_blocks || !out || M < 0 || nb < 1 || nb > 4 || (ldx & 3) || (ld_out & 3) || !aligned16(x) || !aligned16(out) ||
@@ -991,7 +1035,7 @@ extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const vo
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(7, (double)M, (hipStream_t)stream);
-  if (M <= 16 * hgn::lat_max_tiles() && hgn::cs_enabled()) {
+  if (M <= 16 * hgn::lat_max_tiles() && hgn::cs_enabled() && np_ != 3) {
     constexpr int T = 64 * (4 + hgn::CS_LOADERS);
     const long wgs = (M + 15) / 16;
     if (np_ == 1) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
@@ -1003,11 +1047,13 @@ extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const vo
     constexpr int T = 64 * (4 + hgn::LAT_LOADERS);
     if (np_ == 1) hipLaunchKernelGGL((linear6_fwd_kernel<1, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
     else if (np_ == 2) hipLaunchKernelGGL((linear6_fwd_kernel<2, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    else if (np_ == 3) hipLaunchKernelGGL((linear6_fwd_kernel<3, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((linear6_fwd_kernel<6, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
     return hgn_check_launch("hgn_linear_fwd6 (latency form)");
   }
   if (np_ == 1) hipLaunchKernelGGL(linear6_fwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else if (np_ == 2) hipLaunchKernelGGL(linear6_fwd_kernel<2>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  else if (np_ == 3) hipLaunchKernelGGL(linear6_fwd_kernel<3>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear6_fwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_fwd6");
 }
@@ -1046,7 +1092,7 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
 
 extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* pk_blocks, int nb, float* dx,
                                int64_t ld_dx, int products, void* stream) {
-  if (!valid_products(products)) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: products must be 0 (default), 6, 1 or 2");
+  if (!valid_products(products)) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: products must be 0 (default), 6, 3, 1 or 2");
   const int nb_ = bwd_products(products);
   if (M == 0) return HGN_OK;
   if (!g || !pk_blocks || !dx || M < 0 || nb < 1 || nb > 4 || (ldg & 3) || (ld_dx & 3) || !aligned16(g) || !aligned16(dx))

@@ -56,17 +56,120 @@ __device__ __forceinline__ void split3(const Act& x, bf16x8 (&s)[3][4]) {
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// operand split of a product mode: 6 -> three bf16 terms; 1 -> the leading bf16 term; 2 -> fp16 (bit patterns in the bf16 slots)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// Product modes (template parameter NP of every kernel here = hgn_mlp_fwd_t.products):
+//   6  three bf16 terms per operand, six v_mfma_f32_16x16x32_bf16 per product (fp32 accurate; no range limits)
+//   3  TWO fp16 terms per operand, three v_mfma_f32_16x16x32_f16 per product.  fp16 carries 11 significant bits, so hi + lo hold
+//      22 bits + the sign of lo = the 24 bits of an fp32 value to within 2^-24 relative, and hi*hi + hi*lo + lo*hi leaves out only
+//      the lo*lo term (2^-22 of the product at most, 2^-24 typically): the accuracy of the six-product bf16 form at half the matrix work, two
+//      thirds of the weight traffic and operand registers.  What fp16 lacks is RANGE (5 exponent bits): every operand is
+//      therefore scaled by a power of two first -- the weights per packed block at pack time (hgn_pack_t.transposed & 4: header
+//      in the image), the rows of the other operand per row at split time (the largest |x| of the row goes to [2^14, 2^15)) --
+//      and the accumulators are scaled back afterwards.  Scaling by a power of two is exact and commutes with every rounding
+//      of the fp32 accumulation, so  unscale(scale(acc) + products of scaled operands)  has the bits of  acc + products.
+//   1 / 2  one bf16 / one fp16 product (reduced precision, opt-in)
+template <int NP> struct Prod {
+  static constexpr int NSPLIT = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
+  static constexpr bool SCALED = NP == 3;
+  static constexpr bool F16 = NP == 2 || NP == 3;
+};
+constexpr int PK_SCALE_BYTE = 2 * 16 * 1024;       // header of a scaled pack {int exponent sw: tiles hold W * 2^sw}: first word of the (unused) third split
+constexpr int SCALE_TOP = 15;                      // scaled operands: largest magnitude in [2^14, 2^15) (fp16 overflows at 2^16)
+constexpr int SCALE_CLAMP = 62;                    // |exponent| of a row / block scale: the combined factors stay normal fp32 numbers
+
+__device__ __forceinline__ int pack_scale_exp(const __bf16* __restrict__ pk) {      // uniform: one scalar load
+  return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(pk) + PK_SCALE_BYTE);
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_amdgcn_ldexpf(1.0f, e); }
+// the exponent s with max|x| * 2^s in [2^14, 2^15) (0 / inf / nan: frexp gives exponent 0), clamped
+__device__ __forceinline__ int scale_exp_of(float maxabs) {
+  const int s = SCALE_TOP - __builtin_amdgcn_frexp_expf(maxabs);
+  return s < -SCALE_CLAMP ? -SCALE_CLAMP : (s > SCALE_CLAMP ? SCALE_CLAMP : s);
+}
+// largest magnitude of the row a lane holds a quarter of (lanes n, n + 16, n + 32, n + 48 hold row n)
+__device__ __forceinline__ float row_max_abs(const Act& x) {
+  float m = 0.f;
+  HGN_FOR_B(fb) {
+    m = fmaxf(m, fmaxf(fabsf(x.v[fb][0]), fabsf(x.v[fb][1])));
+    m = fmaxf(m, fmaxf(fabsf(x.v[fb][2]), fabsf(x.v[fb][3])));
+  }
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  return m;
+}
+// two values -> their fp16 hi and lo terms (packed pairs): hi = rne(x), lo = rne(x - hi); the subtraction is exact in fp32
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 x = {x0, x1};
+  const f16x2 h = __builtin_convertvector(x, f16x2);
+  const f2 r = x - __builtin_convertvector(h, f2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ void split2_eight(const float (&v)[8], float sc, bf16x8 (&o)[3]) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  u4 w[2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned a, b;
+    split2_pair(v[2 * p] * sc, v[2 * p + 1] * sc, a, b);
+    w[0][p] = a; w[1][p] = b;
+  }
+  o[0] = __builtin_bit_cast(bf16x8, w[0]); o[1] = __builtin_bit_cast(bf16x8, w[1]);
+}
+// operand split of a product mode: 6 -> three bf16 terms; 3 -> two fp16 terms of the row scaled by 2^s (returns s); 1 -> the leading
+// bf16 term; 2 -> fp16 (bit patterns in the bf16 slots)
 template <int NP>
-__device__ __forceinline__ void split_np(const Act& x, bf16x8 (&s)[3][4]) {
+__device__ __forceinline__ int split_np(const Act& x, bf16x8 (&s)[3][4]) {
   if constexpr (NP == 2) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[0][c][j] = __builtin_bit_cast(__bf16, (_Float16)x.v[2 * c + (j >> 2)][j & 3]);
+    return 0;
+  } else if constexpr (NP == 3) {
+    const int e = scale_exp_of(row_max_abs(x));
+    const float sc = pow2f(e);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 &q0 = x.v[2 * c], &q1 = x.v[2 * c + 1];
+      const float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+      bf16x8 t[3];
+      split2_eight(v, sc, t);
+      s[0][c] = t[0]; s[1][c] = t[1];
+    }
+    return e;
   } else {
     split3(x, s);
+    return 0;
   }
+}
+// scaled modes: acc <- acc * 2^e (exact)
+__device__ __forceinline__ void scale_act(Act& a, int e) {
+  const float f = pow2f(e);
+  HGN_FOR_B(fb) a.v[fb] *= f;
+}
+// one product of a mode against the fragments a[0] (hi) a[1] (mid / lo) a[2] (lo) of one operand tile, smallest terms first
+template <int NP>
+__device__ __forceinline__ f32x4 mfma_np(const bf16x8 (&a)[3], const bf16x8& x0, const bf16x8& x1, const bf16x8& x2, f32x4 t) {
+  if constexpr (NP == 6) {
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], x0, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], x2, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], x1, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], x0, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], x1, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], x0, t, 0, 0, 0);
+  } else if constexpr (NP == 3) {
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, x0), t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, x1), t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, x0), t, 0, 0, 0);
+  } else if constexpr (NP == 2) {
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, x0), t, 0, 0, 0);
+  } else {
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], x0, t, 0, 0, 0);
+  }
+  return t;
 }
 // one reduced-precision product: bf16 (NP = 1) or fp16 (NP = 2) operands, fp32 accumulation
 template <int NP>
@@ -75,6 +178,9 @@ __device__ __forceinline__ f32x4 mfma_one(const bf16x8& a, const bf16x8& b, cons
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 // NP = 1 (single bf16 product) / NP = 2 (single fp16 product: the leading third of the pack holds fp16 bit patterns, hgn_pack_bf16x3
@@ -85,7 +191,7 @@ __device__ __forceinline__ void stage_half6(__bf16* __restrict__ lds, const __bf
   asm volatile("" : "+v"(lane));
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar tile offsets, LDS bases straight into M0
 #pragma unroll
-  for (unsigned i = wave; i < (NP != 6 ? HALF_TILES / 3 : HALF_TILES); i += WG / 64)          // one operand tile (1 KiB) per wave instruction
+  for (unsigned i = wave; i < (unsigned)(HALF_TILES / 3 * Prod<NP>::NSPLIT); i += WG / 64)          // one operand tile (1 KiB) per wave instruction
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * TILE_BF16 + lane * 8),
                                      (__attribute__((address_space(3))) void*)(lds + i * TILE_BF16), 16, 0, 0);
 }
@@ -96,7 +202,7 @@ __device__ __forceinline__ void stage_block6(__bf16* __restrict__ lds, const __b
   unsigned lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr unsigned PER_HALF = NP != 6 ? HALF_TILES / 3 : HALF_TILES;
+  constexpr unsigned PER_HALF = HALF_TILES / 3 * Prod<NP>::NSPLIT;
 #pragma unroll
   for (unsigned h = 0; h < 2; ++h)
 #pragma unroll
@@ -115,9 +221,15 @@ __device__ __forceinline__ void mfma_half6(Act (&acc)[NS], const bf16x8 (&xs)[NS
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
       const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(lds + ((0 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
-      if (NP != 6) {
+      if constexpr (NP == 1 || NP == 2) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) acc[u].v[ob] = mfma_one<NP>(a_hi, xs[u][0][c], acc[u].v[ob]);
+        continue;
+      }
+      if constexpr (NP == 3) {
+        const bf16x8 a3[3] = {a_hi, *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8), a_hi};
+#pragma unroll
+        for (int u = 0; u < NS; ++u) acc[u].v[ob] = mfma_np<3>(a3, xs[u][0][c], xs[u][1][c], xs[u][1][c], acc[u].v[ob]);
         continue;
       }
       const bf16x8 a_mi = *reinterpret_cast<const bf16x8*>(lds + ((1 * 2 + cl) * 8 + ob) * TILE_BF16 + lane * 8);
@@ -143,7 +255,7 @@ template <int HALF, int NP>
 __device__ __forceinline__ void mfma_half6_pipe(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
   const int lane = threadIdx.x & 63;
   const __bf16* lp = lds + lane * 8;
-  constexpr int NSP = NP != 6 ? 1 : 3;
+  constexpr int NSP = Prod<NP>::NSPLIT;
   bf16x8 fr[2][3];
 #pragma unroll
   for (int s = 0; s < NSP; ++s) fr[0][s] = *reinterpret_cast<const bf16x8*>(lp + ((s * 2 + 0) * 8 + 0) * TILE_BF16);
@@ -158,8 +270,8 @@ __device__ __forceinline__ void mfma_half6_pipe(Act& acc, const bf16x8 (&xs)[3][
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8 (&a)[3] = fr[i & 1];              // a[0] hi, a[1] mid, a[2] lo
     f32x4 t = acc.v[ob];
-    if (NP != 6) {
-      t = mfma_one<NP>(a[0], xs[0][c], t);
+    if constexpr (NP != 6) {
+      t = mfma_np<NP>(a, xs[0][c], xs[1][c], xs[2][c], t);
     } else {
       t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[0][c], t, 0, 0, 0);      // smallest terms first
       t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[2][c], t, 0, 0, 0);
@@ -180,7 +292,7 @@ template <int HALF, int NP>
 __device__ __forceinline__ void mfma_half6_pipe2(Act& acc, const bf16x8 (&xs)[3][4], const __bf16* __restrict__ lds) {
   const int lane = threadIdx.x & 63;
   const __bf16* lp = lds + lane * 8;
-  constexpr int NSP = NP != 6 ? 1 : 3;
+  constexpr int NSP = Prod<NP>::NSPLIT;
   bf16x8 fr[2][2][3];
   auto load_pair = [&](int g, bf16x8 (&f)[2][3]) {
     const int cl = g >> 2, ob0 = 2 * (g & 3);
@@ -200,9 +312,16 @@ __device__ __forceinline__ void mfma_half6_pipe2(Act& acc, const bf16x8 (&xs)[3]
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8 (&a)[2][3] = fr[g & 1];           // a[k][0] hi, [1] mid, [2] lo of output block ob0 + k
     f32x4 t0 = acc.v[ob0], t1 = acc.v[ob0 + 1];
-    if (NP != 6) {
+    if constexpr (NP == 1 || NP == 2) {
       t0 = mfma_one<NP>(a[0][0], xs[0][c], t0);
       t1 = mfma_one<NP>(a[1][0], xs[0][c], t1);
+    } else if constexpr (NP == 3) {                   // smallest terms first, the two accumulation chains interleaved
+      t0 = mfma_f16(a[0][1], xs[0][c], t0);
+      t1 = mfma_f16(a[1][1], xs[0][c], t1);
+      t0 = mfma_f16(a[0][0], xs[1][c], t0);
+      t1 = mfma_f16(a[1][0], xs[1][c], t1);
+      t0 = mfma_f16(a[0][0], xs[0][c], t0);
+      t1 = mfma_f16(a[1][0], xs[0][c], t1);
     } else {
       t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][2], xs[0][c], t0, 0, 0, 0);      // smallest terms first
       t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][2], xs[0][c], t1, 0, 0, 0);
@@ -238,6 +357,9 @@ template <int NS, int NP, class F, class G>
 __device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
                                       F&& between, G&& post_split) {
   bf16x8 xs[NS][3][4];
+  int T[NS];                                      // scaled modes: acc[u] is carried at 2^T[u] through the block (row scale + block scale)
+  int sw = 0;
+  if constexpr (Prod<NP>::SCALED) sw = pack_scale_exp(pk);
   HGN_STAMP();                                    // 0: block entered
   wg_barrier_lds();
   HGN_STAMP();                                    // 1: stage free
@@ -247,7 +369,10 @@ __device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __re
   __syncthreads();
   HGN_STAMP();                                    // 3: landed
 #pragma unroll
-  for (int u = 0; u < NS; ++u) split_np<NP>(b[u], xs[u]);
+  for (int u = 0; u < NS; ++u) {
+    T[u] = split_np<NP>(b[u], xs[u]) + sw;
+    if constexpr (Prod<NP>::SCALED) scale_act(acc[u], T[u]);
+  }
   post_split(b);
   HGN_STAMP();                                    // 4: split
   if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(2);
@@ -263,6 +388,10 @@ __device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __re
   if (!(HGN_ABL & 2)) mfma_half6_sel<1, NS, NP>(acc, xs, lds);
   if (HGN_ABL & 32) __builtin_amdgcn_s_setprio(0);
   HGN_STAMP();                                    // 8: products of half 1 issued
+  if constexpr (Prod<NP>::SCALED) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) scale_act(acc[u], -T[u]);
+  }
 }
 template <int NS, int NP, class F>
 __device__ __forceinline__ void gemm6(Act (&acc)[NS], const Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
@@ -305,9 +434,15 @@ template <int NP>
 __device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: source of tile (0, ww)*/, unsigned voff /*dma_lane_off*/,
                                            unsigned lds_dst /*wave-uniform: LDS byte address of tile (0, ww) in the slot*/) {
   const unsigned m0v = lds_dst + 0x800u;
-  if (NP != 6) {
+  if constexpr (Prod<NP>::NSPLIT == 1) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
                  : : "v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
+  } else if constexpr (Prod<NP>::NSPLIT == 2) {
+    asm volatile("" : "+s"(sbase));
+    const void* s1 = static_cast<const unsigned char*>(sbase) + 0x4000;
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:-2048\n\tglobal_load_lds_dwordx4 %0, %2 offset:2048"
+                 : : "v"(voff), "s"(sbase), "s"(s1), "s"(m0v) : "memory", "scc", "m0");
   } else {
     asm volatile("" : "+s"(sbase));                  // the two bases below are made here (four scalar adds), not kept in registers per piece
     const void* s1 = static_cast<const unsigned char*>(sbase) + 0x4000;
@@ -330,7 +465,7 @@ __device__ __forceinline__ void dma_piece6(const __bf16* __restrict__ blk, int c
 template <int C, int NS, int NP>
 __device__ __forceinline__ void sweep_piece6(Act (&acc)[NS], const bf16x8 (&xs)[NS][3][4], const unsigned char* __restrict__ lp /*slot + 16 lane*/) {
   if (HGN_ABL & 2) return;
-  constexpr int NSP = NP != 6 ? 1 : 3;
+  constexpr int NSP = Prod<NP>::NSPLIT;
   bf16x8 fr[2][3];
 #pragma unroll
   for (int s = 0; s < NSP; ++s) fr[0][s] = *reinterpret_cast<const bf16x8*>(lp + (s * 8) * 1024);
@@ -357,12 +492,21 @@ __device__ __forceinline__ void sweep_piece6(Act (&acc)[NS], const bf16x8 (&xs)[
       t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[0][0][C], t0, 0, 0, 0);
       t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[1][0][C], t1, 0, 0, 0);
       acc[0].v[ob] = t0; acc[1].v[ob] = t1;
+    } else if constexpr (NS == 2 && NP == 3) {      // two independent accumulation chains, interleaved; smallest terms first
+      f32x4 t0 = acc[0].v[ob], t1 = acc[1].v[ob];
+      t0 = mfma_f16(a[1], xs[0][0][C], t0);
+      t1 = mfma_f16(a[1], xs[1][0][C], t1);
+      t0 = mfma_f16(a[0], xs[0][1][C], t0);
+      t1 = mfma_f16(a[0], xs[1][1][C], t1);
+      t0 = mfma_f16(a[0], xs[0][0][C], t0);
+      t1 = mfma_f16(a[0], xs[1][0][C], t1);
+      acc[0].v[ob] = t0; acc[1].v[ob] = t1;
     } else {
 #pragma unroll
       for (int u = 0; u < NS; ++u) {
         f32x4 t = acc[u].v[ob];
         if constexpr (NP != 6) {
-          t = mfma_one<NP>(a[0], xs[u][0][C], t);
+          t = mfma_np<NP>(a, xs[u][0][C], xs[u][1][C], xs[u][2][C], t);
         } else {
           t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], xs[u][0][C], t, 0, 0, 0);
           t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], xs[u][2][C], t, 0, 0, 0);
@@ -403,6 +547,9 @@ template <int NS, int NP, bool PREWAITED, int KEEP1, int KEEP2, int KEEP3, class
 __device__ __forceinline__ void gemm6q(Act (&acc)[NS], Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
                                        const __bf16* __restrict__ pk_next, bool first, F&& between, G&& at_piece) {
   bf16x8 xs[NS][3][4];
+  int T[NS];
+  int sw = 0;
+  if constexpr (Prod<NP>::SCALED) sw = pack_scale_exp(pk);
   const unsigned lane = threadIdx.x & 63;
   const unsigned ww = (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(lds);
@@ -416,7 +563,10 @@ __device__ __forceinline__ void gemm6q(Act (&acc)[NS], Act (&b)[NS], __bf16* __r
   __builtin_amdgcn_s_barrier();                     // ---- piece 0 has landed for every wave; slot 1 is free
   dma_piece6<NP>(pk, 1, lds_base, 1, ww, dma_lane_off(lane));
 #pragma unroll
-  for (int u = 0; u < NS; ++u) split_np<NP>(b[u], xs[u]);
+  for (int u = 0; u < NS; ++u) {
+    T[u] = split_np<NP>(b[u], xs[u]) + sw;
+    if constexpr (Prod<NP>::SCALED) scale_act(acc[u], T[u]);
+  }
   at_piece(0, b);
   sweep_piece6<0, NS, NP>(acc, xs, ring + opaque_u(lane * 16u));
   wait_vm_keep<KEEP1>();
@@ -434,6 +584,10 @@ __device__ __forceinline__ void gemm6q(Act (&acc)[NS], Act (&b)[NS], __bf16* __r
   if (pk_next) dma_piece6<NP>(pk_next, 0, lds_base, 0, ww, dma_lane_off(lane));
   at_piece(3, b);
   sweep_piece6<3, NS, NP>(acc, xs, ring + opaque_u(lane * 16u + PIECE_BYTES6));
+  if constexpr (Prod<NP>::SCALED) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) scale_act(acc[u], -T[u]);
+  }
 }
 
 // ---- latency form (small launches: at most a tile or two per CU, csrc/mlp6.hip: mlp6_fwd_kernel<1, NP, 5>) -----------------------
@@ -443,7 +597,7 @@ __device__ __forceinline__ void gemm6q(Act (&acc)[NS], Act (&b)[NS], __bf16* __r
 // retires each with a counted wait of its own (its vector-memory queue holds the DMAs and nothing else); the four compute waves
 // meet it at ONE barrier per half and never wait for a transfer.  Slot of half h = h mod 3; at barrier h every compute wave has
 // finished the products of half h - 1, whose slot the loader then refills with half h + 2.
-template <int NP> struct LatRing { static constexpr int PER = NP != 6 ? HALF_TILES / 3 : HALF_TILES; };   // DMA instructions per half
+template <int NP> struct LatRing { static constexpr int PER = HALF_TILES / 3 * Prod<NP>::NSPLIT; };   // DMA instructions per half
 
 // loader wave l of NL issues the operand tiles l, l + NL, ... of a half
 template <int NP, int NL>
@@ -488,14 +642,18 @@ __device__ __forceinline__ void lat_loader(__bf16* __restrict__ lds, unsigned l,
 // A compute wave's block: the same products in the same order as gemm6 (identical bits); `slot` is the ring position of the
 // block's first half and is advanced by two.
 template <int NP, class F, class G>
-__device__ __forceinline__ void gemm6_lat(Act (&acc)[1], Act (&b)[1], __bf16* __restrict__ lds, int& slot, F&& between, G&& post_split) {
+__device__ __forceinline__ void gemm6_lat(Act (&acc)[1], Act (&b)[1], __bf16* __restrict__ lds, int& slot, const __bf16* __restrict__ pk,
+                                          F&& between, G&& post_split) {
   bf16x8 xs[1][3][4];
+  int sw = 0;
+  if constexpr (Prod<NP>::SCALED) sw = pack_scale_exp(pk);
   HGN_STAMP();                                      // 0: block entered
   between();
   HGN_STAMP();                                      // 1: caller's loads issued
   wg_barrier_lds();                                 // half 2 b has landed
   HGN_STAMP();                                      // 2: past the barrier of half 0
-  split_np<NP>(b[0], xs[0]);
+  const int T = split_np<NP>(b[0], xs[0]) + sw;
+  if constexpr (Prod<NP>::SCALED) scale_act(acc[0], T);
   post_split(b);
   HGN_STAMP();                                      // 3: split (the caller's loads have arrived)
   if (!(HGN_ABL & 2)) mfma_half6_sel<0, 1, NP>(acc, xs, lds + slot * HALF_BF16);
@@ -506,6 +664,7 @@ __device__ __forceinline__ void gemm6_lat(Act (&acc)[1], Act (&b)[1], __bf16* __
   if (!(HGN_ABL & 2)) mfma_half6_sel<1, 1, NP>(acc, xs, lds + slot * HALF_BF16);
   slot = slot == 2 ? 0 : slot + 1;
   HGN_STAMP();                                      // 6: products of half 1 issued
+  if constexpr (Prod<NP>::SCALED) scale_act(acc[0], -T);
 }
 
 // The same block for a BIG workgroup (NWV waves, one per CU) that can afford a 96 KB stage: both halves are fetched at once, so
@@ -514,6 +673,7 @@ template <int NS, int NP, int NWV, class F, class G>
 __device__ __forceinline__ void gemm6_big(Act (&acc)[NS], Act (&b)[NS], __bf16* __restrict__ lds, const __bf16* __restrict__ pk,
                                           F&& between, G&& post_split) {
   bf16x8 xs[NS][3][4];
+  static_assert(!Prod<NP>::SCALED, "big workgroups (laboratory build): unscaled product modes only");
   wg_barrier_lds();
   if (!(HGN_ABL & 1)) stage_block6<NP, NWV>(lds, pk);
   between();

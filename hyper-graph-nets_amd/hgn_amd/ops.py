@@ -18,7 +18,7 @@ LAT = 128
 _GATE_LOG = None              # tests only: when a list, every training forward appends (first-layer weight ptr, ReLU sign words, row index)
 _ARG_LOG = None               # tests only: when a list, every training edge block with max / min aggregates appends (first-layer weight ptr, argmax, argmin, sorted position -> edge index)
 
-_PRODUCTS = {'fp32': 6, 'bf16': 1, 'fp16': 2}
+_PRODUCTS = {'fp32': 6, 'fp32-bf16x3': 6, 'fp32-f16x2': 3, 'bf16': 1, 'fp16': 2}
 _ENV = __import__('os').environ
 # Process-wide DEFAULTS, resolved once here (the library itself reads no environment variable): what a Context that does not say
 # otherwise follows.  HGN_FP32_MFMA: the plain fp32-MFMA kernels everywhere; HGN_NO_FUSED_BWD: hgn_mlp_bwd + hgn_mlp_wgrad instead of
@@ -42,7 +42,7 @@ class Context:
 
     def __init__(self, precision=None, fused_edge_bwd=None, fp32_mfma=None, general_fwd=None):
         if precision is not None and precision not in _PRODUCTS:
-            raise ValueError("matmul precision must be 'fp32', 'bf16' or 'fp16'")
+            raise ValueError("matmul precision must be one of " + ', '.join(repr(k) for k in _PRODUCTS))
         self.precision, self.fused_edge_bwd, self.fp32_mfma, self.general_fwd = precision, fused_edge_bwd, fp32_mfma, general_fwd
         self.wgrad_stream = None          # weight-gradient launches go to this side stream (parallel.DataParallelTrainer)
         self.wq = {}                      # (M, device) -> [tasks, tensors kept alive, set of queued dW / db target addresses]
@@ -82,7 +82,7 @@ class Context:
     def set_matmul_precision(self, mode) -> None:
         """This context's own precision ('fp32' / 'bf16' / 'fp16'; None: follow the process default again)."""
         if mode is not None and mode not in _PRODUCTS:
-            raise ValueError("matmul precision must be 'fp32', 'bf16' or 'fp16'")
+            raise ValueError("matmul precision must be one of " + ', '.join(repr(k) for k in _PRODUCTS))
         self.precision = mode
         self.invalidate_packs()
 
@@ -153,7 +153,7 @@ def set_matmul_precision(mode: str) -> None:
     their next use."""
     global _defaults_epoch
     if mode not in _PRODUCTS:
-        raise ValueError("matmul precision must be 'fp32', 'bf16' or 'fp16'")
+        raise ValueError("matmul precision must be one of " + ', '.join(repr(k) for k in _PRODUCTS))
     _lib.check(_lib.lib().hgn_set_matmul_products(_PRODUCTS[mode]), 'hgn_set_matmul_products')
     _DEFAULTS['precision'] = mode
     _defaults_epoch += 1
@@ -252,7 +252,8 @@ def storage_signature(pairs) -> tuple:
 
 def _pack_form(transposed: bool, c: Context) -> int:
     # forward-form images of the fp16 mode carry fp16 bit patterns in their leading third (hgn_pack_t.transposed | 2)
-    return 1 if transposed else (2 if c.products() == 2 else 0)
+    # ... and those of the scaled two-term fp16 mode two fp16 terms + the block's scale exponent (hgn_pack_t.transposed | 4)
+    return 1 if transposed else {2: 2, 3: 4}.get(c.products(), 0)
 
 
 def _pack_key(w: MLPWeights, t: int, c: Context) -> tuple:

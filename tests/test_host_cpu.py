@@ -66,11 +66,12 @@ def test_abi_argument_validation_without_gpu():
     assert lib.hgn_node_features(None, None, 3, 3, None, 1, None, 0, 40, 1, -1, 5, None, 43, None) == -1
     assert lib.hgn_normalize(None, 5, 0, None, None, None, 1e-8, 0, None, None) == -1
     assert lib.hgn_lincomb3(None, 1.0, None, 1.0, None, 0.0, 5, None, None) == -1
-    # precision switch: 6 (default), 1 (bf16), 2 (fp16 forward / bf16 backward); anything else is refused and changes nothing
+    # precision switch: 6 (default) / 3 (fp32-accurate: three bf16 / two scaled fp16 terms), 1 (bf16), 2 (fp16 forward / bf16 backward);
+    # anything else is refused and changes nothing
     assert lib.hgn_get_matmul_products() == 6
-    for n in (1, 2, 6):
+    for n in (1, 2, 3, 6):
         assert lib.hgn_set_matmul_products(n) == 0 and lib.hgn_get_matmul_products() == n
-    assert lib.hgn_set_matmul_products(3) == -1 and lib.hgn_get_matmul_products() == 6
+    assert lib.hgn_set_matmul_products(4) == -1 and lib.hgn_get_matmul_products() == 6
     # the shipped library carries no laboratory variants (tools/lab/): their switches are not exported
     raw = C.CDLL(_lib.LIB_PATH)
     assert not any(hasattr(raw, n) for n in ('hgn_set_ws_fwd', 'hgn_set_big_tiles', 'hgn_mlp_fwd_ws_eligible'))
