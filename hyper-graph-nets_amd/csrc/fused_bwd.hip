@@ -638,6 +638,7 @@ extern "C" int hgn_edge_bwd_fused_workspace_bytes(int64_t M, size_t* bytes) {
 
 extern "C" int hgn_edge_bwd_fused_eligible(const hgn_mlp_bwd_t* a) {
   if (!a || !hgn_mlp_bwd6_eligible(a)) return 0;          // (includes the HGN_F_FP32_MFMA flag of the call)
+  if (bwd_products(a->products) == 3) return 0;             // (mode 3: the two-launch path until the fused kernel has its form)
   if (a->n_dx != 1 || !a->dx[0].residual || a->dx[0].K != 128 || a->seg_dz1 || !a->dz1) return 0;
   if (a->agg_dout && (a->n_agg_ops != 1 || a->agg_ops[0] != HGN_OP_SUM)) return 0;      // several aggregates (pna): the two-launch path
   const int64_t ldmax = a->ld_dout > a->dx[0].ld ? a->ld_dout : a->dx[0].ld;

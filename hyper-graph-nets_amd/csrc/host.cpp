@@ -13,7 +13,7 @@ thread_local int g_prof_tag = 0;
 // the DEFAULT for calls that leave `products` at 0: one word, written by hgn_set_matmul_products only (relaxed atomic)
 static std::atomic<int> g_products{6};
 int matmul_products(int per_call) { return per_call ? per_call : g_products.load(std::memory_order_relaxed); }
-int bwd_products(int per_call) { const int p = matmul_products(per_call); return (p == 6 || p == 3) ? 6 : 1; }
+int bwd_products(int per_call) { const int p = matmul_products(per_call); return (p == 6 || p == 3) ? p : 1; }
 bool valid_products(int p) { return p == 0 || p == 1 || p == 2 || p == 3 || p == 6; }
 
 int hgn_fail(int code, const char* msg) {

@@ -1082,6 +1082,8 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
     if (a->agg_dout && a->n_agg_ops > 1)
       for (int i = 0; i < a->n_dx; ++i) park = park || a->dx[i].residual;
     if (nb_ == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else if (nb_ == 3 && park) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 3, true>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
+    else if (nb_ == 3) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 3, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else if (park) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, true>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, false>), dim3((unsigned)tiles), dim3(WG), lds_pad(), (hipStream_t)stream, *a);
     *n_slabs = tiles;
@@ -1105,6 +1107,7 @@ extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const voi
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(8, (double)M, (hipStream_t)stream);
   if (nb_ == 1) hipLaunchKernelGGL(linear6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
+  else if (nb_ == 3) hipLaunchKernelGGL(linear6_bwd_kernel<3>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear6_bwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   return hgn_check_launch("hgn_linear_bwd6");
 }

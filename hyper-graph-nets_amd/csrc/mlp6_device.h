@@ -75,17 +75,10 @@ template <int NP> struct Prod {
   static constexpr bool F16 = NP == 2 || NP == 3;
 };
 constexpr int PK_SCALE_BYTE = 2 * 16 * 1024;       // header of a scaled pack {int exponent sw: tiles hold W * 2^sw}: first word of the (unused) third split
-constexpr int SCALE_TOP = 15;                      // scaled operands: largest magnitude in [2^14, 2^15) (fp16 overflows at 2^16)
-constexpr int SCALE_CLAMP = 62;                    // |exponent| of a row / block scale: the combined factors stay normal fp32 numbers
-
+using hgn_split::pow2f;
+using hgn_split::scale_exp_of;
 __device__ __forceinline__ int pack_scale_exp(const __bf16* __restrict__ pk) {      // uniform: one scalar load
   return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(pk) + PK_SCALE_BYTE);
-}
-__device__ __forceinline__ float pow2f(int e) { return __builtin_amdgcn_ldexpf(1.0f, e); }
-// the exponent s with max|x| * 2^s in [2^14, 2^15) (0 / inf / nan: frexp gives exponent 0), clamped
-__device__ __forceinline__ int scale_exp_of(float maxabs) {
-  const int s = SCALE_TOP - __builtin_amdgcn_frexp_expf(maxabs);
-  return s < -SCALE_CLAMP ? -SCALE_CLAMP : (s > SCALE_CLAMP ? SCALE_CLAMP : s);
 }
 // largest magnitude of the row a lane holds a quarter of (lanes n, n + 16, n + 32, n + 48 hold row n)
 __device__ __forceinline__ float row_max_abs(const Act& x) {
@@ -97,26 +90,6 @@ __device__ __forceinline__ float row_max_abs(const Act& x) {
   m = fmaxf(m, __shfl_xor(m, 16));
   m = fmaxf(m, __shfl_xor(m, 32));
   return m;
-}
-// two values -> their fp16 hi and lo terms (packed pairs): hi = rne(x), lo = rne(x - hi); the subtraction is exact in fp32
-__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  const f2 x = {x0, x1};
-  const f16x2 h = __builtin_convertvector(x, f16x2);
-  const f2 r = x - __builtin_convertvector(h, f2);
-  hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-}
-__device__ __forceinline__ void split2_eight(const float (&v)[8], float sc, bf16x8 (&o)[3]) {
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  u4 w[2];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    unsigned a, b;
-    split2_pair(v[2 * p] * sc, v[2 * p + 1] * sc, a, b);
-    w[0][p] = a; w[1][p] = b;
-  }
-  o[0] = __builtin_bit_cast(bf16x8, w[0]); o[1] = __builtin_bit_cast(bf16x8, w[1]);
 }
 // operand split of a product mode: 6 -> three bf16 terms; 3 -> two fp16 terms of the row scaled by 2^s (returns s); 1 -> the leading
 // bf16 term; 2 -> fp16 (bit patterns in the bf16 slots)
@@ -136,7 +109,7 @@ __device__ __forceinline__ int split_np(const Act& x, bf16x8 (&s)[3][4]) {
       const f32x4 &q0 = x.v[2 * c], &q1 = x.v[2 * c + 1];
       const float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
       bf16x8 t[3];
-      split2_eight(v, sc, t);
+      hgn_split::eight16(v, sc, t);
       s[0][c] = t[0]; s[1][c] = t[1];
     }
     return e;

@@ -35,4 +35,36 @@ __device__ __forceinline__ void eight(const float (&v)[8], b8 (&s)[3]) {
   s[0] = __builtin_bit_cast(b8, w[0]); s[1] = __builtin_bit_cast(b8, w[1]); s[2] = __builtin_bit_cast(b8, w[2]);
 }
 
+// ---- two-term fp16 split (product mode 3): hi = rne(x), lo = rne(x - hi), on operands scaled by a power of two so that their largest
+// magnitude lies in [2^14, 2^15) -- fp16 keeps 11 significant bits per term (hi + lo: the fp32 value to 2^-24 relative) but only 5
+// exponent bits.  Three products hi*hi + hi*lo + lo*hi then carry what six products of three bf16 terms carry.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+constexpr int SCALE_TOP = 15;       // scaled operands: largest magnitude in [2^14, 2^15) (fp16 overflows at 2^16)
+constexpr int SCALE_CLAMP = 60;     // |exponent| of a scale: sums of two of them stay normal fp32 powers of two
+
+__device__ __forceinline__ float pow2f(int e) { return __builtin_amdgcn_ldexpf(1.0f, e); }
+// the exponent s with maxabs * 2^s in [2^14, 2^15) (0 / inf / nan: frexp gives exponent 0), clamped
+__device__ __forceinline__ int scale_exp_of(float maxabs) {
+  const int s = SCALE_TOP - __builtin_amdgcn_frexp_expf(maxabs);
+  return s < -SCALE_CLAMP ? -SCALE_CLAMP : (s > SCALE_CLAMP ? SCALE_CLAMP : s);
+}
+__device__ __forceinline__ void pair16(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f2 x = {x0, x1};
+  const h2 h = __builtin_convertvector(x, h2);
+  const f2 r = x - __builtin_convertvector(h, f2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
+}
+// eight values times the power of two `sc` -> the two operand vectors (fp16 bit patterns in bf16x8 containers)
+__device__ __forceinline__ void eight16(const float (&v)[8], float sc, b8 (&s)[3]) {
+  u4 w[2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned a, b;
+    pair16(v[2 * p] * sc, v[2 * p + 1] * sc, a, b);
+    w[0][p] = a; w[1][p] = b;
+  }
+  s[0] = __builtin_bit_cast(b8, w[0]); s[1] = __builtin_bit_cast(b8, w[1]);
+}
+
 }  // namespace hgn_split

@@ -360,9 +360,16 @@ __global__ __launch_bounds__(WGW, 2) void wgrad6_kernel(const WArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int OPS_VEC = 2 * 3 * 4 * 128;          // bf16x8 vectors per block: [A|G][split][row group][feature]
 
-template <int NP>          // 6: fp32-accurate split products; 1: single bf16 product (hgn_set_matmul_products)
+// NP = 3 (two scaled fp16 terms, three products; csrc/split_bf16.h): the contraction runs over ROWS, so a scale must be uniform over the
+// 32 rows of a block: every producer wave leaves the largest magnitude of its 16 rows in LDS before the barrier that frees the
+// operand image, all waves derive the block's two exponents (eA, eG) from the four values, the block is multiplied from ZERO
+// accumulators on the matrix pipe and added to the fp32 accumulators on the vector pipe with the factor 2^-(eA + eG) (exact): no
+// running scale, no overflow however the gradient magnitude moves along the rows.
+template <int NP>          // 6 / 3: fp32-accurate split products; 1: single bf16 product (hgn_set_matmul_products)
 __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
   __shared__ __attribute__((aligned(16))) bf16x8 ops[OPS_VEC];                 // 48 KB
+  __shared__ float blkmax[2][2];                                                // [array][producer wave of the array]
+  constexpr int NSP = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
   const WTaskDev t = a.t[a.task0 + blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kg = lane >> 4;
@@ -403,16 +410,32 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) cs += x[j];
     }
+    if constexpr (NP == 3) {
+      float mx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[j][0]), fabsf(x[j][1]))), fmaxf(fabsf(x[j][2]), fabsf(x[j][3])));
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+      if (lane == 0) blkmax[arr][wave & 1] = mx;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                   // every wave has finished reading the operands of block p-1
+    float unscale = 1.f, sc = 1.f;
+    if constexpr (NP == 3) {
+      const int eA = hgn_split::scale_exp_of(fmaxf(blkmax[0][0], blkmax[0][1]));
+      const int eG = hgn_split::scale_exp_of(fmaxf(blkmax[1][0], blkmax[1][1]));
+      sc = hgn_split::pow2f(arr ? eG : eA);
+      unscale = hgn_split::pow2f(-(eA + eG));
+    }
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = x[j][f];
       bf16x8 sp[3];
-      split3v(v, sp);
+      if constexpr (NP == 3) hgn_split::eight16(v, sc, sp); else split3v(v, sp);
 #pragma unroll
-      for (int sidx = 0; sidx < (NP == 1 ? 1 : 3); ++sidx) ops[((arr * 3 + sidx) * 4 + kgp) * 128 + 4 * q + f] = sp[sidx];
+      for (int sidx = 0; sidx < NSP; ++sidx) ops[((arr * 3 + sidx) * 4 + kgp) * 128 + 4 * q + f] = sp[sidx];
     }
     if (p + 1 < nblocks) fetch(p + 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -421,14 +444,23 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int sidx = 0; sidx < (NP == 1 ? 1 : 3); ++sidx) gs[mb][sidx] = ops[((3 + sidx) * 4 + kg) * 128 + 32 * wave + 16 * mb + m];
+      for (int sidx = 0; sidx < NSP; ++sidx) gs[mb][sidx] = ops[((3 + sidx) * 4 + kg) * 128 + 32 * wave + 16 * mb + m];
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
       bf16x8 as[3];
 #pragma unroll
-      for (int sidx = 0; sidx < (NP == 1 ? 1 : 3); ++sidx) as[sidx] = ops[(sidx * 4 + kg) * 128 + 16 * nb + m];
+      for (int sidx = 0; sidx < NSP; ++sidx) as[sidx] = ops[(sidx * 4 + kg) * 128 + 16 * nb + m];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
+        if constexpr (NP == 3) {                  // the block's product from zero (smallest terms first), then into the fp32 accumulators
+          typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+          f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, gs[mb][1]), __builtin_bit_cast(f16x8, as[0]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, gs[mb][0]), __builtin_bit_cast(f16x8, as[1]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, gs[mb][0]), __builtin_bit_cast(f16x8, as[0]), c, 0, 0, 0);
+          acc[mb][nb] += c * unscale;
+          continue;
+        }
         f32x4 c = acc[mb][nb];
         if (NP != 1) {
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gs[mb][2], as[0], c, 0, 0, 0);
@@ -590,7 +622,7 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   if (n0 + n1 != n_tasks) return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad task type");
   for (int i = 0; i < n_tasks; ++i)
     if (!valid_products(tasks[i].products) || tasks[i].products != tasks[0].products || tasks[i].flags != tasks[0].flags)
-      return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: products (0, 6, 1 or 2) and flags must agree over the tasks of one launch");
+      return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: products (0, 6, 3, 1 or 2) and flags must agree over the tasks of one launch");
   const int nch0 = chunks_mfma(M, n0), nch1 = chunks_ln(M);
   WArgs wa; RArgs ra;
   wa.M = M;
@@ -626,6 +658,7 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
       else
 #endif
       if (bwd_products(tasks[0].products) == 1) hipLaunchKernelGGL(wgrad6s_kernel<1>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
+      else if (bwd_products(tasks[0].products) == 3) hipLaunchKernelGGL(wgrad6s_kernel<3>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
       else hipLaunchKernelGGL(wgrad6s_kernel<6>, dim3((unsigned)nch0, (unsigned)nd), dim3(WGW), 0, (hipStream_t)stream, wa);
     }
   }

@@ -253,7 +253,9 @@ def storage_signature(pairs) -> tuple:
 def _pack_form(transposed: bool, c: Context) -> int:
     # forward-form images of the fp16 mode carry fp16 bit patterns in their leading third (hgn_pack_t.transposed | 2)
     # ... and those of the scaled two-term fp16 mode two fp16 terms + the block's scale exponent (hgn_pack_t.transposed | 4)
-    return 1 if transposed else {2: 2, 3: 4}.get(c.products(), 0)
+    if transposed:
+        return 5 if c.products() == 3 else 1
+    return {2: 2, 3: 4}.get(c.products(), 0)
 
 
 def _pack_key(w: MLPWeights, t: int, c: Context) -> tuple:

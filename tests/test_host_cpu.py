@@ -615,7 +615,7 @@ def test_two_contexts_with_different_precisions_from_two_threads_through_the_abi
                     a.M = 5
                     a.out_w = 500                                   # invalid on purpose: the call answers with a status code
                     assert lib.hgn_mlp_fwd(C.byref(a), None) == -1 and b'out_w' in lib.hgn_last_error()      # thread-local text
-                    a.products = 3                                  # not a mode: refused before anything else
+                    a.products = 4                                  # not a mode: refused before anything else
                     assert lib.hgn_mlp_fwd(C.byref(a), None) == -1 and b'products' in lib.hgn_last_error()
                     t = _lib.WTask()
                     c.stamp(t)

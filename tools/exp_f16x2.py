@@ -70,6 +70,58 @@ for cfg in [(20, 20, 1, 1, 1, 0), (20, 20, 1, 1, 1, 3), (20, 20, 1e-6, 1e-6, 1, 
             (20, 20, 1, 1, 1e-3, 0), (7, 5, 1, 1, 1, 0)]:
     accuracy(*cfg)
 
+def grad_accuracy(nx, ny, gscale):
+    """forward + backward of an edge block and a two-source node MLP against fp64 autograd; `gscale` scales the loss (gradient magnitude)"""
+    g = synthetic.grid_graph(seed=3, nx=nx, ny=ny)
+    es = g.edge_sets[0]
+    N, E = g.node_features[0].shape[0], es.senders.shape[0]
+    topo = topology.EdgeTopology(es.senders.cuda(), es.receivers.cuda(), N, dev)
+    torch.manual_seed(0)
+    m = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges']).cuda()
+    with torch.no_grad():
+        m(hgn_amd.MultiGraph([g.node_features[0].cuda()], [hgn_amd.EdgeSet(es.name, es.features.cuda(), es.senders.cuda(), es.receivers.cuda())]))
+    blk = m.processor.graphnet_blocks[0]
+    we = modules.weights_of(blk.edge_models['mesh_edges'], 384)
+    wn = modules.weights_of(blk.node_model_cross, 256)
+    h0 = torch.randn(N, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    e0 = torch.randn(E, 128, generator=torch.Generator().manual_seed(2)).cuda()
+    rowsc = torch.exp(torch.randn(E, 1, generator=torch.Generator().manual_seed(3)) * 2).cuda()      # rows whose gradients differ by orders of magnitude
+
+    def run():
+        h = h0.clone().requires_grad_(True); e = e0.clone().requires_grad_(True)
+        for p in list(blk.parameters()):
+            p.grad = None
+        y, agg = ops.edge_block(h, e, topo, we, ('sum',))
+        hn = ops.fused_mlp([h, agg], wn, None, 0)
+        ((hn.square().sum() + (y * rowsc).square().sum()) * gscale).backward()
+        return [y.detach(), hn.detach(), h.grad, e.grad] + [p.grad.clone() for p in blk.parameters()]
+
+    snd, rcv = topo.snd.long(), topo.rcv.long()
+    h = h0.double().requires_grad_(True); e = e0.double().requires_grad_(True)
+    ps = [p.detach().double().requires_grad_(True) for p in blk.parameters()]
+    P = dict(zip([n for n, _ in blk.named_parameters()], ps))
+
+    def mlp(x, pre):
+        z = torch.relu(x @ P[pre + '.0.layers.linear_0.weight'].T + P[pre + '.0.layers.linear_0.bias'])
+        z = torch.relu(z @ P[pre + '.0.layers.linear_1.weight'].T + P[pre + '.0.layers.linear_1.bias'])
+        z = z @ P[pre + '.0.layers.linear_2.weight'].T + P[pre + '.0.layers.linear_2.bias']
+        return torch.nn.functional.layer_norm(z, (128,), P[pre + '.1.weight'], P[pre + '.1.bias'], 1e-5)
+    y = e + mlp(torch.cat([h[snd], h[rcv], e], 1), 'edge_models.mesh_edges')
+    agg = torch.zeros(N, 128, dtype=torch.float64, device='cuda').index_add(0, rcv, y)
+    hn = h + mlp(torch.cat([h, agg], 1), 'node_model_cross')
+    ((hn.square().sum() + (y * rowsc.double()).square().sum()) * gscale).backward()
+    r64 = [y.detach(), hn.detach(), h.grad, e.grad] + [p.grad for p in ps]
+    for mode in a.modes.split(','):
+        with ops.using(ops.Context(precision=mode)):
+            got = run()
+        errs = [rel(x, y_) for x, y_ in zip(got, r64)]
+        print(f'grads E={E} loss*{gscale:g} {mode}: out {max(errs[:2]):.2e}  dh {errs[2]:.2e} de {errs[3]:.2e}  worst param grad {max(errs[4:]):.2e}  '
+              f'finite {all(bool(torch.isfinite(x).all()) for x in got)}', flush=True)
+
+
+for cfg in [(20, 20, 1.0), (20, 20, 1e-9), (20, 20, 1e6), (33, 29, 1e-4)]:
+    grad_accuracy(*cfg)
+
 # ---- timing at the headline row count ----------------------------------------------------------------------------------
 g = synthetic.batch([synthetic.grid_graph(seed=i % 4) for i in range(a.batch)])
 es = g.edge_sets[0]
