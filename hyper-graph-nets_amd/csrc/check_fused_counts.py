@@ -12,19 +12,21 @@ import re
 import sys
 
 KERNEL = '_ZN3hgn21edge_bwd_fused_kernelILi6EEEvNS_9FusedArgsE'
+KERNEL3 = '_ZN3hgn2f322edge_bwd_fused3_kernelENS_9FusedArgsE'      # csrc/fused_bwd3.hip: two fp16 terms, 4 DMA instructions per piece and wave
 PHASES = 12
 DMA_PER_PHASE = 6            # Ring<6>::DPW
 LOADS_PER_FETCH = 8
 FETCH_PHASES = {1, 4, 6, 11}  # wg_fetches()
 
 
-def check(text: str) -> None:
-    at = text.index(KERNEL + ':')
+def check(text: str, kernel: str = KERNEL, DMA_PER_PHASE: int = DMA_PER_PHASE, fetch_dma: int = 0) -> None:
+    LOADS = 0 if fetch_dma else LOADS_PER_FETCH           # fused_bwd3: the operand fetches are LDS-DMA too (fetch_dma per fetch)
+    at = text.index(kernel + ':')
     body = text[at:text.index('.Lfunc_end', at)]
     if 'scratch_' in body:
         raise AssertionError('register spills in the fused backward: their memory traffic breaks the counted waits')
     lines = [l.strip() for l in body.splitlines()]
-    total = PHASES * DMA_PER_PHASE
+    total = PHASES * DMA_PER_PHASE + fetch_dma * len(FETCH_PHASES)
     heads = [i for i, l in enumerate(lines) if 'Loop Header' in l]
     dma_lines = [i for i, l in enumerate(lines) if l.startswith('global_load_lds_dwordx4')]
     # the weight-gradient loop: the innermost loop that holds a whole tile's LDS-DMA instructions (the prologue's lie before it)
@@ -48,10 +50,12 @@ def check(text: str) -> None:
     if len(phases) != PHASES or len(waits) != PHASES:
         raise AssertionError(f'expected {PHASES} phases / waits in the weight-gradient loop, found {len(phases)} / {len(waits)}')
     for p, ph in enumerate(phases):
-        want_loads = LOADS_PER_FETCH if p in FETCH_PHASES else 0
-        if ph['dma'] != DMA_PER_PHASE or ph['stores'] != 0 or ph['loads'] != want_loads:
-            raise AssertionError(f'phase {p}: {ph}, expected {DMA_PER_PHASE} DMA, {want_loads} loads, 0 stores')
-        keep = DMA_PER_PHASE + LOADS_PER_FETCH * (((p - 2) % PHASES) in FETCH_PHASES) + LOADS_PER_FETCH * (((p - 1) % PHASES) in FETCH_PHASES)
+        want_loads = LOADS if p in FETCH_PHASES else 0
+        want_dma = DMA_PER_PHASE + (fetch_dma if p in FETCH_PHASES else 0)
+        if ph['dma'] != want_dma or ph['stores'] != 0 or ph['loads'] != want_loads:
+            raise AssertionError(f'phase {p}: {ph}, expected {want_dma} DMA, {want_loads} loads, 0 stores')
+        per_fetch = fetch_dma or LOADS_PER_FETCH
+        keep = DMA_PER_PHASE + per_fetch * (((p - 2) % PHASES) in FETCH_PHASES) + per_fetch * (((p - 1) % PHASES) in FETCH_PHASES)
         if waits[p] != keep:
             raise AssertionError(f'phase {p}: s_waitcnt vmcnt({waits[p]}), Keep<> says {keep}')
 
@@ -101,6 +105,9 @@ if __name__ == '__main__':
         if KERNEL + ':' in text:
             check(text)
             print('check_fused_counts: ok (fused backward: 12 phases, counted waits match the emitted instructions)')
+        if KERNEL3 + ':' in text:
+            check(text, KERNEL3, 4, 4)
+            print('check_fused_counts: ok (fused backward, two-term fp16 form: 12 phases, counted waits match the emitted instructions)')
         for kernel in EDGE_KERNELS:
             if kernel + ':' in text:
                 n = check_edge_forward(text, kernel)

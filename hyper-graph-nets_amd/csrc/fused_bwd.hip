@@ -37,6 +37,7 @@
 #include "hgn_host.h"
 #include "mlp_common.h"
 #include "mlp6_device.h"
+#include "fused_args.h"
 
 // Diagnostic build only (-DHGN_FUSED_STAMPS, tools/fusedstamps.py): shader-clock stamps of one mid-launch workgroup's waves 0 (chain)
 // and 4 (weight gradients) at every phase boundary of its 11th tile.  In the shipped library FSTAMP() is empty.  Read them with
@@ -67,15 +68,8 @@ constexpr int G_BYTES = 3 * 64 * 256;                 // [split][row 0..63][feat
 constexpr int A_BYTES = 3 * 4 * 128 * 16;             // [split][row group 0..3][feature] bf16x8: 32 rows, 24 KB
 constexpr int G_OFF = RING_BYTES, A_OFF = G_OFF + G_BYTES, LN_OFF = A_OFF + A_BYTES, LNG_OFF = LN_OFF + 4 * 256 * 4;
 constexpr int FUSED_LDS = LNG_OFF + 128 * 4;
-constexpr int FSLAB = 128 * 128 + 128;                // floats per (workgroup, layer): dW partial + bias partial (= wgrad.hip SLAB)
 static_assert(FUSED_LDS <= 160 * 1024, "one workgroup per CU");
-
-struct FusedArgs {
-  hgn_mlp_bwd_t b;                                    // the data-gradient chain (n_dx == 1, residual, LayerNorm, ReLU sign words)
-  const float* A[2];                                  // other operand of dW3, dW2: z2, z1 (row stride 128)
-  float* slabs;                                       // [gridDim.x][2][FSLAB]
-  long tiles;                                         // 64-row tiles
-};
+// (FusedArgs, FSLAB: csrc/fused_args.h)
 
 __device__ __forceinline__ void bar_lds() {           // every wave's LDS traffic issued so far is complete; global traffic stays in flight
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -638,7 +632,6 @@ extern "C" int hgn_edge_bwd_fused_workspace_bytes(int64_t M, size_t* bytes) {
 
 extern "C" int hgn_edge_bwd_fused_eligible(const hgn_mlp_bwd_t* a) {
   if (!a || !hgn_mlp_bwd6_eligible(a)) return 0;          // (includes the HGN_F_FP32_MFMA flag of the call)
-  if (bwd_products(a->products) == 3) return 0;             // (mode 3: the two-launch path until the fused kernel has its form)
   if (a->n_dx != 1 || !a->dx[0].residual || a->dx[0].K != 128 || a->seg_dz1 || !a->dz1) return 0;
   if (a->agg_dout && (a->n_agg_ops != 1 || a->agg_ops[0] != HGN_OP_SUM)) return 0;      // several aggregates (pna): the two-launch path
   const int64_t ldmax = a->ld_dout > a->dx[0].ld ? a->ld_dout : a->dx[0].ld;
@@ -678,7 +671,8 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   fa.slabs = (float*)workspace;
   fa.tiles = (a->M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(14, (double)a->M, stream);
-  if (bwd_products(a->products) == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
+  if (bwd_products(a->products) == 3) { if (launch_edge_bwd_fused3(fa, G, stream) != HGN_OK) return HGN_E_LAUNCH; }
+  else if (bwd_products(a->products) == 1) hipLaunchKernelGGL((edge_bwd_fused_kernel<1>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
   else hipLaunchKernelGGL((edge_bwd_fused_kernel<6>), dim3((unsigned)G), dim3(FT), 0, stream, fa);
   if (hgn_check_launch("hgn_edge_bwd_fused") != HGN_OK) return HGN_E_LAUNCH;
   // fixed-order sums of the per-workgroup partials: two weight gradients + biases, and the LayerNorm-affine gradients

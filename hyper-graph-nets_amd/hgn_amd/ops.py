@@ -23,7 +23,7 @@ _ENV = __import__('os').environ
 # Process-wide DEFAULTS, resolved once here (the library itself reads no environment variable): what a Context that does not say
 # otherwise follows.  HGN_FP32_MFMA: the plain fp32-MFMA kernels everywhere; HGN_NO_FUSED_BWD: hgn_mlp_bwd + hgn_mlp_wgrad instead of
 # hgn_edge_bwd_fused; HGN_NO_EDGE_FWD: the general forward kernel for training edge blocks too.
-_DEFAULTS = {'precision': 'fp32', 'fp32_mfma': bool(_ENV.get('HGN_FP32_MFMA')), 'general_fwd': bool(_ENV.get('HGN_NO_EDGE_FWD')),
+_DEFAULTS = {'precision': _ENV.get('HGN_PRECISION', 'fp32'), 'fp32_mfma': bool(_ENV.get('HGN_FP32_MFMA')), 'general_fwd': bool(_ENV.get('HGN_NO_EDGE_FWD')),
              'fused_edge_bwd': not bool(_ENV.get('HGN_NO_FUSED_BWD')) and not bool(_ENV.get('HGN_FP32_MFMA'))}
 _defaults_epoch = 0           # bumped when a default changes: packed weight images of every context are rebuilt on their next use
 _FUSED_SEG_MAX_ROWS = 65      # a segment of <= 65 consecutive rows touches at most two 64-row tiles
