@@ -34,6 +34,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix pea
 
 
 
+PRODUCT_TEXT = {3: 'fp32 operands split into 2 fp16 terms scaled by powers of two, 3 fp16 MFMAs per product, fp32 accumulate',
+                6: 'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate',
+                1: 'operands rounded to bf16, 1 bf16 MFMA per product', 2: 'forward: operands rounded to fp16, 1 fp16 MFMA per product; backward as mode 3'}
+
+
 def limited_by(ent: dict, hbm_frac: float) -> str:
     """The bound label of the roofline object, DERIVED from the counters of profiles/sq_counters.json (rocprofv3 SQ_* passes of the
     same kernel sources) and the live HBM fraction: a roof binds above 70 % of it; otherwise the waves' own cycle split says whether
@@ -639,6 +644,7 @@ def main():
             per_row = {'mlp_fwd_edge': 3, 'mlp_bwd_edge': 3, 'wgrad': 1, 'wgrad_node': 1, 'edge_bwd_fused': 5}[name] * 2 * 128 * 128
             tf = per_row * rows / t_launch / 1e12
             fp32_only = bool(os.environ.get('HGN_FP32_MFMA'))
+            n_prod = ops._PRODUCTS[args.precision]
             traffic, traffic_note = None, None
             sha = kernel_source_sha()
             try:        # HBM bytes per launch from the rocprofv3 PMC passes of this configuration (profiles/README.md)
@@ -663,9 +669,9 @@ def main():
                                                            else bytes_launch) / t_launch / 1e9 / PEAK_HBM_GBS,
                                'matrix_pipe': {'fp32_equivalent_TFLOPs': tf, 'flop_per_row': per_row,
                                                'frac_of_fp32_mfma_peak': tf / PEAK_F32_MFMA_TFLOPS,
-                                               'frac_of_bf16_mfma_peak': None if fp32_only else 6 * tf / PEAK_BF16_MFMA_TFLOPS,
-                                               'products': 'fp32 MFMA' if fp32_only else
-                                               'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate'},
+                                               'mfmas_per_product': None if fp32_only else n_prod,
+                                               'frac_of_16bit_mfma_peak': None if fp32_only else n_prod * tf / PEAK_BF16_MFMA_TFLOPS,
+                                               'products': 'fp32 MFMA' if fp32_only else PRODUCT_TEXT[n_prod]},
                                'selection': 'largest accumulated time' + (' among forward kernels (side stream on)' if overlapped else '')}
             # what the hardware counters of the same launch say (profiles/sq_counters.json: rocprofv3 --pmc SQ_* passes of
             # tools/fusedbench.py on these kernel sources; dropped when the sources have changed since)
@@ -692,11 +698,12 @@ def main():
             step_tf = step_flops / (ms_per_step * 1e-3) / 1e12
             res['roofline_step'] = {'bound': 'mfma', 'achieved': step_tf, 'peak': PEAK_F32_MFMA_TFLOPS,
                                     'unit': 'TFLOP/s', 'frac': step_tf / PEAK_F32_MFMA_TFLOPS,
-                                    # the pipe these products really run on: six bf16 MFMAs per fp32-accurate product, so the hardware
-                                    # roof for fp32-equivalent work is the bf16 peak / 6 (417 TFLOP/s) -- `frac` above prices bf16-pipe
-                                    # work against the fp32-MFMA peak and is NOT a hardware fraction
-                                    'bf16x6_roof_TFLOPs': None if fp32_only else PEAK_BF16_MFMA_TFLOPS / 6,
-                                    'frac_of_bf16x6_roof': None if fp32_only else step_tf / (PEAK_BF16_MFMA_TFLOPS / 6),
+                                    # the pipe these products really run on: n_prod 16-bit MFMAs per fp32-accurate product (3: two scaled fp16
+                                    # terms; 6: three bf16 terms), so the hardware roof for fp32-equivalent work is the 16-bit peak / n_prod
+                                    # (833 / 417 TFLOP/s) -- `frac` above prices that work against the fp32-MFMA peak and is NOT a hardware fraction
+                                    'mfmas_per_product': None if fp32_only else n_prod,
+                                    'split_product_roof_TFLOPs': None if fp32_only else PEAK_BF16_MFMA_TFLOPS / n_prod,
+                                    'frac_of_split_product_roof': None if fp32_only else step_tf / (PEAK_BF16_MFMA_TFLOPS / n_prod),
                                     'note': 'fp32-equivalent flops (one per fp32 product term, not per bf16 MFMA); lower bound: node MLPs with '
                                             'more than one 128-wide source do more than 3 products'}
             # the scatter-add (segment-sum) kernel vs HBM.  With `sum` aggregation the forward aggregate is formed inside the

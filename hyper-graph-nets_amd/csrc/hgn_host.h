@@ -8,9 +8,9 @@ namespace hgn {
 int hgn_fail(int code, const char* msg);          // records msg (thread-local) and returns code
 int hgn_check_launch(const char* what);
 // `per_call`: the call's own `products` field (include/hgn_mp.h), 0 = the process default of hgn_set_matmul_products
-int bwd_products(int per_call);                   // products of the backward / weight-gradient kernels: 6, or 1 (bf16) in both reduced modes
-int matmul_products(int per_call);                // 6 (fp32-accurate split products), 1 (single bf16 product) or 2 (single fp16 product, forward only)
-bool valid_products(int p);                       // 0, 1, 2 or 6
+int bwd_products(int per_call);                   // products of the backward / weight-gradient kernels: 6, 3, 1 -- and 3 for mode 2 (host.cpp)
+int matmul_products(int per_call);                // 6 / 3 (fp32-accurate split products), 1 (single bf16 product) or 2 (single fp16 product, forward only)
+bool valid_products(int p);                       // 0, 1, 2, 3 or 6
 extern thread_local int g_prof_tag;           // hipGetLastError() -> HGN_OK / HGN_E_LAUNCH
 
 // Fixed-order reductions shared between translation units (wgrad.hip / mlp.hip own the kernels).

@@ -11,9 +11,13 @@ namespace hgn {
 static thread_local char g_err[512] = "";
 thread_local int g_prof_tag = 0;
 // the DEFAULT for calls that leave `products` at 0: one word, written by hgn_set_matmul_products only (relaxed atomic)
-static std::atomic<int> g_products{6};
+static std::atomic<int> g_products{3};
 int matmul_products(int per_call) { return per_call ? per_call : g_products.load(std::memory_order_relaxed); }
-int bwd_products(int per_call) { const int p = matmul_products(per_call); return (p == 6 || p == 3) ? p : 1; }
+// products of the backward / weight-gradient kernels: the forward's for 6, 3 and 1; mode 2 (ONE fp16 product in the forward) differentiates
+// with the two-term fp16 products of mode 3 -- fp16 operands need per-row / per-block scales in the backward anyway (gradients leave
+// fp16's range), and with the scales in place the second term costs little: the gradients are then exact derivatives of the
+// reduced-precision forward up to fp32 rounding, which is what gives the mode a gradient tolerance at all
+int bwd_products(int per_call) { const int p = matmul_products(per_call); return p == 2 ? 3 : p; }
 bool valid_products(int p) { return p == 0 || p == 1 || p == 2 || p == 3 || p == 6; }
 
 int hgn_fail(int code, const char* msg) {

@@ -425,9 +425,11 @@ __global__ __launch_bounds__(WG, 2) void mlp6_fwd_edge_kernel(const hgn_mlp_fwd_
 // per accumulator, same row sums: bit-identical to the other forms.  No saved activations, no in-kernel segment sums: launches
 // that need either take mlp6_fwd_kernel<1, NP, 4 + LAT_LOADERS>.
 template <int NP>
-__device__ __forceinline__ void cs_split8(const f32x4& v0, const f32x4& v1, bf16x8 (&o)[3]) {
+__device__ __forceinline__ void cs_split8(const f32x4& v0, const f32x4& v1, bf16x8 (&o)[3], float sc = 1.f) {
   const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-  if constexpr (NP == 2) {
+  if constexpr (NP == 3) {
+    hgn_split::eight16(v, sc, o);
+  } else if constexpr (NP == 2) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[0][j] = __builtin_bit_cast(__bf16, (_Float16)v[j]);
   } else {
@@ -457,9 +459,10 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
       if (tail == 1) return reinterpret_cast<const __bf16*>(a.W2pk);
       if (tail == 2) return reinterpret_cast<const __bf16*>(a.W3pk);
       return tail - 3 < a.n_post ? reinterpret_cast<const __bf16*>(a.post_pk[tail - 3]) : nullptr;
-    }, a.n_post > 0 ? main_halves : -1);
+    }, a.n_post > 0 ? main_halves : -1, Prod<NP>::SCALED ? 1 : 0, Prod<NP>::SCALED ? 3 : 2);
     return;
   }
+  __shared__ float rmax[4][16];                       // scaled mode: the four waves' shares of the row maxima of a block's operand
   const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
   const long row = (long)blockIdx.x * 16 + n;
   const bool valid = row < a.M;
@@ -473,12 +476,27 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
   f32x4 acc[2];
   bf16x8 xs[3][4];
   int slot = 0;
-  constexpr int NSP = NP != 6 ? 1 : 3;
-  auto produce = [&](const f32x4& v0, const f32x4& v1) {
+  constexpr int NSP = Prod<NP>::NSPLIT;
+  // -> the row's scale exponent (mode 3: whole-row maximum over the four waves' shares, as split_np computes it in the other forms:
+  // one barrier of the compute waves' own, which the loaders join -- lat_loader: xbar)
+  auto produce = [&](const f32x4& v0, const f32x4& v1) -> int {
     bf16x8 o[3];
-    cs_split8<NP>(v0, v1, o);
+    int e = 0;
+    float sc = 1.f;
+    if constexpr (Prod<NP>::SCALED) {
+      float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                      fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (kq == 0) rmax[wave][n] = m;
+      wg_barrier_lds();
+      e = scale_exp_of(fmaxf(fmaxf(rmax[0][n], rmax[1][n]), fmaxf(rmax[2][n], rmax[3][n])));
+      sc = pow2f(e);
+    }
+    cs_split8<NP>(v0, v1, o, sc);
 #pragma unroll
     for (int sp = 0; sp < NSP; ++sp) xch[wave][sp][lane] = o[sp];
+    return e;
   };
   auto consume = [&] {
 #pragma unroll
@@ -498,7 +516,14 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
 #pragma unroll
         for (int sp = 0; sp < NSP; ++sp) fr[k][sp] = *reinterpret_cast<const bf16x8*>(lp + ((sp * 2 + cl) * 8 + k) * TILE_BF16);
       f32x4 t0 = acc[0], t1 = acc[1];
-      if constexpr (NP != 6) {
+      if constexpr (NP == 3) {                        // smallest terms first, the two accumulation chains interleaved
+        t0 = mfma_f16(fr[0][1], xs[0][c], t0);
+        t1 = mfma_f16(fr[1][1], xs[0][c], t1);
+        t0 = mfma_f16(fr[0][0], xs[1][c], t0);
+        t1 = mfma_f16(fr[1][0], xs[1][c], t1);
+        t0 = mfma_f16(fr[0][0], xs[0][c], t0);
+        t1 = mfma_f16(fr[1][0], xs[0][c], t1);
+      } else if constexpr (NP != 6) {
         t0 = mfma_one<NP>(fr[0][0], xs[0][c], t0);
         t1 = mfma_one<NP>(fr[1][0], xs[0][c], t1);
       } else {
@@ -519,13 +544,17 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     }
     slot = slot == 2 ? 0 : slot + 1;
   };
-  auto block = [&](bool opened = false) {             // xch holds the operand vectors of this block's input
+  // `T` (scaled mode): exponent of the operand rows' scale + the block's (acc is carried at 2^T through the block, true scale outside)
+  auto block = [&](bool opened = false, int T = 0) {  // xch holds the operand vectors of this block's input
+    if constexpr (Prod<NP>::SCALED) { const float f = pow2f(T); acc[0] *= f; acc[1] *= f; }
     if (!opened) wg_barrier_lds();                    // ... visible to every wave; the block's first weight half has landed
     consume();
     sweep(std::integral_constant<int, 0>{});
     wg_barrier_lds();                                 // second half landed; every wave has read xch
     sweep(std::integral_constant<int, 1>{});
+    if constexpr (Prod<NP>::SCALED) { const float f = pow2f(-T); acc[0] *= f; acc[1] *= f; }
   };
+  auto sw_of = [&](const void* pk) -> int { return Prod<NP>::SCALED ? pack_scale_exp(reinterpret_cast<const __bf16*>(pk)) : 0; };
 
   bool first = true;
   for (int si = 0; si < a.n_src; ++si) {
@@ -559,21 +588,22 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
         }
         first = false;
       }
-      produce(v[0], v[1]);
-      block();
+      const int e = produce(v[0], v[1]);
+      block(false, e + sw_of(reinterpret_cast<const __bf16*>(s.Wpk) + (long)(k0 >> 7) * BLOCK_BF16));
     }
   }
   const float* bias[2] = {a.b2, a.b3};
+  const void* wpk[2] = {a.W2pk, a.W3pk};
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[k][u] = fmaxf(acc[k][u], 0.f);
-    produce(acc[0], acc[1]);
+    const int e = produce(acc[0], acc[1]);
     acc[0] = chunk(bias[l] + col0);
     acc[1] = chunk(bias[l] + col1);
-    block();
+    block(false, e + sw_of(wpk[l]));
   }
   // ---- the whole pre-LayerNorm tile to every wave (row sums in the order of the other kernels) -----------------------------
   *reinterpret_cast<f32x4*>(tile + n * 132 + col0) = acc[0];
@@ -605,12 +635,12 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
   // the tile in LDS, and those from their readers.
   if (a.n_post > 0) {
     wg_barrier_lds();                                 // every wave has read the tile
-    produce(o2[0], o2[1]);
+    const int e_post = produce(o2[0], o2[1]);         // (scaled mode: one more barrier inside, lat_loader: extra_n = 3)
     wg_barrier_lds();                                 // the operand vectors of the output rows are visible
     for (int pb = 0; pb < a.n_post; ++pb) {
       acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      block(pb == 0);                                 // (xs is re-read per block: 12 LDS reads against 48 products)
+      block(pb == 0, e_post + sw_of(a.post_pk[pb]));  // (xs is re-read per block: 12 LDS reads against 48 products)
       if (valid) {
         *reinterpret_cast<f32x4*>(a.post_out + row * a.ld_post + 128 * pb + col0) = acc[0];
         *reinterpret_cast<f32x4*>(a.post_out + row * a.ld_post + 128 * pb + col1) = acc[1];
@@ -625,7 +655,8 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
 
 // single Linear over packed 128-wide blocks (node pre-projection of the split edge layer)
 struct Lin6Args { const float* x; long ldx; long M; const __bf16* pk[4]; int n_blocks; float* out; long ld_out;
-                  float* zero; long ld_zero; };      // zero (optional): rows [0, M) x 128 floats set to 0 in the same pass
+                  float* zero; long ld_zero;        // zero (optional): rows [0, M) x 128 floats set to 0 in the same pass
+                  int accumulate; };                // backward only: out += ... (the accumulators start from the rows of `out`)
 
 // LATF: the latency form (see mlp6_fwd_kernel<1, NP, 6>): 4 compute waves + LAT_LOADERS loader waves, ring of three 48 KB slots
 template <int NP, bool LATF = false>
@@ -768,7 +799,7 @@ __global__ __launch_bounds__(WG, 3) void linear6_bwd_kernel(const Lin6Args a) {
   const int kq = (threadIdx.x & 63) >> 4;
   const Rows<1> R(a.M);
   Act acc[1], b[1];
-  t_zero(acc[0]);
+  if (a.accumulate) t_load(acc[0], a.out + R.rc[0] * a.ld_out, kq); else t_zero(acc[0]);
   for (int blk = 0; blk < a.n_blocks; ++blk)
     gemm6<1, NP>(acc, b, lds, a.pk[blk], [&] { t_load(b[0], a.x + R.rc[0] * a.ldx + 128 * blk, kq); });
   if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out, kq);
@@ -893,11 +924,12 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, 192-row tiles)");
   }
 #endif
-  if (cs_eligible(a) && np_ != 3) {               // (mode 3 needs whole-row scales: its small launches take the row-per-wave latency form)
+  if (cs_eligible(a)) {
     const long wgs = (a->M + 15) / 16;               // inference on at most 16 rows per CU: the column-split latency form
     constexpr int T = 64 * (4 + CS_LOADERS);
     if (np_ == 1) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
     else if (np_ == 2) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<2>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+    else if (np_ == 3) hipLaunchKernelGGL((mlp6_fwd_cs_kernel<3>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((mlp6_fwd_cs_kernel<6>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, column-split latency form)");
   }
@@ -943,19 +975,34 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_fwd_cs_kerne
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave >= 4) {
     int blk = 0;
-    lat_loader<NP, CS_LOADERS>(lds, (unsigned)wave - 4u, [&]() -> const __bf16* { return blk < a.n_blocks ? a.pk[blk++] : nullptr; });
+    lat_loader<NP, CS_LOADERS>(lds, (unsigned)wave - 4u, [&]() -> const __bf16* { return blk < a.n_blocks ? a.pk[blk++] : nullptr; }, -1,
+                               Prod<NP>::SCALED ? 2 : 0);
     return;
   }
+  __shared__ float rmax[4][16];
   const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
   const long row = (long)blockIdx.x * 16 + n;
   const bool valid = row < a.M;
   const long rc = valid ? row : a.M - 1;
   const int col0 = 16 * (2 * wave) + 4 * kq, col1 = col0 + 16;
-  constexpr int NSP = NP != 6 ? 1 : 3;
+  constexpr int NSP = Prod<NP>::NSPLIT;
+  int e_row = 0;
   {
     const float* xr = a.x + rc * a.ldx;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr + col0), v1 = *reinterpret_cast<const f32x4*>(xr + col1);
+    float sc = 1.f;
+    if constexpr (Prod<NP>::SCALED) {                 // whole-row maximum over the four waves' shares (one barrier, joined by the loaders)
+      float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                      fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (kq == 0) rmax[wave][n] = m;
+      wg_barrier_lds();
+      e_row = scale_exp_of(fmaxf(fmaxf(rmax[0][n], rmax[1][n]), fmaxf(rmax[2][n], rmax[3][n])));
+      sc = pow2f(e_row);
+    }
     bf16x8 o[3];
-    cs_split8<NP>(*reinterpret_cast<const f32x4*>(xr + col0), *reinterpret_cast<const f32x4*>(xr + col1), o);
+    cs_split8<NP>(v0, v1, o, sc);
 #pragma unroll
     for (int sp = 0; sp < NSP; ++sp) xch[wave][sp][lane] = o[sp];
   }
@@ -987,7 +1034,11 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_fwd_cs_kerne
           for (int hsel = 0; hsel < 2; ++hsel) {
             if (hsel != half) continue;               // (xs is a register array: the contraction block is selected at compile time)
             const int c = 2 * hsel + cl;
-            if constexpr (NP != 6) t = mfma_one<NP>(fr[k][0], xs[0][c], t);
+            if constexpr (NP == 3) {
+              t = mfma_f16(fr[k][1], xs[0][c], t);      // smallest terms first
+              t = mfma_f16(fr[k][0], xs[1][c], t);
+              t = mfma_f16(fr[k][0], xs[0][c], t);
+            } else if constexpr (NP != 6) t = mfma_one<NP>(fr[k][0], xs[0][c], t);
             else {
               t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[k][2], xs[0][c], t, 0, 0, 0);      // smallest terms first
               t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[k][0], xs[2][c], t, 0, 0, 0);
@@ -1001,6 +1052,10 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_fwd_cs_kerne
         }
       }
       slot = slot == 2 ? 0 : slot + 1;
+    }
+    if constexpr (Prod<NP>::SCALED) {                 // (the products ran from zero: only the way back to the true scale)
+      const float f = pow2f(-(e_row + pack_scale_exp(a.pk[blk])));
+      acc[0] *= f; acc[1] *= f;
     }
     if (valid) {
       *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + 128 * blk + col0) = acc[0];
@@ -1029,17 +1084,18 @@ extern "C" int hgn_linear_fwd6z(const float* x, int64_t ldx, int64_t M, const vo
       (zero_rows && ((ld_zero & 3) || ld_zero < 128 || !aligned16(zero_rows))))
     return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: bad argument");
   Lin6Args a;
-  a.x = x; a.ldx = ldx; a.M = M; a.n_blocks = nb; a.out = out; a.ld_out = ld_out; a.zero = zero_rows; a.ld_zero = ld_zero;
+  a.x = x; a.ldx = ldx; a.M = M; a.n_blocks = nb; a.out = out; a.ld_out = ld_out; a.zero = zero_rows; a.ld_zero = ld_zero; a.accumulate = 0;
   for (int i = 0; i < 4; ++i) a.pk[i] = i < nb ? reinterpret_cast<const __bf16*>(pk_blocks[i]) : nullptr;
   for (int i = 0; i < nb; ++i)
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_fwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(7, (double)M, (hipStream_t)stream);
-  if (M <= 16 * hgn::lat_max_tiles() && hgn::cs_enabled() && np_ != 3) {
+  if (M <= 16 * hgn::lat_max_tiles() && hgn::cs_enabled()) {
     constexpr int T = 64 * (4 + hgn::CS_LOADERS);
     const long wgs = (M + 15) / 16;
     if (np_ == 1) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
     else if (np_ == 2) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<2>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    else if (np_ == 3) hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<3>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((hgn::linear6_fwd_cs_kernel<6>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
     return hgn_check_launch("hgn_linear_fwd6 (column-split latency form)");
   }
@@ -1092,15 +1148,21 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
 }
 }  // namespace hgn
 
+extern "C" int hgn_linear_bwd6a(const float* g, int64_t ldg, int64_t M, const void* const* pk_blocks, int nb, float* dx,
+                                int64_t ld_dx, int accumulate, int products, void* stream);
 extern "C" int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* pk_blocks, int nb, float* dx,
                                int64_t ld_dx, int products, void* stream) {
+  return hgn_linear_bwd6a(g, ldg, M, pk_blocks, nb, dx, ld_dx, 0, products, stream);
+}
+extern "C" int hgn_linear_bwd6a(const float* g, int64_t ldg, int64_t M, const void* const* pk_blocks, int nb, float* dx,
+                                int64_t ld_dx, int accumulate, int products, void* stream) {
   if (!valid_products(products)) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: products must be 0 (default), 6, 3, 1 or 2");
   const int nb_ = bwd_products(products);
   if (M == 0) return HGN_OK;
   if (!g || !pk_blocks || !dx || M < 0 || nb < 1 || nb > 4 || (ldg & 3) || (ld_dx & 3) || !aligned16(g) || !aligned16(dx))
     return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: bad argument");
   Lin6Args a;
-  a.x = g; a.ldx = ldg; a.M = M; a.n_blocks = nb; a.out = dx; a.ld_out = ld_dx; a.zero = nullptr; a.ld_zero = 0;
+  a.x = g; a.ldx = ldg; a.M = M; a.n_blocks = nb; a.out = dx; a.ld_out = ld_dx; a.zero = nullptr; a.ld_zero = 0; a.accumulate = accumulate ? 1 : 0;
   for (int i = 0; i < 4; ++i) a.pk[i] = i < nb ? reinterpret_cast<const __bf16*>(pk_blocks[i]) : nullptr;
   for (int i = 0; i < nb; ++i)
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: null packed block");

@@ -589,15 +589,20 @@ template <int N> __device__ __forceinline__ void lat_wait_keep() {
 // A loader wave (l of NL): `next()` yields the packed blocks in the order the compute waves multiply them (nullptr = no more).
 // `extra_after` (optional): the compute waves run two barriers of their own right after the barrier that opens half
 // `extra_after` (mlp6_fwd_cs_kernel: between the LayerNorm epilogue and the post-projection blocks); the loader joins them.
+// `xbar` (column-split kernels in the scaled product mode 3: the four compute waves exchange the row maxima of a block's operand
+// through LDS and run one barrier of their own for it, right BEFORE the barrier that opens the block's first half): 0 never, 1 in
+// front of every block up to and including the one of half `extra_after` (the post blocks behind it share one operand), 2 in front
+// of the first block only; `extra_n`: barriers of the compute waves behind half `extra_after`.
 template <int NP, int NL, class Next>
-__device__ __forceinline__ void lat_loader(__bf16* __restrict__ lds, unsigned l, Next&& next, int extra_after = -1) {
+__device__ __forceinline__ void lat_loader(__bf16* __restrict__ lds, unsigned l, Next&& next, int extra_after = -1, int xbar = 0, int extra_n = 2) {
   static_assert(LatRing<NP>::PER % NL == 0, "whole tiles per loader wave");
   constexpr int MINE = LatRing<NP>::PER / NL;
   int j = 0, slot = 0;
   auto open = [&](int h, bool last) {               // half h has landed (a younger one may still fly); then its barrier
+    if ((h & 1) == 0 && (xbar == 1 || (xbar == 2 && h == 0)) && !(extra_after >= 0 && h >= extra_after)) __builtin_amdgcn_s_barrier();
     if (last) lat_wait_keep<0>(); else lat_wait_keep<MINE>();
     __builtin_amdgcn_s_barrier();
-    if (h == extra_after) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+    if (h == extra_after) for (int k = 0; k < extra_n; ++k) __builtin_amdgcn_s_barrier();
   };
   for (const __bf16* pk = next(); pk != nullptr; pk = next()) {
 #pragma unroll 1

@@ -113,6 +113,8 @@ _SIGS = {
     'hgn_mlp_bwd6_eligible': (C.c_int, [C.POINTER(MlpBwd)]),
     'hgn_linear_bwd6': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_int, C.c_void_p]),
+    'hgn_linear_bwd6a': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
+                                   C.c_int, C.c_int, C.c_void_p]),
     'hgn_mlp_bwd_ln_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     'hgn_mlp_bwd': (C.c_int, [C.POINTER(MlpBwd), C.c_void_p]),
     'hgn_edge_bwd_fused_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),

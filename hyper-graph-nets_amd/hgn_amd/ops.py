@@ -18,7 +18,7 @@ LAT = 128
 _GATE_LOG = None              # tests only: when a list, every training forward appends (first-layer weight ptr, ReLU sign words, row index)
 _ARG_LOG = None               # tests only: when a list, every training edge block with max / min aggregates appends (first-layer weight ptr, argmax, argmin, sorted position -> edge index)
 
-_PRODUCTS = {'fp32': 6, 'fp32-bf16x3': 6, 'fp32-f16x2': 3, 'bf16': 1, 'fp16': 2}
+_PRODUCTS = {'fp32': 3, 'fp32-f16x2': 3, 'fp32-bf16x3': 6, 'bf16': 1, 'fp16': 2}
 _ENV = __import__('os').environ
 # Process-wide DEFAULTS, resolved once here (the library itself reads no environment variable): what a Context that does not say
 # otherwise follows.  HGN_FP32_MFMA: the plain fp32-MFMA kernels everywhere; HGN_NO_FUSED_BWD: hgn_mlp_bwd + hgn_mlp_wgrad instead of
@@ -51,6 +51,9 @@ class Context:
         self.pack_in_capture = True       # graphs.GraphedForward keeps the pack launches out of its captured graph
         self.pack_recorder = None         # list that collects the (weights, form) pairs a forward pass packs
         self.pack_plan = None             # PackPlan of a trainer's step: every image the step uses, refreshed by ONE launch
+        # gradients of node latents shared between the consumers of ONE tensor inside one backward pass (MLPFn -> EdgeBlockFn):
+        # {data_ptr of the forward tensor: (engine run, gradient tensor)}; see share_grad / shared_grad
+        self.grad_share = {}
         self.plan_epoch = -1              # pack_epoch at which the plan last ran: packs_of then trusts its cache, also during a capture
         self._plan_rec = None
         self.ws_cache = {}
@@ -144,13 +147,16 @@ def set_fused_edge_backward(on) -> None:
 
 def set_matmul_precision(mode: str) -> None:
     """Process DEFAULT (contexts that set their own precision are not touched).
-    'fp32' (default): every 128x128 product as six split-bf16 MFMAs, fp32 accurate -- the mode all parity claims refer to.
+    'fp32' (default) = 'fp32-f16x2': every 128x128 product as THREE fp16 MFMAs on operands split into two fp16 terms and scaled by powers
+    of two (per row / per packed block / per 32-row block of a weight gradient) -- fp32 accurate, the mode all parity claims refer to.
+    'fp32-bf16x3': the same accuracy from six bf16 MFMAs on three bf16 terms per operand (no scales; twice the matrix work: the
+    default of rounds 1-4, kept as a cross-check).
     'bf16': ONE bf16 MFMA per product (operands rounded to bf16, fp32 accumulation; ~4e-3 relative error per product).
-    'fp16': the forward products as ONE fp16 MFMA (11 significant bits: ~5e-4 per product; activations behind a LayerNorm and
-    weights are far inside fp16's range), the backward / weight-gradient products as one bf16 MFMA (fp32 range: gradients need no
-    loss scaling) -- the "fp16 MFMA edge-MLP" of BASELINE.json configs[4].  Opt-in; also becomes the library's default for callers
-    of the C ABI that leave `products` at 0 (include/hgn_mp.h: hgn_set_matmul_products); packed weight images are rebuilt on
-    their next use."""
+    'fp16': the FORWARD products as ONE fp16 MFMA (11 significant bits: ~5e-4 per product; activations behind a LayerNorm and
+    weights are far inside fp16's range), the backward / weight-gradient products as in 'fp32' (scaled two-term fp16: exact derivatives
+    of the reduced-precision forward) -- the "fp16 MFMA edge-MLP" of BASELINE.json configs[4].  Opt-in; the mode also becomes the
+    library's default for callers of the C ABI that leave `products` at 0 (include/hgn_mp.h: hgn_set_matmul_products); packed
+    weight images are rebuilt on their next use."""
     global _defaults_epoch
     if mode not in _PRODUCTS:
         raise ValueError("matmul precision must be one of " + ', '.join(repr(k) for k in _PRODUCTS))
@@ -253,8 +259,8 @@ def storage_signature(pairs) -> tuple:
 def _pack_form(transposed: bool, c: Context) -> int:
     # forward-form images of the fp16 mode carry fp16 bit patterns in their leading third (hgn_pack_t.transposed | 2)
     # ... and those of the scaled two-term fp16 mode two fp16 terms + the block's scale exponent (hgn_pack_t.transposed | 4)
-    if transposed:
-        return 5 if c.products() == 3 else 1
+    if transposed:                                   # (mode 2 differentiates with mode 3's products: csrc/host.cpp bwd_products)
+        return 5 if c.products() in (2, 3) else 1
     return {2: 2, 3: 4}.get(c.products(), 0)
 
 
@@ -365,7 +371,8 @@ class PackPlan:
                     self.table.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8), non_blocking=False)
                     self.generation += 1
             else:
-                self.retired.append((self.table, self.bufs))     # (never dropped while a graph may still replay against them)
+                if self.table is not None:
+                    self.retired.append((self.table, self.bufs))     # (never dropped while a graph may still replay against them)
                 self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
                 self.generation += 1
             self.bufs, self.host = bufs, host
@@ -577,6 +584,33 @@ def _wtask(typ, A, lda, K, idxA, G, ldg, n_out, dW_ptr, ldw, db_ptr, acc=0):
 # ------------------------------------------------------------------------------------------------------------
 # generic fused MLP over concatenated sources
 # ------------------------------------------------------------------------------------------------------------
+_SHARE_GRADS = not bool(_ENV.get('HGN_NO_SHARED_DH'))
+
+
+def share_grad(c: Context, src: torch.Tensor, grad: torch.Tensor) -> None:
+    """A node latent h is read by the node update (MLPFn source) AND by the edge blocks (EdgeBlockFn: graphnet.py:25-26, 43-47); the
+    engine would add the two gradients with a pass of its own over [N, 128] (15 launches of 46 us per step of the headline
+    model).  The node update's backward runs first (it comes later in the forward): it leaves the gradient tensor it returns for
+    `src` here, keyed by the forward tensor's address and the engine run; an edge block that finds the entry for ITS h accumulates
+    into that tensor (hgn_linear_bwd6a) and returns no gradient of its own.  The engine holds the first gradient it is handed by
+    reference until every consumer has reported, so the tensor it passes on is the finished sum."""
+    if not _SHARE_GRADS:
+        return
+    gid = _graph_task_id()
+    if gid < 0:
+        return
+    if c.grad_share and next(iter(c.grad_share.values()))[0] != gid:
+        c.grad_share.clear()                          # entries of an earlier engine run (nobody came for them)
+    c.grad_share[src.data_ptr()] = (gid, grad, tuple(src.shape))
+
+
+def shared_grad(c: Context, src: torch.Tensor):
+    ent = c.grad_share.get(src.data_ptr()) if _SHARE_GRADS else None
+    if ent is None or ent[0] != _graph_task_id() or ent[2] != tuple(src.shape) or ent[1].shape != src.shape or not ent[1].is_contiguous():
+        return None
+    return ent[1]
+
+
 class MLPFn(torch.autograd.Function):
     """out = [src[residual] +] [LN](MLP(cat(src_0[idx_0], src_1[idx_1], ...)))   without materialising the cat."""
 
@@ -734,6 +768,8 @@ class MLPFn(torch.autograd.Function):
                 full = torch.zeros_like(srcs[i])
                 full.index_add_(0, idxs[i].long(), dxs[i])
                 dxs[i] = full
+            elif dxs[i] is not None and srcs[i].shape[1] == LAT and M > 0:
+                share_grad(c, srcs[i], dxs[i])
         return (None, *dxs, *grads_w)
 
 
@@ -1025,6 +1061,12 @@ class EdgeBlockFn(torch.autograd.Function):
         for slot, (need, n, b0, nb, gptr) in enumerate(((ctx.needs_input_grad[5], Ns, 0, 2 if same else 1, dPs),
                                                          (not same and ctx.needs_input_grad[6], Nr, 1, 1, dPr))):
             if not need:
+                continue
+            hsrc = h_s if slot == 0 else h_r
+            dh = shared_grad(c, hsrc) if (pk_t is not None and n > 0) else None
+            if dh is not None:                       # the node update's gradient for this very tensor: add into it, return nothing
+                pb = (C.c_void_p * 2)(*[pk_t.data_ptr() + (b0 + j) * _lib.PACK_BLOCK_BYTES for j in range(nb)], *([None] * (2 - nb)))
+                _lib.check(L.hgn_linear_bwd6a(gptr, ldd, n, pb, nb, dh.data_ptr(), LAT, 1, c.products(), st), 'hgn_linear_bwd6a')
                 continue
             dh = torch.empty(n, LAT, device=dev)
             if pk_t is not None:

@@ -193,8 +193,10 @@ int hgn_mlp_fwd(const hgn_mlp_fwd_t* args /*host*/, void* stream);
 typedef struct {
   const float* W; int64_t ldw;     /* block origin (&W[o0][i0]) and leading dimension                       */
   int32_t n_out; int32_t n_in;     /* valid extents of the block (<= 128 each; the rest is zero padded)     */
-  int32_t transposed;              /* 0: contraction over i (forward products), 1: over o (data gradients);
-                                    * 2: forward form with fp16 bit patterns in the leading third (products mode 2)    */
+  int32_t transposed;              /* bit 0: 0 contraction over i (forward products), 1 over o (data gradients);
+                                    * | 2: ONE fp16 term in the leading third (forward form of products mode 2);
+                                    * | 4: TWO fp16 terms of W * 2^sw in the first two thirds + the exponent sw (int32) at byte
+                                    *      32768 of the image (products mode 3; mode 2's backward)                          */
   void* out;                       /* HGN_PACK_BLOCK_BYTES, 16-byte aligned                                 */
 } hgn_pack_t;
 int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* stream);   /* one launch for up to HGN_MAX_PACK blocks */
@@ -203,19 +205,23 @@ int hgn_pack_bf16x3(const hgn_pack_t* blocks /*host*/, int n_blocks, void* strea
  * that lives in device memory -- `blocks_dev` holds the same n_blocks descriptors as `blocks` (which is only validated here), written
  * once by the caller; capturable (no host data is read at replay).  n_blocks <= 65535. */
 int hgn_pack_bf16x3_table(const hgn_pack_t* blocks /*host copy*/, const hgn_pack_t* blocks_dev /*device*/, int n_blocks, void* stream);
-/* DEFAULT precision of the split-bf16 kernels: what a call with `products` = 0 gets.  6 (default): the six products above, fp32 accurate -- the mode every
- * parity claim of this library refers to.  1: ONE bf16 MFMA per product (both operands rounded to bf16, fp32 accumulation,
- * relative error ~4e-3 per product; a third of the weight traffic, a sixth of the MFMAs).  2: the FORWARD products as ONE fp16
- * MFMA (v_mfma_f32_16x16x32_f16: 11 significant bits, ~5e-4 per product; the forward-form packs must then be built with
- * hgn_pack_t.transposed = 2), the backward / weight-gradient products as one bf16 MFMA (fp32 exponent range: no loss scaling)
- * -- the "fp16 MFMA edge-MLP" of BASELINE.json configs[4].  1 and 2 are opt-in, never a default, outside the 1e-5 parity
- * tolerance. */
-int hgn_set_matmul_products(int n /* 6, 1 or 2 */);
+/* DEFAULT product mode of the split-product kernels: what a call with `products` = 0 gets.
+ *   3 (default): each fp32 operand as TWO fp16 terms (hi = rne(x), lo = rne(x - hi): the fp32 value to 2^-24), three
+ *      v_mfma_f32_16x16x32_f16 per product (hi*hi + hi*lo + lo*hi, fp32 accumulation).  fp16 has 5 exponent bits, so every operand is
+ *      scaled by a power of two first (exact): weights per packed block at pack time (hgn_pack_t.transposed | 4: the exponent is
+ *      stored in the image), rows of activations / gradients per row at split time, the operands of a weight gradient per 32-row
+ *      block; accumulators are scaled back.  fp32 accurate -- the mode every parity claim of this library refers to.
+ *   6: three bf16 terms per operand, six bf16 MFMAs per product; the same accuracy without scales at twice the matrix work.
+ *   1: ONE bf16 MFMA per product (both operands rounded to bf16; relative error ~4e-3 per product).
+ *   2: the FORWARD products as ONE fp16 MFMA (~5e-4 per product; forward-form packs built with hgn_pack_t.transposed = 2), the
+ *      backward / weight-gradient products as in mode 3 (transposed packs with transposed = 1 | 4) -- the "fp16 MFMA edge-MLP" of
+ *      BASELINE.json configs[4].  1 and 2 are opt-in, never a default, outside the 1e-5 parity tolerance. */
+int hgn_set_matmul_products(int n /* 3, 6, 1 or 2 */);
 int hgn_get_matmul_products(void);
 int hgn_mlp_fwd6_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd will take the split-bf16 kernel */
 int hgn_mlp_fwd_post_eligible(const hgn_mlp_fwd_t* args /*host*/);   /* 1 if hgn_mlp_fwd accepts these args WITH their post_* fields */
 int hgn_linear_fwd6(const float* x, int64_t ldx, int64_t M, const void* const* packed_blocks /*host array*/, int n_blocks,
-                    float* out, int64_t ld_out, int products /*0 = process default, or 6 / 1 / 2*/, void* stream);
+                    float* out, int64_t ld_out, int products /*0 = process default, or 3 / 6 / 1 / 2*/, void* stream);
 /* The same launch, which also sets zero_rows[i][0..128) = 0 for i < M (nullable; leading dimension ld_zero >= 128, a multiple of
  * 4; 16-byte aligned): an edge block needs its node-level pre-projection AND a zero-filled aggregate buffer over the same node
  * rows (hgn_mlp_fwd_t.seg_out) -- one pass over the rows instead of a launch of its own for the fill. */
@@ -259,7 +265,7 @@ typedef struct {
   /* optional, split-bf16 kernel only: seg_dz1[seg_ids[i]][0..128) += dz1[i]  (same contract as hgn_mlp_fwd_t.seg_out): the
    * receiver half of the pre-projection gradient of the split edge layer, without re-reading dz1 */
   float* seg_dz1; int64_t ld_seg_dz1; const int32_t* seg_ids;
-  int32_t products; int32_t flags;          /* per-call options, as in hgn_mlp_fwd_t (backward products: 6, or 1 in both reduced modes) */
+  int32_t products; int32_t flags;          /* per-call options, as in hgn_mlp_fwd_t (backward products: those of the forward; mode 2 differentiates with mode 3's) */
 } hgn_mlp_bwd_t;
 
 int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes /*host*/);
@@ -267,6 +273,11 @@ int hgn_mlp_bwd(const hgn_mlp_bwd_t* args /*host*/, void* stream);
 int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* args /*host*/);   /* 1 if hgn_mlp_bwd will take the split-bf16 kernel */
 int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* packed_blocks_t /*host array, transposed form*/,
                     int n_blocks, float* dx, int64_t ld_dx, int products, void* stream);
+/* The same with an ACCUMULATE target: dx (+)= g W.  A node latent h feeds the edge block (graphnet.py:25-26, through this
+ * product) and the node update (graphnet.py:43-47): autograd sums the two gradients with a pass of its own over [N, 128]; with
+ * accumulate != 0 this launch starts its accumulators from the gradient the node update already wrote instead. */
+int hgn_linear_bwd6a(const float* g, int64_t ldg, int64_t M, const void* const* packed_blocks_t /*host array, transposed form*/,
+                     int n_blocks, float* dx, int64_t ld_dx, int accumulate, int products, void* stream);
 
 /* Edge-block backward with the weight gradients of the two inner layers in the SAME pass (csrc/fused_bwd.hip): autograd of
  * GraphNet._update_edge_features (graphnet.py:22-32) for one edge set -- everything hgn_mlp_bwd computes for an edge block

@@ -741,11 +741,20 @@ def test_flag_L15_sum_vs_oracle_fp64():
                       'seeds_rejected': wseed - 3, 'criterion': 'smallest |ReLU input| of the fp64 oracle run > 3e-7',
                       'margin_of_seed_used': km.worst})
     model = H.hip_model('none', 'sum', 15, ['mesh_edges'], sd)
-    out, loss, grads, _ = H.hip_run(model, graph, target, mask)
+    out, loss, grads, _, gates, winners = H.hip_run_logged(model, graph, target, mask)
     assert H.rel_err(out, out_o) <= TOL_OUT
     assert H.rel_err(loss, loss_o) <= TOL_OUT
     worst = max((H.rel_err(grads[k], grads_o[k]), k) for k in grads_o)
-    assert worst[0] <= 5e-5, worst
+    # The arithmetic: against the fp64 oracle run with the HIP forward's ReLU gates (tests/helpers.py: GateTransfer) every gradient
+    # tensor agrees to 1e-5.  Without the transfer the bound is 5e-5 -- unless a gate of this instance sits within fp32 rounding of
+    # its kink after all (the seed search above looks at the fp64 run's margin, 3e-7; a forward that is 3e-7 off at layer 10 can still
+    # draw one): then at most three gates may differ, each at |pre-activation| <= 1e-6, and the transferred figure is the statement.
+    _, _, grads_g, gt, _ = H.oracle_run_with_hip_decisions(sd, graph, 'none', 'sum', target, mask, gates, winners)
+    gn, _ = H.worst_grad(grads, grads_g)
+    H._REPORT.append({'test': 'test_flag_L15_sum_vs_oracle_fp64', 'what': 'param grads (worst tensor)', 'norm': worst[0], 'tensor': worst[1],
+                      'norm_with_hip_gates': gn, 'gates_differing_from_fp64': gt.flipped, 'max_abs_preactivation_at_flip': gt.max_abs_at_flip})
+    assert gn <= 1e-5, gn
+    assert worst[0] <= 5e-5 or (0 < gt.flipped <= 3 and gt.max_abs_at_flip <= 1e-6), (worst, gt.flipped, gt.max_abs_at_flip)
 
 
 @pytest.mark.parametrize('agg', ['sum', 'pna'])
@@ -908,11 +917,12 @@ def test_one_launch_pack_table_equals_per_mlp_packs(monkeypatch):
     tr1.ctx.pack_recorder = None
     have = {(w.w1.data_ptr(), tr) for w, tr in plan.items}
     assert rec and all((w.w1.data_ptr(), bool(tr)) in have for w, tr in rec)
-    table = plan.table
-    tr1.ctx.set_matmul_precision('bf16')                       # other images (forward form of the fp16 mode aside): same table layout,
-    tr1.ctx.set_matmul_precision('fp16')                       # but the descriptors' form flags change -> rebuilt
-    ops.begin_step_packs(tr1.ctx)
-    assert plan.table is not table
+    table, ptr, gen = plan.table, plan.table.data_ptr(), plan.generation
+    before = bytes(plan.table.cpu().numpy().tobytes())
+    tr1.ctx.set_matmul_precision('bf16')                       # other images: same table layout, but the descriptors' form flags change ->
+    ops.begin_step_packs(tr1.ctx)                              # rewritten IN PLACE (a captured step has the table's address baked in)
+    assert plan.table is table and plan.table.data_ptr() == ptr and plan.generation == gen + 1
+    assert bytes(plan.table.cpu().numpy().tobytes()) != before
 
 
 def test_trainer_flat_gradients_and_adam_match_torch():
@@ -1425,9 +1435,12 @@ def test_config4_shape_cylinder_hyper_L25_balance_vs_oracle(steps):
     rb = H.report(tid, 'output (reduced precision: one bf16 product)', out_b, out_o)
     assert rb['norm'] <= (2e-2 if steps == 1 else 5e-2), rb
     assert H.rel_err(loss_b, loss_o) <= 5e-2
-    # fp16 forward products (what configs[4] names), bf16 backward products: 11 significant bits per forward operand instead
-    # of 8 -> the outputs are ~8x closer to the fp64 result than in the bf16 mode (bound: a quarter of the bf16 bound, and
-    # better than the bf16 run of the same inputs); gradients flow through bf16 products and keep the bf16 tolerance.
+    # fp16 forward products (what configs[4] names): 11 significant bits per forward operand instead of 8 -> the outputs are ~8x
+    # closer to the fp64 result than in the bf16 mode (bound: a quarter of the bf16 bound, and better than the bf16 run of the same
+    # inputs).  The BACKWARD of this mode runs the two-term fp16 products of mode 3 on per-row / per-block scaled operands
+    # (csrc/host.cpp: bwd_products): the gradients are the exact derivatives of the reduced-precision forward up to fp32 rounding, so
+    # their distance from the fp64 gradients is the forward's rounding carried through the chain rule -- STATED TOLERANCE of the
+    # mode: worst parameter-gradient tensor <= 2e-2 at one layer, <= 5e-2 at 25 layers (norm-wise, tensor by tensor).
     hgn_amd.set_matmul_precision('fp16')
     try:
         assert hgn_amd.get_matmul_precision() == 'fp16'
@@ -1439,8 +1452,8 @@ def test_config4_shape_cylinder_hyper_L25_balance_vs_oracle(steps):
     assert rh['norm'] < rb['norm'], (rh, rb)
     assert H.rel_err(loss_h, loss_o) <= 2e-2
     wh, _ = H.worst_grad(grads_h, grads_o)
-    H._REPORT.append({'test': tid, 'what': 'param grads (worst tensor), fp16 forward / bf16 backward', 'norm': wh})
-    assert wh < 1.0, wh                                     # (bf16 products in the backward: measured in the report, no bound claimed)
+    H._REPORT.append({'test': tid, 'what': 'param grads (worst tensor), fp16 forward / two-term fp16 backward', 'norm': wh})
+    assert wh <= (2e-2 if steps == 1 else 5e-2), wh
     out_again, _, _, _ = H.hip_run(model, graph, target, mask)
     assert torch.equal(out_again, out)                     # switching back restores the fp32-accurate results bit for bit
 

@@ -66,12 +66,12 @@ def test_abi_argument_validation_without_gpu():
     assert lib.hgn_node_features(None, None, 3, 3, None, 1, None, 0, 40, 1, -1, 5, None, 43, None) == -1
     assert lib.hgn_normalize(None, 5, 0, None, None, None, 1e-8, 0, None, None) == -1
     assert lib.hgn_lincomb3(None, 1.0, None, 1.0, None, 0.0, 5, None, None) == -1
-    # precision switch: 6 (default) / 3 (fp32-accurate: three bf16 / two scaled fp16 terms), 1 (bf16), 2 (fp16 forward / bf16 backward);
+    # precision switch: 3 (default) / 6 (fp32-accurate: two scaled fp16 / three bf16 terms), 1 (bf16), 2 (fp16 forward, mode-3 backward);
     # anything else is refused and changes nothing
-    assert lib.hgn_get_matmul_products() == 6
-    for n in (1, 2, 3, 6):
+    assert lib.hgn_get_matmul_products() == 3
+    for n in (1, 2, 6, 3):
         assert lib.hgn_set_matmul_products(n) == 0 and lib.hgn_get_matmul_products() == n
-    assert lib.hgn_set_matmul_products(4) == -1 and lib.hgn_get_matmul_products() == 6
+    assert lib.hgn_set_matmul_products(4) == -1 and lib.hgn_get_matmul_products() == 3
     # the shipped library carries no laboratory variants (tools/lab/): their switches are not exported
     raw = C.CDLL(_lib.LIB_PATH)
     assert not any(hasattr(raw, n) for n in ('hgn_set_ws_fwd', 'hgn_set_big_tiles', 'hgn_mlp_fwd_ws_eligible'))
@@ -600,7 +600,7 @@ def test_two_contexts_with_different_precisions_from_two_threads_through_the_abi
     import threading
     from hgn_amd import _lib, ops
     lib = _lib.lib()
-    assert lib.hgn_get_matmul_products() == 6
+    assert lib.hgn_get_matmul_products() == 3
     results, errors = {}, []
 
     def drive(name, ctx, want_products, n=300):
@@ -638,14 +638,14 @@ def test_two_contexts_with_different_precisions_from_two_threads_through_the_abi
         t.join()
     assert not errors, errors
     assert results == {'a': (300, 2), 'b': (300, 1)}
-    assert ops.current() is ops.default_context() and ops.default_context().products() == 6 and lib.hgn_get_matmul_products() == 6
+    assert ops.current() is ops.default_context() and ops.default_context().products() == 3 and lib.hgn_get_matmul_products() == 3
     assert b_ctx.flags() == _lib.F_GENERAL_FWD and a_ctx.flags() == ops.default_context().flags()
     import hgn_amd
     m1 = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges'])
     m2 = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges'])
     assert m1._hgn_ctx is not m2._hgn_ctx and m1._hgn_ctx.wq is not m2._hgn_ctx.wq
     m2.set_matmul_precision('bf16')
-    assert (m1._hgn_ctx.products(), m2._hgn_ctx.products()) == (6, 1)
+    assert (m1._hgn_ctx.products(), m2._hgn_ctx.products()) == (3, 1)
 
 
 def test_topology_parts_of_a_hierarchical_graph():
