@@ -17,7 +17,7 @@ PACK_BLOCK_BYTES = 98304
 HGN_MAX_PACK = 32
 NUM_KERNEL_IDS = 15
 OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
-F_FP32_MFMA, F_GENERAL_FWD = 1, 2          # hgn_mlp_fwd_t.flags / hgn_mlp_bwd_t.flags / hgn_wtask_t.flags
+F_FP32_MFMA, F_GENERAL_FWD, F_TILE64_FWD = 1, 2, 4          # hgn_mlp_fwd_t.flags / hgn_mlp_bwd_t.flags / hgn_wtask_t.flags
 KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
                 'linear_bwd', 'adam', 'csr', 'wgrad_node', 'seg_fwd_agg', 'features', 'edge_bwd_fused']
 

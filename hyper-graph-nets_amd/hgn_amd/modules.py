@@ -81,10 +81,10 @@ def weights_of(module: nn.Module, in_features: int) -> ops.MLPWeights:
     return w
 
 
-def fused_apply(module: nn.Module, srcs: Sequence[Tensor], idxs=None, residual: int = -1, post=None, cols=None, width=None):
+def fused_apply(module: nn.Module, srcs: Sequence[Tensor], idxs=None, residual: int = -1, post=None, cols=None, width=None, share=False):
     """`cols` / `width`: first input column of every source and the full input width, when column ranges are left out (ops.fused_mlp)."""
     width = sum(s.shape[1] for s in srcs) if width is None else width
-    return ops.fused_mlp(srcs, weights_of(module, width), idxs, residual, post, cols)
+    return ops.fused_mlp(srcs, weights_of(module, width), idxs, residual, post, cols, share)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -231,7 +231,10 @@ class GraphNet(nn.Module):
                 srcs.append(a.t)
                 cols.append(col)
             col += a.t.shape[1]
-        lat.nodes[which] = fused_apply(model, srcs, residual=0, cols=cols if len(srcs) <= len(aggs) else None, width=col)
+        # (one node part: its latents are read by this update and by the block's edge blocks -- our own autograd nodes -- only: the
+        #  update's gradient tensor doubles as their accumulation target, ops.share_grad)
+        lat.nodes[which] = fused_apply(model, srcs, residual=0, cols=cols if len(srcs) <= len(aggs) else None, width=col,
+                                       share=len(lat.nodes) == 1 and type(self) in (GraphNet, MultiGraphNet, RepeatedGraphNet))
 
     # -- GraphNet.forward (graphnet.py:72-84) --------------------------------------------------------------------
     def _forward_latent(self, lat: _Latent, nxt: Optional['GraphNet'] = None) -> _Latent:

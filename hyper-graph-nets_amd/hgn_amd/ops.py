@@ -69,7 +69,7 @@ class Context:
     def flags(self) -> int:
         f32 = self.fp32_mfma if self.fp32_mfma is not None else _DEFAULTS['fp32_mfma']
         gen = self.general_fwd if self.general_fwd is not None else _DEFAULTS['general_fwd']
-        return (_lib.F_FP32_MFMA if f32 else 0) | (_lib.F_GENERAL_FWD if gen else 0)
+        return (_lib.F_FP32_MFMA if f32 else 0) | (_lib.F_GENERAL_FWD if gen else 0) | (_lib.F_TILE64_FWD if _ENV.get('HGN_TILE64_FWD') else 0)
 
     def fp32_only(self) -> bool:
         return bool(self.flags() & _lib.F_FP32_MFMA)
@@ -587,28 +587,46 @@ def _wtask(typ, A, lda, K, idxA, G, ldg, n_out, dW_ptr, ldw, db_ptr, acc=0):
 _SHARE_GRADS = not bool(_ENV.get('HGN_NO_SHARED_DH'))
 
 
+def _share_table(c: Context):
+    """The table of the CURRENT engine run (entries of an earlier run belong to nobody)."""
+    gid = _graph_task_id()
+    if gid < 0 or not _SHARE_GRADS:
+        return None
+    if c.grad_share.get('run') != gid:
+        c.grad_share.clear()
+        c.grad_share['run'] = gid
+    return c.grad_share
+
+
 def share_grad(c: Context, src: torch.Tensor, grad: torch.Tensor) -> None:
     """A node latent h is read by the node update (MLPFn source) AND by the edge blocks (EdgeBlockFn: graphnet.py:25-26, 43-47); the
     engine would add the two gradients with a pass of its own over [N, 128] (15 launches of 46 us per step of the headline
     model).  The node update's backward runs first (it comes later in the forward): it leaves the gradient tensor it returns for
-    `src` here, keyed by the forward tensor's address and the engine run; an edge block that finds the entry for ITS h accumulates
-    into that tensor (hgn_linear_bwd6a) and returns no gradient of its own.  The engine holds the first gradient it is handed by
-    reference until every consumer has reported, so the tensor it passes on is the finished sum."""
-    if not _SHARE_GRADS:
+    `src` here, keyed by the forward tensor's address; an edge block that finds the entry for ITS h accumulates into that tensor
+    (hgn_linear_bwd6a) and returns no gradient of its own.  The engine holds the FIRST gradient it is handed for a tensor by
+    reference until every consumer has reported, so what it passes on is the finished sum -- as long as nobody hands it a second
+    tensor for the same h: it would then add the two into a buffer of its own and the shared tensor would be a dead copy.  Hence:
+    an entry is made only by the first of our functions to report for a tensor, and whoever returns a gradient tensor of its own
+    for a tensor closes its entry for the rest of the run (`unshare_grad`)."""
+    t = _share_table(c)
+    if t is None:
         return
-    gid = _graph_task_id()
-    if gid < 0:
-        return
-    if c.grad_share and next(iter(c.grad_share.values()))[0] != gid:
-        c.grad_share.clear()                          # entries of an earlier engine run (nobody came for them)
-    c.grad_share[src.data_ptr()] = (gid, grad, tuple(src.shape))
+    k = src.data_ptr()
+    t[k] = None if k in t else (grad, tuple(src.shape))      # a second reporter: the engine adds -- nothing to share any more
+
+
+def unshare_grad(c: Context, src: torch.Tensor) -> None:
+    t = _share_table(c)
+    if t is not None:
+        t[src.data_ptr()] = None
 
 
 def shared_grad(c: Context, src: torch.Tensor):
-    ent = c.grad_share.get(src.data_ptr()) if _SHARE_GRADS else None
-    if ent is None or ent[0] != _graph_task_id() or ent[2] != tuple(src.shape) or ent[1].shape != src.shape or not ent[1].is_contiguous():
+    t = _share_table(c)
+    ent = t.get(src.data_ptr()) if t is not None else None
+    if ent is None or ent[1] != tuple(src.shape) or ent[0].shape != src.shape or not ent[0].is_contiguous():
         return None
-    return ent[1]
+    return ent[0]
 
 
 class MLPFn(torch.autograd.Function):
@@ -619,6 +637,7 @@ class MLPFn(torch.autograd.Function):
         n_src, idxs, residual, has_ln, train = meta[:5]
         post = meta[5] if len(meta) > 5 else None          # (packed next-block weights, zero-fill wanted): inference only, see fused_mlp
         given = meta[6] if len(meta) > 6 else None         # first W1 column of every source (fused_mlp: cols), or None: back to back
+        share = bool(meta[7]) if len(meta) > 7 else False   # the caller vouches for the consumers of source 0 (share_grad)
         c = current()
         srcs = [_rowmajor(t) for t in tensors[:n_src]]
         wt = tensors[n_src:]
@@ -684,6 +703,7 @@ class MLPFn(torch.autograd.Function):
         if train:
             ctx.meta = (n_src, idxs, residual, has_ln, cols, M)
             ctx.gaps = sum(s.shape[1] for s in srcs) != w.w1.shape[1]      # W1 columns no source feeds: their gradient is zero
+            ctx.share = share
             ctx.saves = saves
             ctx.targets = _grad_targets(wt)
             ctx.pk_t = packs_of(w, transposed=True, ctx=c) if pk is not None else None
@@ -768,25 +788,29 @@ class MLPFn(torch.autograd.Function):
                 full = torch.zeros_like(srcs[i])
                 full.index_add_(0, idxs[i].long(), dxs[i])
                 dxs[i] = full
-            elif dxs[i] is not None and srcs[i].shape[1] == LAT and M > 0:
+            elif dxs[i] is not None and i == 0 and ctx.share and srcs[i].shape[1] == LAT and M > 0:
                 share_grad(c, srcs[i], dxs[i])
+            elif dxs[i] is not None:
+                unshare_grad(c, srcs[i])
         return (None, *dxs, *grads_w)
 
 
 def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequence[Optional[torch.Tensor]]] = None,
-              residual: int = -1, post=None, cols: Optional[Sequence[int]] = None):
+              residual: int = -1, post=None, cols: Optional[Sequence[int]] = None, share: bool = False):
     """`cols`: first W1 column of every source when the sources do NOT cover the input back to back -- column ranges left out stand for
     inputs that are zero for every row of this launch (an aggregate over edges none of which arrive at these rows): no operand, no
     product, a zero weight gradient.
     `post` (inference only): (packs_of(weights of the NEXT edge block), zero-fill wanted) -- when the launch is small enough for
     the column-split form the node-level pre-projection of that block (its P = [h W1s^T | h W1r^T]) and the zero fill of its
-    aggregate buffer come out of the same launch: -> (out, (P, zeros) or None)."""
+    aggregate buffer come out of the same launch: -> (out, (P, zeros) or None).
+    `share`: the caller vouches that source 0 (a node latent) is otherwise consumed by EdgeBlockFn nodes only: its gradient tensor is
+    offered to them as their accumulation target (share_grad)."""
     idxs = tuple(idxs) if idxs is not None else (None,) * len(srcs)
     wt = w.tensors()
     train = torch.is_grad_enabled() and any(t.requires_grad for t in list(srcs) + wt)
     cols = tuple(int(x) for x in cols) if cols is not None else None
     if post is None or train:
-        out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, None, cols), *srcs, *wt)
+        out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, None, cols, share), *srcs, *wt)
         return out if post is None else (out, None)
     c = current()
     c.post_result = None
@@ -1068,6 +1092,7 @@ class EdgeBlockFn(torch.autograd.Function):
                 pb = (C.c_void_p * 2)(*[pk_t.data_ptr() + (b0 + j) * _lib.PACK_BLOCK_BYTES for j in range(nb)], *([None] * (2 - nb)))
                 _lib.check(L.hgn_linear_bwd6a(gptr, ldd, n, pb, nb, dh.data_ptr(), LAT, 1, c.products(), st), 'hgn_linear_bwd6a')
                 continue
+            unshare_grad(c, hsrc)                    # a gradient tensor of our own for this h: the engine will add
             dh = torch.empty(n, LAT, device=dev)
             if pk_t is not None:
                 pb = (C.c_void_p * 2)(*[pk_t.data_ptr() + (b0 + j) * _lib.PACK_BLOCK_BYTES for j in range(nb)], *([None] * (2 - nb)))

@@ -39,6 +39,7 @@ extern "C" {
 #define HGN_OP_MIN 3
 #define HGN_F_FP32_MFMA 1
 #define HGN_F_GENERAL_FWD 2
+#define HGN_F_TILE64_FWD 4   /* A/B switch: 64-row forward tiles (three workgroups per CU) also for launches that would take 128-row tiles */
 
 #define HGN_MAX_SRC 8
 #define HGN_MAX_ADD 2

@@ -134,3 +134,26 @@ def test_bench_gpus_2_starts_two_ranks():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['config']['parallelism'] == 'dp2' and res['config']['ranks'] == 2
     assert res['config']['global_batch'] == 8 and res['value'] > 0
+
+
+@pytest.mark.parametrize('global_batch,per_rank', [(2, 1), (8, 4)])
+def test_bench_gpus_2_strong_scaling_global_batch(global_batch, per_rank):
+    """BASELINE.json configs[3] on two ranks: `bench.py --gpus 2 --global-batch B` splits a FIXED global batch over the ranks (one graph
+    ... four graphs per rank; `scaling: strong`), the line reports the world size torch.distributed saw in its `collective` object, the
+    flat gradient that was all-reduced (9.33 MB at 15 layers: SURVEY section 8e; here 3 layers) and whole-job edges/s.  gloo, because
+    this box has one GPU; the driver's 8-GPU node runs the same code over RCCL."""
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '3', '--warmup', '1',
+                        '--global-batch', str(global_batch), '--layers', '3', '--no-prof', '--no-cpu-baseline', '--no-cold', '--no-secondary'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['scaling'] == 'strong' and res['config']['parallelism'] == 'dp2'
+    assert res['config']['global_batch'] == global_batch and res['config']['graphs_per_gpu'] == per_rank
+    col = res['collective']
+    assert col['ranks_reported_by_torch_distributed'] == 2 and col['backend'] == 'gloo'
+    assert col['flat_gradient_bytes'] > 4 * 500_000 and sum(col['bucket_bytes']) == col['flat_gradient_bytes']
+    assert res['value'] > 0 and abs(res['value'] - res['config']['edges_per_step'] / (res['ms_per_step'] * 1e-3)) <= 1e-6 * res['value']

@@ -24,9 +24,9 @@ out = {'commit': sys.argv[5] if len(sys.argv) > 5 else None, 'kernel_source_sha'
        'counters': 'FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64 bytes) + WRITE_SIZE, KiB, mean over the launches of '
                    'that (kernel, grid) in `bench.py --steps 2 --warmup 1`'}
 per_step = 0.0
-fused_present = any('edge_bwd_fused_kernel' in kk[0] for kk in fetch)
+fused_present = any('edge_bwd_fused' in kk[0] for kk in fetch)
 for bench_name, kern in (('mlp_fwd_edge', 'mlp6_fwd_kernel'), ('mlp_bwd_edge', 'mlp6_bwd_kernel'), ('wgrad', 'wgrad6s_kernel'),
-                         ('edge_bwd_fused', 'edge_bwd_fused_kernel'), ('seg_fwd', 'seg_fwd128_kernel'), ('seg_pair', 'seg_sum_pair128_kernel')):
+                         ('edge_bwd_fused', 'edge_bwd_fused'), ('seg_fwd', 'seg_fwd128_kernel'), ('seg_pair', 'seg_sum_pair128_kernel')):
     if bench_name == 'mlp_bwd_edge' and fused_present:
         continue                                              # only the encoder's backward is left on that kernel at the edge grid
     keys = [k for k in fetch if kern in k[0]]

@@ -15,15 +15,15 @@ done
 {
   echo "# rocprofv3 --kernel-trace --pmc <set> -- python3 tools/fusedbench.py --iters 3   (four separate passes, one counter set each; tools/sq_counters.py)"
   echo "# 128 flag_simple-shape graphs, 1 188 096 edge rows; per launch.  SQ_WAVE_CYCLES and the SQ_WAIT_* / SQ_ACTIVE_* counters tick once per 4 cycles per wave;"
-  echo "# SQ_VALU_MFMA_BUSY_CYCLES is in cycles summed over the 1 024 SIMDs: = SQ_INSTS_MFMA x 16;  SQ_INSTS_VALU INCLUDES the MFMA instructions"
-  for j in 1 2 3 4; do python tools/sq_counters.py $O/sq$j | grep -A6 "edge_bwd_fused_kernel<6>\|mlp6_fwd_edge_kernel<6>"; done
+  echo "# SQ_VALU_MFMA_BUSY_CYCLES is in cycles summed over the 1 024 SIMDs: = SQ_INSTS_MFMA x 16 (v_mfma_f32_16x16x32_f16 / _bf16);  SQ_INSTS_VALU INCLUDES the MFMA instructions"
+  for j in 1 2 3 4; do python tools/sq_counters.py $O/sq$j | grep -A6 "edge_bwd_fused3_kernel\|edge_bwd_fused_kernel<6>\|mlp6_fwd_edge_kernel<"; done
 } > $O/sq_counters.txt
 python - "$O" "$COMMIT" <<'PY'
 import csv, glob, json, os, sys, collections
 O, commit = sys.argv[1], sys.argv[2]
 sys.path.insert(0, os.getcwd())
 import bench
-names = {'edge_bwd_fused_kernel<6>': 'edge_bwd_fused', 'mlp6_fwd_edge_kernel<6>': 'mlp_fwd_edge'}
+names = {'edge_bwd_fused3_kernel': 'edge_bwd_fused', 'edge_bwd_fused_kernel<6>': 'edge_bwd_fused', 'mlp6_fwd_edge_kernel<': 'mlp_fwd_edge'}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(O + '/sq*/**/*counter_collection.csv', recursive=True):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
