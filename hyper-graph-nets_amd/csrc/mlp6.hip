@@ -690,15 +690,41 @@ __global__ __launch_bounds__(LATF ? 64 * (4 + LAT_LOADERS) : WG, LATF ? 1 : 3) v
 // backward (data gradients): same contract as mlp_bwd_kernel; weights come as TRANSPOSED-form packs.  Eligibility
 // guarantees LayerNorm, its workspace and the ReLU sign words: straight-line code without optional parts.
 // ----------------------------------------------------------------------------------------------------------
-template <int NS, int NP, bool PARK>
-__global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) {
-  __shared__ __attribute__((aligned(16))) float ldsf[HALF_BF16 / 2 + (WG / 64) * 256];
+// NWV = 4 + LAT_LOADERS ("latency form", launches of at most one 64-row tile per CU -- the node update's backward of a one-graph
+// step is 25 tiles): four compute waves + loader waves that stream the packed transposed blocks through a ring of three 48 KB
+// slots in the order the chain multiplies them (mlp6_device.h: lat_loader / gemm6_lat), as in the forward's latency form: a
+// workgroup that has its CU to itself otherwise waits ~2 us for each of its ten weight halves.  Same arithmetic, bit for bit.
+template <int NS, int NP, bool PARK, int NWV = WG / 64>
+__global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) void mlp6_bwd_kernel(const hgn_mlp_bwd_t a) {
+  constexpr bool LATF = NWV != WG / 64;
+  static_assert(!LATF || (NS == 1 && !PARK), "latency form: one 16-row sub-tile per compute wave");
+  __shared__ __attribute__((aligned(16))) float ldsf[(LATF ? 3 * HALF_BF16 : HALF_BF16) / 2 + (WG / 64) * 256];
   static_assert(HALF_BF16 / 2 >= SEG_LDS_FLOATS, "the weight stage doubles as the segment-sum tile");
   __bf16* lds = reinterpret_cast<__bf16*>(ldsf);
-  float* lnl = ldsf + HALF_BF16 / 2;
+  float* lnl = ldsf + (LATF ? 3 * HALF_BF16 : HALF_BF16) / 2;
+  if constexpr (LATF) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {       // a loader wave: the blocks in the order of the code below
+      int stage = 0, di = 0, k0 = 0;
+      lat_loader<NP, NWV - 4>(lds, (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - 4u, [&]() -> const __bf16* {
+        if (stage == 0) { ++stage; return reinterpret_cast<const __bf16*>(a.W3pk_t); }
+        if (stage == 1) { ++stage; return reinterpret_cast<const __bf16*>(a.W2pk_t); }
+        if (di >= a.n_dx) return nullptr;
+        const __bf16* p = reinterpret_cast<const __bf16*>(a.dx[di].Wpk_t) + (long)(k0 >> 7) * BLOCK_BF16;
+        k0 += 128;
+        if (k0 >= a.dx[di].K) { ++di; k0 = 0; }
+        return p;
+      });
+      return;
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
-  const Rows<NS> R(a.M);
+  const Rows<NS, WG / 64> R(a.M);
+  int ring_slot = 0;
+  auto block = [&](Act (&acc_)[NS], Act (&b_)[NS], const __bf16* pk_, auto&& between_) {
+    if constexpr (LATF) gemm6_lat<NP>(acc_, b_, lds, ring_slot, pk_, between_, [](Act (&)[NS]) {});
+    else gemm6<NS, NP>(acc_, b_, lds, pk_, between_);
+  };
 
   Act g[NS], t[NS];
   // PARK (several aggregation ops, i.e. pna: d_out_eff costs ~3.5 KB of gathered reads per row -- four d(agg) slots, two
@@ -715,7 +741,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
 #pragma unroll
   for (int u = 0; u < NS; ++u) pre_seg[u] = a.agg_dout ? a.agg_seg[R.rc[u]] : -1;
   // ---- dz3 (LayerNorm backward, computed while the first half of W3 is in flight), dz2 = relu'(z2) * (W3^T dz3) -------
-  gemm6<NS, NP>(t, g, lds, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
+  block(t, g, reinterpret_cast<const __bf16*>(a.W3pk_t), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       Act& xh = t[u];
@@ -750,7 +776,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
     if (!(HGN_ABL & 4) && a.dz2 && R.valid[u]) t_store(t[u], a.dz2 + R.row[u] * LAT, kq);
   }
   // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------
-  gemm6<NS, NP>(g, t, lds, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] {
+  block(g, t, reinterpret_cast<const __bf16*>(a.W2pk_t), [&] {
 #pragma unroll
     for (int u = 0; u < NS; ++u) t_zero(g[u]);
   });
@@ -772,7 +798,7 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
     const hgn_dx_t d = a.dx[di];
     const __bf16* pk = reinterpret_cast<const __bf16*>(d.Wpk_t);
     for (int k0 = 0; k0 < d.K; k0 += 128) {
-      gemm6<NS, NP>(t, g, lds, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
+      block(t, g, pk + (long)(k0 >> 7) * BLOCK_BF16, [&] {
 #pragma unroll
         for (int u = 0; u < NS; ++u) t_zero(t[u]);
       });
@@ -792,16 +818,28 @@ __global__ __launch_bounds__(WG, NS == 1 ? 3 : 2) void mlp6_bwd_kernel(const hgn
   if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;        // ticket of ln_reduce_kernel (csrc/mlp.hip)
 }
 
-template <int NP>
-__global__ __launch_bounds__(WG, 3) void linear6_bwd_kernel(const Lin6Args a) {
-  // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]; packs are transposed-form
-  __shared__ __attribute__((aligned(16))) __bf16 lds[HALF_BF16];
+template <int NP, bool LATF = false>
+__global__ __launch_bounds__(LATF ? 64 * (4 + LAT_LOADERS) : WG, LATF ? 1 : 3) void linear6_bwd_kernel(const Lin6Args a) {
+  // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]; packs are transposed-form.  LATF: the latency form (see linear6_fwd_kernel)
+  __shared__ __attribute__((aligned(16))) __bf16 lds[LATF ? 3 * HALF_BF16 : HALF_BF16];
   const int kq = (threadIdx.x & 63) >> 4;
+  if constexpr (LATF) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {
+      int blk = 0;
+      lat_loader<NP, LAT_LOADERS>(lds, (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - 4u,
+                                  [&]() -> const __bf16* { return blk < a.n_blocks ? a.pk[blk++] : nullptr; });
+      return;
+    }
+  }
   const Rows<1> R(a.M);
   Act acc[1], b[1];
+  int ring_slot = 0;
   if (a.accumulate) t_load(acc[0], a.out + R.rc[0] * a.ld_out, kq); else t_zero(acc[0]);
-  for (int blk = 0; blk < a.n_blocks; ++blk)
-    gemm6<1, NP>(acc, b, lds, a.pk[blk], [&] { t_load(b[0], a.x + R.rc[0] * a.ldx + 128 * blk, kq); });
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    auto between = [&] { t_load(b[0], a.x + R.rc[0] * a.ldx + 128 * blk, kq); };
+    if constexpr (LATF) gemm6_lat<NP>(acc, b, lds, ring_slot, a.pk[blk], between, [](Act (&)[1]) {});
+    else gemm6<1, NP>(acc, b, lds, a.pk[blk], between);
+  }
   if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out, kq);
 }
 
@@ -1137,6 +1175,14 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
     bool park = false;                      // several aggregation ops feeding a residual source gradient (pna edge blocks)
     if (a->agg_dout && a->n_agg_ops > 1)
       for (int i = 0; i < a->n_dx; ++i) park = park || a->dx[i].residual;
+    if (tiles <= lat_max_tiles() && !park && !a->seg_dz1) {      // a tile per CU at most: the latency form (loader waves + LDS weight ring)
+      constexpr int T = 64 * (4 + LAT_LOADERS);
+      if (nb_ == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+      else if (nb_ == 3) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 3, false, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+      else hipLaunchKernelGGL((mlp6_bwd_kernel<1, 6, false, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
+      *n_slabs = tiles;
+      return hgn_check_launch("hgn_mlp_bwd (split products, latency form)");
+    }
     if (nb_ == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else if (nb_ == 3 && park) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 3, true>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
     else if (nb_ == 3) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 3, false>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);
@@ -1168,6 +1214,13 @@ extern "C" int hgn_linear_bwd6a(const float* g, int64_t ldg, int64_t M, const vo
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(8, (double)M, (hipStream_t)stream);
+  if (tiles <= hgn::lat_max_tiles()) {
+    constexpr int T = 64 * (4 + hgn::LAT_LOADERS);
+    if (nb_ == 1) hipLaunchKernelGGL((linear6_bwd_kernel<1, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    else if (nb_ == 3) hipLaunchKernelGGL((linear6_bwd_kernel<3, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((linear6_bwd_kernel<6, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);
+    return hgn_check_launch("hgn_linear_bwd6 (latency form)");
+  }
   if (nb_ == 1) hipLaunchKernelGGL(linear6_bwd_kernel<1>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else if (nb_ == 3) hipLaunchKernelGGL(linear6_bwd_kernel<3>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear6_bwd_kernel<6>, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, a);
