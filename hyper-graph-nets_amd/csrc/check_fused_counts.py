@@ -60,6 +60,47 @@ def check(text: str, kernel: str = KERNEL, DMA_PER_PHASE: int = DMA_PER_PHASE, f
             raise AssertionError(f'phase {p}: s_waitcnt vmcnt({waits[p]}), Keep<> says {keep}')
 
 
+def check3(text: str) -> None:
+    """csrc/fused_bwd3.hip: two weight-gradient tile loops (wgrad_role<true>: ring waves, 8 LDS-DMA instructions per phase, vmcnt(8) in
+    front of every barrier; wgrad_role<false>: rows waves, 8 in the four fetch phases, vmcnt(8) in front of those phases' barriers only).
+    Checked on both loops: no scratch anywhere in the kernel, no ordinary load / store inside a loop, the DMA count of every phase, every
+    counted wait of a loop is vmcnt(8) and their number is 12 / 4."""
+    at = text.index(KERNEL3 + ':')
+    body = text[at:text.index('.Lfunc_end', at)]
+    if 'scratch_' in body:
+        raise AssertionError('register spills in the fused backward (two-term fp16 form): their memory traffic breaks the counted waits')
+    lines = [l.strip() for l in body.splitlines()]
+    heads = [i for i, l in enumerate(lines) if 'Loop Header' in l]
+    found = {}
+    for h in heads:
+        bars = [i for i in range(h, len(lines)) if lines[i].startswith('s_barrier')]
+        if len(bars) < PHASES:
+            continue
+        try:
+            end = next(i for i in range(bars[PHASES - 1], len(lines)) if lines[i].startswith(('s_cbranch', 's_branch')))
+        except StopIteration:
+            continue
+        if any(re.match(r'^\.?L?BB\d+_\d+:', lines[i]) for i in range(h + 1, end)):
+            continue                                                  # (a loop with inner labels: not one of the straight-line tile loops)
+        seg_dma = [sum(1 for l in lines[bars[p_]:(bars[p_ + 1] if p_ + 1 < PHASES else end)] if l.startswith('global_load_lds')) for p_ in range(PHASES)]
+        if sum(seg_dma) == 0:
+            continue                                                  # the chain's loop
+        other = [l for l in lines[h:end] if l.startswith(('global_load', 'buffer_load', 'flat_load', 'global_store', 'buffer_store', 'flat_store', 'global_atomic'))
+                 and not l.startswith('global_load_lds')]
+        waits = [int(re.search(r'vmcnt\((\d+)\)', l).group(1)) for l in lines[h:end] if l.startswith('s_waitcnt vmcnt(')]
+        ring = [8] * PHASES
+        rows = [8 if p_ in FETCH_PHASES else 0 for p_ in range(PHASES)]
+        kind = 'ring' if seg_dma == ring else ('rows' if seg_dma == rows else None)
+        if kind is None or other:
+            raise AssertionError(f'weight-gradient loop at line {h}: DMA per phase {seg_dma}, other vector memory {other[:2]}')
+        want = PHASES if kind == 'ring' else len(FETCH_PHASES)
+        if any(w != 8 for w in waits) or len(waits) != want:
+            raise AssertionError(f'{kind} loop: counted waits {waits} (expected {want} x vmcnt(8))')
+        found[kind] = True
+    if set(found) != {'ring', 'rows'}:
+        raise AssertionError(f'expected one ring loop and one rows loop, found {sorted(found)}')
+
+
 # ---- csrc/mlp6.hip: mlp6_fwd_edge_kernel (quarter-pipelined weight ring, mlp6_device.h: gemm6q) -------------------------------------
 # Its waits `s_waitcnt vmcnt(N) lgkmcnt(0)` with N > 0 leave the N youngest vector-memory operations of the wave in flight while the
 # LDS-DMA of a ring piece -- issued BEFORE them -- must have landed.  Safe exactly when, walking back from the wait, the first N
@@ -106,7 +147,7 @@ if __name__ == '__main__':
             check(text)
             print('check_fused_counts: ok (fused backward: 12 phases, counted waits match the emitted instructions)')
         if KERNEL3 + ':' in text:
-            check(text, KERNEL3, 4, 4)
+            check3(text)
             print('check_fused_counts: ok (fused backward, two-term fp16 form: 12 phases, counted waits match the emitted instructions)')
         for kernel in EDGE_KERNELS:
             if kernel + ':' in text:

@@ -18,7 +18,11 @@
 //   * Bias gradients: column sums of the fp32 G values the wave holds anyway (16 adds per block).
 //   * The rows of z2 / z1 travel HBM -> LDS by LDS-DMA (two 16 KB landing buffers) instead of through 32 registers per lane that
 //     were live for the whole tile: the weight-gradient role now holds 128 fp32 accumulators AND the operands of a block.
-// LDS: ring 3 x 16 KB + G 32 KB (fp32, 64 rows) + A 16 KB + 4.5 KB LayerNorm partials + 2 x 16 KB landing buffers = 132.6 KB.
+//   * The published operand image is double-buffered (2 x 16 KB): the last weight-gradient block of a tile (dW2, rows 32-63) then
+//     needs nothing that is overwritten before the NEXT tile's first barrier and runs in phase 11 -- beside the chain's LayerNorm
+//     backward of the next tile, the longest stretch in which the weight-gradient waves used to wait (phase stamps: 4.6 k of a
+//     tile's 34 k cycles) -- instead of in phase 7, where the chain waited 3 k cycles for it.
+// LDS: ring 3 x 16 KB + G 32 KB (fp32, 64 rows) + A 2 x 16 KB + 4.5 KB LayerNorm partials + 2 x 16 KB landing buffers = 148.6 KB.
 #include <cstdlib>
 #include <type_traits>
 #include "hgn_device.h"
@@ -30,6 +34,24 @@
 #ifndef HGN_FEXP
 #define HGN_FEXP 0      // diagnostic builds only (see csrc/fused_bwd.hip)
 #endif
+// Diagnostic build only (-DHGN_FUSED_STAMPS, tools/fusedstamps.py): shader-clock stamps of one mid-launch workgroup's waves 0 (chain) and 4
+// (weight gradients) at the phase boundaries of its 11th tile.  A stamp is an s_memtime plus an lgkmcnt drain: order of magnitude only.
+#ifdef HGN_FUSED_STAMPS
+namespace hgn { __device__ unsigned long long g_fstamps[3 * 64]; __device__ unsigned long long g_wstamps[8 * 32]; }
+#define FSTAMP(role, idx)                                                                                      \
+  do {                                                                                                         \
+    if (blockIdx.x == 37 && (threadIdx.x & 63) == 0 && tile == t_beg + 10) g_fstamps[(role) * 64 + (idx)] = clock64(); \
+  } while (0)
+// WSTAMP(p): every wave's arrival at the barrier of phase p (12 x 8 entries behind the FSTAMP block); WSTAMP2: wgrad waves, after their
+// counted vmcnt wait and before the barrier itself
+#define WSTAMP(p)                                                                                              \
+  do {                                                                                                         \
+    if (blockIdx.x == 37 && (threadIdx.x & 63) == 0 && tile == t_beg + 10) g_wstamps[(threadIdx.x >> 6) * 32 + (p)] = clock64(); \
+  } while (0)
+#else
+#define FSTAMP(role, idx) do {} while (0)
+#define WSTAMP(p) do {} while (0)
+#endif
 
 namespace hgn {
 namespace f3 {
@@ -39,9 +61,9 @@ constexpr int FT = 512;                               // threads: 8 waves
 constexpr int PIECE_BYTES = 2 * 8 * 1024;             // one contraction block of a packed block: [split][output block][lane][8 fp16]
 constexpr int RING_BYTES = 3 * PIECE_BYTES;           // 48 KB
 constexpr int G_BYTES = 64 * 512;                     // fp32 rows of dz3 / dz2, 16-byte chunks XOR-swizzled with the row: 32 KB
-constexpr int A_BYTES = 2 * 4 * 128 * 16;             // [split][row group 0..3][feature] fp16x8: 32 rows, 16 KB
+constexpr int A_BYTES = 2 * 4 * 128 * 16;             // [split][row group 0..3][feature] fp16x8: 32 rows, 16 KB -- TWO of them (A_OFF + buf * A_BYTES)
 constexpr int X_BYTES = 4 * 8 * 512;                  // raw fp32 rows of the other operand on their way in: 4 row groups x 8 rows, 16 KB per buffer
-constexpr int G_OFF = RING_BYTES, A_OFF = G_OFF + G_BYTES, EA_OFF = A_OFF + A_BYTES, LN_OFF = EA_OFF + 16, LNG_OFF = LN_OFF + 4 * 256 * 4;
+constexpr int G_OFF = RING_BYTES, A_OFF = G_OFF + G_BYTES, EA_OFF = A_OFF + 2 * A_BYTES, LN_OFF = EA_OFF + 32, LNG_OFF = LN_OFF + 4 * 256 * 4;
 constexpr int XA_OFF = LNG_OFF + 128 * 4, XB_OFF = XA_OFF + X_BYTES;
 constexpr int FUSED_LDS = XB_OFF + X_BYTES;
 static_assert(FUSED_LDS <= 160 * 1024, "one workgroup per CU");
@@ -107,7 +129,9 @@ __device__ __forceinline__ void sweep_piece(Act& acc, const bf16x8 (&xs)[3][4], 
 
 // dW_layer += G^T A over the 32 rows of block `blk` of the tile (see the header).  acc: TRUE scale, fp32.
 __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&bs)[2], const unsigned char* __restrict__ smem, unsigned gaddr /*opaque (ww, kg, m)*/,
-                                            const bf16x8* __restrict__ ap /*lane base: A image*/, const int* __restrict__ ea_lds, int kg, int blk) {
+                                            const bf16x8* __restrict__ ap0 /*lane base: A image 0*/, const int* __restrict__ ea_lds0, int kg, int blk, int abuf) {
+  const bf16x8* ap = ap0 + abuf * (A_BYTES / 16);       // (abuf, blk: compile-time constants at every call site)
+  const int* ea_lds = ea_lds0 + 4 * abuf;
   // ---- this lane's 2 x 8 values of G: rows 32 blk + 8 kg + j, features 32 ww + 16 mb + m.  Swizzled chunk of (j, mb):
   // ((m >> 2) ^ (j & 3)) + 4 (mb ^ (j >> 2) ^ (kg & 1)): eight lane bases (j & 3, parity), everything else an immediate offset.
   // One 16-feature half (mb) at a time -- read, column sums, scale, split -- so that only its eight values are live beside the accumulators.
@@ -139,12 +163,13 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&bs)[2], 
     mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x122, 0xf, 0xf, true)));   // row_ror:2
     mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x121, 0xf, 0xf, true)));   // row_ror:1
     int T = hgn_split::scale_exp_of(mx) + ea;
-    T = min(T, __shfl_xor(T, 16));
-    T = min(T, __shfl_xor(T, 32));
+    T = rows4_min_i(T);
     hgn_split::eight16(gv, hgn_split::pow2f(T - ea), gs[mb]);
     unscale[mb] = hgn_split::pow2f(-T);
-    asm volatile("" : "+v"(ga) : "v"(gs[mb][0]), "v"(gs[mb][1]));      // the second half's reads start when the first half's values are dead
+#if !(HGN_FEXP & 512)
+    asm volatile("" : "+v"(ga) : "v"(gs[mb][0]), "v"(gs[mb][1]));      // the second half's reads start when the first half's values are dead (8 registers)
     __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   // ---- products from zero, then into the accumulators
   bf16x8 as[2][2];
@@ -174,23 +199,31 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&bs)[2], 
 }
 
 // ---- the weight ring (wgrad waves): piece q of a tile (q = 0..11): layer q / 4 (W3^T, W2^T, W1e^T), contraction block q % 4, slot q % 3
-constexpr int DPW = 4;                                // DMA instructions per wgrad wave and piece (two splits x two tiles)
 
 template <int Q>
 __device__ __forceinline__ void dma_piece(const __bf16* __restrict__ pk3, const __bf16* __restrict__ pk2, const __bf16* __restrict__ pk1,
-                                          unsigned lds_base, unsigned ww, unsigned voff /*dma_lane_off*/) {
+                                          unsigned lds_base, unsigned ww, unsigned voff /*dma_lane_off2*/) {
   constexpr int layer = Q / 4, c = Q % 4, half = c >> 1, cl = c & 1, slot = Q % 3;
   const __bf16* blk = layer == 0 ? pk3 : (layer == 1 ? pk2 : pk1);
   const __bf16* src = blk + (half * HALF_BF16 + (cl * 8) * TILE_BF16) + ww * TILE_BF16;
-  if (!(HGN_FEXP & 1)) glds_piece<NP>(src, voff, lds_base + slot * PIECE_BYTES + ww * 1024);
+  if (!(HGN_FEXP & 1)) glds_piece2(src, voff, lds_base + slot * PIECE_BYTES + ww * 1024);      // ww in {0, 1}: tiles ww, ww + 2, ww + 4, ww + 6 of both splits
 }
 
-// Schedule of the weight-gradient waves: as in fused_bwd.hip (blocks in phases 0, 3, 5, 7; publishes in 1, 4, 6, 11; DMA of piece P + 2 in every phase P)
+// Schedule of the weight-gradient waves: blocks in phases 0, 3, 7, 11 -- the phases in which the chain has the most work of its own
+// (sweep + G rows; sweep + ReLU mask + split; the same + dz1 store; last sweep + the next tile's LayerNorm backward) --, publishes in
+// 1, 4, 6, 11, and in EVERY phase P the DMA of ring piece P + 2.
+// Vector memory retires in order: a wave that issues both the ring's DMA (L2 hits, needed two phases later) and the operand rows'
+// DMA (HBM, needed five phases later) waits for the rows whenever it waits for a piece (phase stamps: 1.7 k cycles at two barriers
+// of a 34 k tile).  So the four waves split the two duties: waves 4, 5 ("ring") issue the whole piece (8 instructions each) and
+// retire it with vmcnt(8) -- only the next piece may fly --; waves 6, 7 ("rows") issue the operand fetches (two row groups = 8
+// instructions each) and wait, with vmcnt(8) as well, only in front of the barrier of the phase that publishes a buffer: the fetch
+// that filled it is five to seven phases old, the one younger fetch may fly.
 constexpr bool wg_fetches(int p) { const int q = ((p % 12) + 12) % 12; return q == 1 || q == 4 || q == 6 || q == 11; }
-constexpr int FETCH_OPS = 4;                          // LDS-DMA instructions of one operand fetch
-template <int P>
-struct Keep_ { static constexpr int value = DPW + FETCH_OPS * (wg_fetches(P - 2) ? 1 : 0) + FETCH_OPS * (wg_fetches(P - 1) ? 1 : 0); };
+constexpr int WAVE_DMA = 8;                           // LDS-DMA instructions of one ring piece per ring wave = of one fetch per rows wave
 
+// RING: this wave's memory duty (the arithmetic is the same for all four): the weight ring (waves 4, 5) or the operand rows (6, 7).  Two
+// instantiations = two straight-line tile loops, each with its own static operation counts (check_fused_counts.py).
+template <bool RING>
 __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* __restrict__ smem, long t_beg, long t_end) {
   const hgn_mlp_bwd_t& a = fa.b;
   const long M = a.M;
@@ -217,23 +250,24 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) acc[l][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  // The other operand's rows: wave ww fetches row group ww (8 rows x 512 B) of a 32-row block by four LDS-DMA instructions (two
-  // whole rows each; lane l: row 2 i + (l >> 5), bytes 16 (l & 31)) into its 4 KB of a landing buffer, at least three phases
-  // before it publishes the group (the counted wait of every phase retires everything older than two phases: Keep<>).
-  auto fetch = [&](int buf_off, int l, long tile, int blk) {
-    const long r0 = tile * TILE_ROWS + blk * 32 + (long)ww * 8 + (lane >> 5);
+  // The other operand's rows: a row group (8 rows x 512 B) of a 32-row block arrives by four LDS-DMA instructions (two whole rows
+  // each; lane l: row 2 i + (l >> 5), bytes 16 (l & 31)) in its 4 KB of a landing buffer, five to seven phases before wave `grp`
+  // publishes it.
+  auto fetch = [&](int buf_off, int l, long tile, int blk) {      // rows waves only (ww in {2, 3}): row groups 2 (ww - 2), 2 (ww - 2) + 1 = 16 rows
+    const long r0 = tile * TILE_ROWS + blk * 32 + (long)(ww - 2u) * 16 + (lane >> 5);
     const char* A = reinterpret_cast<const char*>(fa.A[l]);
-    unsigned vo[4];
+    const unsigned dst = lds_base + (unsigned)buf_off + (ww - 2u) * 8192u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vo[i] = (unsigned)min(r0 + 2 * i, M - 1) * (LAT * 4u) + 16u * (unsigned)(lane & 31);
-    const unsigned dst = lds_base + (unsigned)buf_off + ww * 4096u;
-    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %4\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4"
-                 : : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(A), "s"(dst) : "memory", "scc", "m0");
+    for (int i = 0; i < 8; ++i) {                     // (one address register at a time: eight live ones are four spills in the block phases)
+      unsigned vo = (unsigned)min(r0 + 2 * i, M - 1) * (LAT * 4u) + 16u * (unsigned)(lane & 31);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(A), "s"(dst + 1024u * i) : "memory", "m0");
+    }
   };
-  auto publish = [&](int buf_off) {
+  auto ring_piece = [&](auto Q_) {                    // ring waves only: operand tiles ww + 2 k of the piece
+    constexpr int Q = decltype(Q_)::value;
+    dma_piece<Q>(pk3, pk2, pk1, lds_base, ww, dma_lane_off2((unsigned)lane));
+  };
+  auto publish = [&](int buf_off, int abuf) {
     if (HGN_FEXP & 128) return;
     const f32x2* xp = reinterpret_cast<const f32x2*>(smem + opaque((unsigned)buf_off + ww * 4096u + 8u * (unsigned)lane));
     f32x2 x[8];
@@ -242,8 +276,11 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
     float mx = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fmaxf(fabsf(x[j][0]), fabsf(x[j][1])));
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x128, 0xf, 0xf, true)));   // row_ror:8, 4, 2, 1: over the 16 lanes of a row
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x124, 0xf, 0xf, true)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x122, 0xf, 0xf, true)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x121, 0xf, 0xf, true)));
+    mx = rows4_max(mx);                                   // ... then over the four rows
     const int ea = hgn_split::scale_exp_of(mx);
     const float sc = hgn_split::pow2f(ea);
 #pragma unroll
@@ -254,34 +291,47 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
       bf16x8 sp[3];
       hgn_split::eight16(v, sc, sp);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) apub[s2 * 4 * 128 + f] = sp[s2];
+      for (int s2 = 0; s2 < 2; ++s2) apub[abuf * (A_BYTES / 16) + s2 * 4 * 128 + f] = sp[s2];
     }
-    reinterpret_cast<int*>(smem + EA_OFF)[ww] = ea;      // (every lane, the same word: a predicated store would put a branch into the counted phases)
+    reinterpret_cast<int*>(smem + EA_OFF)[4 * abuf + ww] = ea;      // (every lane, the same word: a predicated store would put a branch into the counted phases)
   };
   auto phase = [&](auto P_, long tile) {
     constexpr int P = decltype(P_)::value;
-    bar_keep<Keep_<P>::value>();
-    if constexpr (P == 1 || P == 6) publish(XB_OFF);
-    if constexpr (P == 4 || P == 11) publish(XA_OFF);
-    dma_piece<(P + 2) % 12>(pk3, pk2, pk1, lds_base, ww, dma_lane_off((unsigned)lane));
-    if constexpr (P == 1 && !(HGN_FEXP & 2)) fetch(XB_OFF, 1, tile, 1);
-    if constexpr (P == 4 && !(HGN_FEXP & 2)) fetch(XA_OFF, 0, tile + 1, 0);     // (past the last tile: clamped rows -- keeps the operation counts static)
-    if constexpr (P == 6 && !(HGN_FEXP & 2)) fetch(XB_OFF, 0, tile + 1, 1);
-    if constexpr (P == 11 && !(HGN_FEXP & 2)) fetch(XA_OFF, 1, tile + 1, 0);
-    if constexpr (P == 0 && !(HGN_FEXP & 32)) wgrad_block(acc[0], bs[0], smem, gaddr, ap, ea_lds, kg, 0);
-    if constexpr (P == 3 && !(HGN_FEXP & 32)) wgrad_block(acc[0], bs[0], smem, gaddr, ap, ea_lds, kg, 1);
-    if constexpr (P == 5 && !(HGN_FEXP & 32)) wgrad_block(acc[1], bs[1], smem, gaddr, ap, ea_lds, kg, 0);
-    if constexpr (P == 7 && !(HGN_FEXP & 32)) wgrad_block(acc[1], bs[1], smem, gaddr, ap, ea_lds, kg, 1);
+    FSTAMP(1, 4 * P);
+    WSTAMP(P);
+    if constexpr (RING || wg_fetches(P)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAVE_DMA) : "memory");   // RING: piece P has landed (piece P + 1
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              // may fly); rows: the buffer published below
+    WSTAMP(12 + P);
+    __builtin_amdgcn_s_barrier();
+    FSTAMP(1, 4 * P + 1);
+    if constexpr (P == 1 || P == 6) publish(XB_OFF, 1);      // rows 32-63 of z2 / z1 -> image 1
+    if constexpr (P == 4 || P == 11) publish(XA_OFF, 0);     // rows 0-31 of z1 / the next tile's z2 -> image 0
+    FSTAMP(1, 4 * P + 2);
+    if constexpr (RING) ring_piece(std::integral_constant<int, (P + 2) % 12>{});
+    else if constexpr (!(HGN_FEXP & 2)) {
+      if constexpr (P == 1) fetch(XB_OFF, 1, tile, 1);
+      if constexpr (P == 4) fetch(XA_OFF, 0, tile + 1, 0);   // (past the last tile: clamped rows -- keeps the operation counts static)
+      if constexpr (P == 6) fetch(XB_OFF, 0, tile + 1, 1);
+      if constexpr (P == 11) fetch(XA_OFF, 1, tile + 1, 0);
+    }
+    FSTAMP(1, 4 * P + 3);
+    if constexpr (P == 0 && !(HGN_FEXP & 32)) wgrad_block(acc[0], bs[0], smem, gaddr, ap, ea_lds, kg, 0, 0);
+    if constexpr (P == 3 && !(HGN_FEXP & 32)) wgrad_block(acc[0], bs[0], smem, gaddr, ap, ea_lds, kg, 1, 1);
+    if constexpr (P == 7 && !(HGN_FEXP & 32)) wgrad_block(acc[1], bs[1], smem, gaddr, ap, ea_lds, kg, 0, 0);      // (G rows 0-31 hold dz2 from barrier 4 on, image 0 z1 from phase 4 to 11)
+    // dW2 rows 32-63: G rows 32-63 (dz2) stay until the next tile's waves 2, 3 write behind barrier 0, image 1 until phase 1 of the next tile
+    if constexpr (P == 11 && !(HGN_FEXP & 32)) wgrad_block(acc[1], bs[1], smem, gaddr, ap, ea_lds, kg, 1, 1);
   };
-  // prologue = phases 10 and 11 of the tile before the first one
-  fetch(XA_OFF, 0, t_beg, 0);
-  fetch(XB_OFF, 0, t_beg, 1);
-  dma_piece<0>(pk3, pk2, pk1, lds_base, ww, dma_lane_off((unsigned)lane));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (prologue only: the first group has landed before it is published)
-  publish(XA_OFF);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read before the next fetch overwrites the buffer
-  dma_piece<1>(pk3, pk2, pk1, lds_base, ww, dma_lane_off((unsigned)lane));
-  fetch(XA_OFF, 1, t_beg, 0);
+  // prologue = phases 10 and 11 of the tile before the first one: both landing buffers' z2 rows and piece 0, a barrier of the whole
+  // workgroup (the groups a wave publishes were fetched by another), publish z2 rows 0-31, piece 1, fetch z1 rows 0-31
+  if constexpr (RING) ring_piece(std::integral_constant<int, 0>{});
+  else { fetch(XA_OFF, 0, t_beg, 0); fetch(XB_OFF, 0, t_beg, 1); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bar_lds();                                          // (P) pairs with the chain's extra barrier
+  publish(XA_OFF, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... read before the next fetch overwrites the buffer (every wave reads its own group: a barrier)
+  __builtin_amdgcn_s_barrier();                       // (Q)
+  if constexpr (RING) ring_piece(std::integral_constant<int, 1>{});
+  else fetch(XA_OFF, 1, t_beg, 0);
   bar_lds();                                          // (S)
   for (long tile = t_beg; tile < t_end; ++tile) {
     phase(std::integral_constant<int, 0>{}, tile);
@@ -310,8 +360,7 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab[(32 * ww + 16 * mb + 4 * kg_e + r) * 128 + 16 * nb + m_e] = acc[l][mb][nb][r];
       float s = bs[l][mb];                            // the four row groups of a feature: fixed-order sum over kg
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      s = rows4_sum(s);
       if (kg_e == 0) slab[128 * 128 + 32 * ww + 16 * mb + m_e] = s;
     }
   }
@@ -381,12 +430,15 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused3_kernel(const FusedArgs 
     fetch_dout(t_beg, n, kq);
     fetch_agg(seg_of(t_beg), kq);
     fetch_small(t_beg, n, kq);
+    bar_lds();                                        // (P), (Q): the weight-gradient waves' prologue barriers
+    bar_lds();
     bar_lds();                                        // (S)
     for (long tile = t_beg; tile < t_end; ++tile) {
       const int lane_i = (int)opaque((unsigned)lane);
       n = lane_i & 15; kq = lane_i >> 4;
       const long row = tile * TILE_ROWS + wave * WAVE_ROWS + n;
       const bool valid = row < M;
+      FSTAMP(0, 0);
       seg_next = seg_of(tile + 1);
       const unsigned mb1 = pf_m1, mb2 = pf_m2;
       // ---- LayerNorm backward -> dz3 (g) ------------------------------------------------------------------------------------
@@ -409,6 +461,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused3_kernel(const FusedArgs 
         HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - xh.v[fb] * m2);
       }
       fetch_xhat(tile + 1, n, kq);
+      FSTAMP(0, 1);
       // ---- layers 3 and 2 (li = 0: g <- W3^T dz3; 1: g <- W2^T dz2).  Ring slot of piece (li, c): (4 li + c) mod 3.
       // G rows: waves 0, 1 (rows 0-31) write before the phase's barrier -- free since the previous layer's first weight-gradient
       // block --, waves 2, 3 (rows 32-63) after it (the previous layer's second block is done).
@@ -417,18 +470,20 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused3_kernel(const FusedArgs 
         if (wave < 2) g_write(smem, wave, (int)opaque((unsigned)n), kq, g);
         const int T = split_np<NP>(g, xs) + (li ? sw2 : sw3);      // the row's scale + the block's
         const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 1 : 0) * PIECE_BYTES));
+        FSTAMP(0, 2 + 8 * li); WSTAMP(4 * li);
         bar_lds();                                              // ---- phase 4 li
+        FSTAMP(0, 3 + 8 * li);
         if (wave >= 2) g_write(smem, wave, (int)opaque((unsigned)n), kq, g);
         sweep_piece<0, 1>(g, xs, ring);
         if (li == 0) fetch_dout(tile + 1, (int)opaque((unsigned)n), kq);       // phase 1: d(e') of the next tile
         ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 2 : 1) * PIECE_BYTES));
-        bar_lds();
+        FSTAMP(0, 4 + 8 * li); WSTAMP(4 * li + 1); bar_lds(); FSTAMP(0, 5 + 8 * li);
         sweep_piece<1>(g, xs, ring);                            // ---- phase 4 li + 1
         ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 0 : 2) * PIECE_BYTES));
-        bar_lds();
+        FSTAMP(0, 6 + 8 * li); WSTAMP(4 * li + 2); bar_lds(); FSTAMP(0, 7 + 8 * li);
         sweep_piece<2>(g, xs, ring);                            // ---- phase 4 li + 2
         ring = smem + opaque((unsigned)(lane_i * 16 + (li ? 1 : 0) * PIECE_BYTES));
-        bar_lds();
+        FSTAMP(0, 8 + 8 * li); WSTAMP(4 * li + 3); bar_lds(); FSTAMP(0, 9 + 8 * li);
         sweep_piece<3>(g, xs, ring);                            // ---- phase 4 li + 3
         scale_act(g, -T);                                       // back to the true scale
         relu_mask_bits(g, li == 0 ? mb2 : mb1);                 // dz2 / dz1
@@ -439,12 +494,13 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused3_kernel(const FusedArgs 
       const int T1 = split_np<NP>(g, xs) + sw1;
       scale_act(geff, T1);                                      // the skip connection enters at the products' scale
       const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16));
-      bar_lds(); sweep_piece<0, 2>(g, xs, ring + 2 * PIECE_BYTES, &geff);                // ---- phase 8
-      bar_lds();
+      FSTAMP(0, 18); WSTAMP(8); bar_lds(); FSTAMP(0, 19); sweep_piece<0, 2>(g, xs, ring + 2 * PIECE_BYTES, &geff);                // ---- phase 8
+      FSTAMP(0, 20); WSTAMP(9); bar_lds(); FSTAMP(0, 21);
       if (has_agg) fetch_agg(seg_next, kq); else t_zero(geff);      // phase 9
       sweep_piece<1>(g, xs, ring + 0 * PIECE_BYTES);                // ---- phase 9
-      bar_lds(); sweep_piece<2>(g, xs, ring + 1 * PIECE_BYTES);     // ---- phase 10
-      bar_lds(); sweep_piece<3>(g, xs, ring + 2 * PIECE_BYTES);     // ---- phase 11
+      FSTAMP(0, 22); WSTAMP(10); bar_lds(); FSTAMP(0, 23); sweep_piece<2>(g, xs, ring + 1 * PIECE_BYTES);     // ---- phase 10
+      FSTAMP(0, 24); WSTAMP(11); bar_lds(); FSTAMP(0, 25); sweep_piece<3>(g, xs, ring + 2 * PIECE_BYTES);     // ---- phase 11
+      FSTAMP(0, 26);
       scale_act(g, -T1);
       if (valid && !(HGN_FEXP & 4)) t_store32(g, d.dx, (unsigned)row * ((unsigned)d.ld * 4u) + 16u * kq);
     }
@@ -458,11 +514,25 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused3_kernel(const FusedArgs 
     a.ln_ws[(long)blockIdx.x * 256 + tid] = sum;
     if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;               // ticket of ln_reduce_kernel (csrc/mlp.hip)
   } else {
-    wgrad_role(fa, smem, t_beg, t_end);
+    if (wave < 6) wgrad_role<true>(fa, smem, t_beg, t_end);      // (uniform)
+    else wgrad_role<false>(fa, smem, t_beg, t_end);
   }
 }
 
 }  // namespace f3
+
+#ifdef HGN_FUSED_STAMPS
+}  // namespace hgn
+extern "C" int hgn_debug_fused_stamps(unsigned long long* host192) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host192, HIP_SYMBOL(hgn::g_fstamps), 3 * 64 * 8) == hipSuccess ? HGN_OK : HGN_E_LAUNCH;
+}
+extern "C" int hgn_debug_fused_wave_stamps(unsigned long long* host256) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host256, HIP_SYMBOL(hgn::g_wstamps), 8 * 32 * 8) == hipSuccess ? HGN_OK : HGN_E_LAUNCH;
+}
+namespace hgn {
+#endif
 
 int launch_edge_bwd_fused3(const FusedArgs& fa, long grid, hipStream_t stream) {
   hipLaunchKernelGGL(f3::edge_bwd_fused3_kernel, dim3((unsigned)grid), dim3(f3::FT), 0, stream, fa);

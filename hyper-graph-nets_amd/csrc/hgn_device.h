@@ -356,6 +356,30 @@ __device__ __forceinline__ void row16_sums_transposed(const Act& a, float (&out)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Butterflies across the four 16-lane rows of a wavefront (lanes l, l ^ 16, l ^ 32, l ^ 48 hold the four quarters of one tile row)
+// on gfx950's v_permlane16_swap / v_permlane32_swap: both operands of a step arrive by ONE vector instruction (swap rows 1 <-> 0',
+// 3 <-> 2' of two copies of the value, then halves) instead of a ds_bpermute round trip through the LDS crossbar (~120 cycles of
+// latency each, two per reduction, in the dependent chain of every LayerNorm and every row scale).  Same operands per lane as
+// x op shfl_xor(x, 16), then op shfl_xor(., 32): commutative ops give the same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <class Op>
+__device__ __forceinline__ float rows4_reduce(float t, Op op) {
+  u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  t = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float rows4_sum(float t) { return rows4_reduce(t, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float rows4_max(float t) { return rows4_reduce(t, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ int rows4_min_i(int t) {
+  u32x2_t r = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false);
+  t = min((int)r[0], (int)r[1]);
+  r = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false);
+  return min((int)r[0], (int)r[1]);
+}
+
 // Sum over the 128 features of a row: 32 in-lane values, then the three partner lanes (same n, other kq).
 __device__ __forceinline__ float row_sum(const Act& a) {
   float s0 = 0.f, s1 = 0.f;
@@ -366,9 +390,7 @@ __device__ __forceinline__ float row_sum(const Act& a) {
     s1 += q;
   }
   float t = s0 + s1;
-  t += __shfl_xor(t, 16);
-  t += __shfl_xor(t, 32);
-  return t;
+  return rows4_sum(t);
 }
 
 // Sum over the row of a * b, the products rounded on their own (no fused multiply-add), in the summation order of row_sum.
@@ -382,9 +404,7 @@ __device__ __forceinline__ float row_dot(const Act& a, const Act& b) {
     s1 += q;
   }
   float t = s0 + s1;
-  t += __shfl_xor(t, 16);
-  t += __shfl_xor(t, 32);
-  return t;
+  return rows4_sum(t);
 }
 
 // row_sum of the squares, with the squares rounded on their own (no fused multiply-add): the same bits as row_sum of a tile
@@ -396,9 +416,7 @@ __device__ __forceinline__ float row_sum_sq(const Act& a) {
     s1 += __fmul_rn(a.v[fb][2], a.v[fb][2]) + __fmul_rn(a.v[fb][3], a.v[fb][3]);
   }
   float t = s0 + s1;
-  t += __shfl_xor(t, 16);
-  t += __shfl_xor(t, 32);
-  return t;
+  return rows4_sum(t);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -486,8 +486,7 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     if constexpr (Prod<NP>::SCALED) {
       float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
                       fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
+      m = rows4_max(m);
       if (kq == 0) rmax[wave][n] = m;
       wg_barrier_lds();
       e = scale_exp_of(fmaxf(fmaxf(rmax[0][n], rmax[1][n]), fmaxf(rmax[2][n], rmax[3][n])));
@@ -1032,8 +1031,7 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_fwd_cs_kerne
     if constexpr (Prod<NP>::SCALED) {                 // whole-row maximum over the four waves' shares (one barrier, joined by the loaders)
       float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
                       fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
+      m = rows4_max(m);
       if (kq == 0) rmax[wave][n] = m;
       wg_barrier_lds();
       e_row = scale_exp_of(fmaxf(fmaxf(rmax[0][n], rmax[1][n]), fmaxf(rmax[2][n], rmax[3][n])));

@@ -87,9 +87,7 @@ __device__ __forceinline__ float row_max_abs(const Act& x) {
     m = fmaxf(m, fmaxf(fabsf(x.v[fb][0]), fabsf(x.v[fb][1])));
     m = fmaxf(m, fmaxf(fabsf(x.v[fb][2]), fabsf(x.v[fb][3])));
   }
-  m = fmaxf(m, __shfl_xor(m, 16));
-  m = fmaxf(m, __shfl_xor(m, 32));
-  return m;
+  return rows4_max(m);
 }
 // operand split of a product mode: 6 -> three bf16 terms; 3 -> two fp16 terms of the row scaled by 2^s (returns s); 1 -> the leading
 // bf16 term; 2 -> fp16 (bit patterns in the bf16 slots)
@@ -425,6 +423,23 @@ __device__ __forceinline__ void glds_piece(const void* sbase /*wave-uniform: sou
                  "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3 offset:-2048\n\tglobal_load_lds_dwordx4 %0, %3 offset:2048"
                  : : "v"(voff), "s"(sbase), "s"(s1), "s"(s2), "s"(m0v) : "memory", "scc", "m0");
   }
+}
+// The same piece by one of TWO waves (csrc/fused_bwd3.hip: the ring waves): wave ww in {0, 1} copies tiles ww + 2 k, k = 0..3, of both
+// splits -- 2 KiB apart on both sides, so with a lane offset that carries +4 KiB (dma_lane_off2) the immediates -4096, -2048, 0, +2048
+// reach all four from one M0 and one scalar base per split.  Two-split modes only.
+__device__ __forceinline__ unsigned dma_lane_off2(unsigned lane) { return opaque_u(lane * 16u + 0x1000u); }
+__device__ __forceinline__ void glds_piece2(const void* sbase /*wave-uniform: source of tile (0, ww)*/, unsigned voff /*dma_lane_off2*/,
+                                            unsigned lds_dst /*wave-uniform: LDS byte address of tile (0, ww) in the slot*/) {
+  const unsigned m0v = lds_dst + 0x1000u;
+  asm volatile("" : "+s"(sbase));
+  const void* s1 = static_cast<const unsigned char*>(sbase) + 0x4000;
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:-4096\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+               "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %2 offset:-4096\n\tglobal_load_lds_dwordx4 %0, %2 offset:-2048\n\t"
+               "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:2048"
+               : : "v"(voff), "s"(sbase), "s"(s1), "s"(m0v) : "memory", "scc", "m0");
 }
 // piece c (contraction block) of the packed block `blk` -> ring slot `slot` of the ring at LDS byte address lds_base
 template <int NP>
