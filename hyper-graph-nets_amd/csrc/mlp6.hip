@@ -984,7 +984,12 @@ int launch_mlp6_fwd(const hgn_mlp_fwd_t* a, void* stream) {
     else hipLaunchKernelGGL((mlp6_fwd_kernel<1, 6, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
     return hgn_check_launch("hgn_mlp_fwd (split-bf16, latency form)");
   }
-  if ((tile128() || (tile128_fwd() && a->M >= big_min_rows() && !(a->flags & HGN_F_TILE64_FWD))) && (np_ == 6 || np_ == 3) && a->M > TILE_ROWS) {
+  // 128-row tiles (two sub-tiles per wave, two workgroups per CU) pay for edge-shaped launches -- one source (+ gathered pre-projections) over
+  // >= 98 304 rows --; a node update (several 128-wide sources, a sixth of the rows) is faster on 64-row tiles at three workgroups per CU
+  // (mode 3, 204 800 rows: 0.190 -> 0.176 ms, tools/exp_tile64.py).  Same bits either way.
+  const bool edge_like = a->n_src == 1 || a->n_add > 0;
+  if ((tile128() || (tile128_fwd() && a->M >= big_min_rows() && !(a->flags & HGN_F_TILE64_FWD) && (edge_like || np_ == 6))) && (np_ == 6 || np_ == 3) &&
+      a->M > TILE_ROWS) {
     const long tiles = (a->M + 2 * TILE_ROWS - 1) / (2 * TILE_ROWS);
     if (np_ == 3) {
       if (edge_block_shape(a)) hipLaunchKernelGGL((mlp6_fwd_edge_kernel<3>), dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, *a);

@@ -748,13 +748,13 @@ def test_flag_L15_sum_vs_oracle_fp64():
     # The arithmetic: against the fp64 oracle run with the HIP forward's ReLU gates (tests/helpers.py: GateTransfer) every gradient
     # tensor agrees to 1e-5.  Without the transfer the bound is 5e-5 -- unless a gate of this instance sits within fp32 rounding of
     # its kink after all (the seed search above looks at the fp64 run's margin, 3e-7; a forward that is 3e-7 off at layer 10 can still
-    # draw one): then at most three gates may differ, each at |pre-activation| <= 1e-6, and the transferred figure is the statement.
+    # draw one): then at most three gates may differ, each at |pre-activation| <= 1e-5 (the bound of the headline test), and the transferred figure is the statement.
     _, _, grads_g, gt, _ = H.oracle_run_with_hip_decisions(sd, graph, 'none', 'sum', target, mask, gates, winners)
     gn, _ = H.worst_grad(grads, grads_g)
     H._REPORT.append({'test': 'test_flag_L15_sum_vs_oracle_fp64', 'what': 'param grads (worst tensor)', 'norm': worst[0], 'tensor': worst[1],
                       'norm_with_hip_gates': gn, 'gates_differing_from_fp64': gt.flipped, 'max_abs_preactivation_at_flip': gt.max_abs_at_flip})
     assert gn <= 1e-5, gn
-    assert worst[0] <= 5e-5 or (0 < gt.flipped <= 3 and gt.max_abs_at_flip <= 1e-6), (worst, gt.flipped, gt.max_abs_at_flip)
+    assert worst[0] <= 5e-5 or (0 < gt.flipped <= 3 and gt.max_abs_at_flip <= 1e-5), (worst, gt.flipped, gt.max_abs_at_flip)
 
 
 @pytest.mark.parametrize('agg', ['sum', 'pna'])
@@ -1109,6 +1109,79 @@ def test_captured_step_survives_another_models_storage_move_and_an_eager_step_in
     before = gs.captures
     gs()
     assert gs.captures == before + 1 and plan.table.data_ptr() == table_ptr
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp32-bf16x3'])
+def test_split_products_cover_the_fp32_range(mode):
+    """Product mode 3 (the default: two fp16 terms per operand, three MFMAs per product) lives on powers of two that put every operand
+    into fp16's five exponent bits: per row for activations and gradients, per packed block for weights, per 32-row block for the
+    operands of a weight gradient (csrc/mlp6_device.h: Prod<3>).  The scales must make the arithmetic independent of magnitude: an edge
+    block + node update, forward and backward, against fp64 autograd with rows whose magnitudes lie e^(+-12) apart, inputs at 1e-12
+    and 1e+12, weights x 1e-4 and x 300, loss scales 1e-20 .. 1e+12, an all-zero row, and a whole zero tile of 64 rows -- every
+    output and gradient tensor within 5e-6 of fp64 norm-wise (2e-6 away from the extremes), nothing non-finite.  The six-product
+    bf16 mode, which needs no scales, runs as the second parameter on the same inputs -- except the regime with gradients around
+    1e-32, where its third bf16 term falls into fp32's denormal range and the mode is 5e-4 off (measured): there the scaled mode is
+    the more accurate one."""
+    from hgn_amd import ops, topology, modules
+    import hgn_amd
+    g = synth.grid_graph(seed=3, nx=20, ny=20)
+    es = g.edge_sets[0]
+    N, E = g.node_features[0].shape[0], es.senders.shape[0]
+    topo = topology.EdgeTopology(es.senders.cuda(), es.receivers.cuda(), N, torch.device('cuda'))
+    worst = 0.0
+    for h_scale, e_scale, w_scale, spread, gscale in ((1.0, 1.0, 1.0, 4.0, 1.0), (1e-12, 1e-12, 1.0, 0.0, 1e-20), (1e12, 1e10, 1.0, 0.0, 1e12),
+                                                     (1.0, 1.0, 300.0, 2.0, 1e-6), (1.0, 1.0, 1e-4, 0.0, 1e6)):
+        if mode == 'fp32-bf16x3' and gscale < 1e-10:
+            continue
+        torch.manual_seed(0)
+        m = hgn_amd.MeshGraphNet(3, 128, 2, 'sum', 1, 'none', ['mesh_edges']).cuda()
+        with torch.no_grad():
+            m(hgn_amd.MultiGraph([g.node_features[0].cuda()], [hgn_amd.EdgeSet(es.name, es.features.cuda(), es.senders.cuda(), es.receivers.cuda())]))
+            for p_ in m.parameters():
+                if p_.dim() == 2:
+                    p_.mul_(w_scale)
+        blk = m.processor.graphnet_blocks[0]
+        we = modules.weights_of(blk.edge_models['mesh_edges'], 384)
+        wn = modules.weights_of(blk.node_model_cross, 256)
+        gen = torch.Generator().manual_seed(1)
+        h0 = (torch.randn(N, 128, generator=gen) * h_scale).cuda()
+        rs = torch.exp(torch.randn(E, 1, generator=gen) * spread)
+        e0 = (torch.randn(E, 128, generator=gen) * e_scale * rs).cuda()
+        e0[5] = 0                                              # an all-zero row
+        e0[128:192] = 0                                        # a whole 64-row tile of zeros
+        rowsc = torch.exp(torch.randn(E, 1, generator=gen) * spread).cuda()      # gradient rows of very different magnitude
+
+        def run():
+            h = h0.clone().requires_grad_(True); e = e0.clone().requires_grad_(True)
+            for p_ in blk.parameters():
+                p_.grad = None
+            y, agg = ops.edge_block(h, e, topo, we, ('sum',))
+            hn = ops.fused_mlp([h, agg], wn, None, 0)
+            ((hn.square().sum() + (y * rowsc).square().sum()) * gscale).backward()
+            return [y.detach(), hn.detach(), h.grad, e.grad] + [p_.grad.clone() for p_ in blk.parameters()]
+        snd, rcv = topo.snd.long(), topo.rcv.long()
+        h = h0.double().requires_grad_(True); e = e0.double().requires_grad_(True)
+        ps = [p_.detach().double().requires_grad_(True) for p_ in blk.parameters()]
+        P = dict(zip([n for n, _ in blk.named_parameters()], ps))
+
+        def mlp(x, pre):
+            z = torch.relu(x @ P[pre + '.0.layers.linear_0.weight'].T + P[pre + '.0.layers.linear_0.bias'])
+            z = torch.relu(z @ P[pre + '.0.layers.linear_1.weight'].T + P[pre + '.0.layers.linear_1.bias'])
+            z = z @ P[pre + '.0.layers.linear_2.weight'].T + P[pre + '.0.layers.linear_2.bias']
+            return torch.nn.functional.layer_norm(z, (128,), P[pre + '.1.weight'], P[pre + '.1.bias'], 1e-5)
+        y = e + mlp(torch.cat([h[snd], h[rcv], e], 1), 'edge_models.mesh_edges')
+        agg = torch.zeros(N, 128, dtype=torch.float64, device='cuda').index_add(0, rcv, y)
+        hn = h + mlp(torch.cat([h, agg], 1), 'node_model_cross')
+        ((hn.square().sum() + (y * rowsc.double()).square().sum()) * gscale).backward()
+        want = [y.detach(), hn.detach(), h.grad, e.grad] + [p_.grad for p_ in ps]
+        with ops.using(ops.Context(precision=mode)):
+            got = run()
+        for i, (a_, b_) in enumerate(zip(got, want)):
+            assert bool(torch.isfinite(a_).all()), (mode, h_scale, w_scale, gscale, i)
+            err = H.rel_err(a_, b_)
+            worst = max(worst, err)
+            assert err <= (2e-6 if (h_scale == 1.0 and w_scale == 1.0) else 5e-6), (mode, h_scale, e_scale, w_scale, spread, gscale, i, err)
+    H._REPORT.append({'test': f'test_split_products_cover_the_fp32_range[{mode}]', 'what': 'worst tensor over five magnitude regimes', 'norm': worst})
 
 
 def test_split_bf16_products_are_fp32_accurate():
