@@ -138,7 +138,7 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&bs)[2], 
   // The block's scale, per half: T = min over the four row groups of (sG + eA), sG of this lane's row group over the half's 16
   // features, eA of the group from its publisher; group kg of G enters at 2^(T - eA[kg]) <= 2^sG.
   bf16x8 gs[2][3];
-  float unscale[2];
+  float unscale[2], unscale2[2];
   const int ea = ea_lds[kg];
   unsigned ga = gaddr;
   asm volatile("" : "+v"(ga));                         // (derived here, per block: hoisted out of the tile loop the eight lane bases are eight spills)
@@ -162,10 +162,14 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&bs)[2], 
     mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x124, 0xf, 0xf, true)));   // row_ror:4
     mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x122, 0xf, 0xf, true)));   // row_ror:2
     mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x121, 0xf, 0xf, true)));   // row_ror:1
-    int T = hgn_split::scale_exp_of(mx) + ea;
+    int T = hgn_split::scale_exp_shared(mx) + ea;
     T = rows4_min_i(T);
-    hgn_split::eight16(gv, hgn_split::pow2f(T - ea), gs[mb]);
-    unscale[mb] = hgn_split::pow2f(-T);
+    hgn_split::eight16(gv, hgn_split::pow2f(T - ea), gs[mb]);   // (T - ea <= sG: no overflow; a group far below the block's largest goes to zero)
+    // 2^-T in two factors (|T| <= 2 SCALE_CLAMP: 2^-T itself need not be a normal number).  T is the same in every lane: scalar registers.
+    const int Tu = __builtin_amdgcn_readfirstlane(-T);
+    const int T1 = Tu < -hgn_split::SCALE_CLAMP ? -hgn_split::SCALE_CLAMP : (Tu > hgn_split::SCALE_CLAMP ? hgn_split::SCALE_CLAMP : Tu);
+    unscale[mb] = hgn_split::pow2f(T1);
+    unscale2[mb] = hgn_split::pow2f(Tu - T1);
 #if !(HGN_FEXP & 512)
     asm volatile("" : "+v"(ga) : "v"(gs[mb][0]), "v"(gs[mb][1]));      // the second half's reads start when the first half's values are dead (8 registers)
     __builtin_amdgcn_sched_barrier(0);
@@ -189,7 +193,7 @@ __device__ __forceinline__ void wgrad_block(f32x4 (&acc)[2][8], float (&bs)[2], 
       c = mfma_f16(gs[mb][1], a[0], c);                // smallest terms first
       c = mfma_f16(gs[mb][0], a[1], c);
       c = mfma_f16(gs[mb][0], a[0], c);
-      acc[mb][nb] += c * unscale[mb];
+      acc[mb][nb] += (c * unscale[mb]) * unscale2[mb];
       // (the sum is "used" here: left alone, the compiler parks the sixteen products of a block in scratch and adds all four blocks
       // of a tile at the loop's end)
       asm volatile("" : "+v"(acc[mb][nb]));
@@ -281,7 +285,7 @@ __device__ __forceinline__ void wgrad_role(const FusedArgs& fa, unsigned char* _
     mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x122, 0xf, 0xf, true)));
     mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x121, 0xf, 0xf, true)));
     mx = rows4_max(mx);                                   // ... then over the four rows
-    const int ea = hgn_split::scale_exp_of(mx);
+    const int ea = hgn_split::scale_exp_shared(mx);
     const float sc = hgn_split::pow2f(ea);
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused3_kernel(const FusedArgs 
       }
       // ---- layer 1: de = d_out_eff + dz1 W1e, accumulated in g from `geff` ---------------------------------------------------
       if (!(HGN_FEXP & 4)) t_store32(g, a.dz1, (unsigned)row * (LAT * 4u) + 16u * kq);
-      const int T1 = split_np<NP>(g, xs) + sw1;
+      const int T1 = split_np<NP, false>(g, xs, &geff, sw1) + sw1;    // (capped by what the skip connection holds)
       scale_act(geff, T1);                                      // the skip connection enters at the products' scale
       const unsigned char* ring = smem + opaque((unsigned)(lane_i * 16));
       FSTAMP(0, 18); WSTAMP(8); bar_lds(); FSTAMP(0, 19); sweep_piece<0, 2>(g, xs, ring + 2 * PIECE_BYTES, &geff);                // ---- phase 8

@@ -301,7 +301,7 @@ extern "C" int hgn_mlp_fwd_post_eligible(const hgn_mlp_fwd_t* a) {
   for (int i = 0; i < a->n_post; ++i)
     if (!a->post_pk[i]) return 0;
   if (a->post_zero && ((a->ld_post_zero & 3) || a->ld_post_zero < 128 || !aligned16(a->post_zero))) return 0;
-  return a->out_w == 128 && hgn_mlp_fwd6_eligible(a) && hgn::cs_eligible(a) ? 1 : 0;
+  return a->out_w == 128 && hgn_mlp_fwd6_eligible(a) && a->n_add == 0 && !a->seg_out ? 1 : 0;      // any form of the split-product forward (the edge-block shape has no use for it)
 }
 
 extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
@@ -325,7 +325,7 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
   const int kid = a->n_add ? 0 : 1;
   ProfScope ps(kid, (double)a->M, (hipStream_t)stream);
   if (a->n_post != 0 && !hgn_mlp_fwd_post_eligible(a))
-    return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: post_* needs the column-split inference form (hgn_mlp_fwd_post_eligible)");
+    return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: post_* needs the split-product forward without gathered addends (hgn_mlp_fwd_post_eligible)");
   if (a->seg_out && (!a->seg_ids || a->out_w != 128 || a->ld_seg_out < 128 || !hgn_mlp_fwd6_eligible(a)))
     return hgn_fail(HGN_E_INVALID, "hgn_mlp_fwd: seg_out needs seg_ids, a 128-wide output and the split-bf16 kernel");
 #if HGN_LAB

@@ -145,7 +145,9 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
           return p;
         }
         ++tail;
-        return tail == 1 ? reinterpret_cast<const __bf16*>(a.W2pk) : tail == 2 ? reinterpret_cast<const __bf16*>(a.W3pk) : nullptr;
+        if (tail == 1) return reinterpret_cast<const __bf16*>(a.W2pk);
+        if (tail == 2) return reinterpret_cast<const __bf16*>(a.W3pk);
+        return tail - 3 < a.n_post ? reinterpret_cast<const __bf16*>(a.post_pk[tail - 3]) : nullptr;
       });
       return;
     }
@@ -271,6 +273,27 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
     }
   }
   HGN_STAMP();                                      // segment sums done
+  // ---- post-projection blocks (hgn_mlp_fwd_t.post_*): the output rows are the NEXT edge block's node operand -- its pre-projection
+  // P = [h W1s^T | h W1r^T] (and the zero fill of its aggregate buffer) while the rows are still in registers: the same products in the
+  // same order as hgn_linear_fwd6 on the stored rows (bit-identical), without reading them back and without the launch.
+  if constexpr (!BIG) {
+    if (a.n_post > 0) {
+      for (int pb = 0; pb < a.n_post; ++pb) {
+        block(b, acc, reinterpret_cast<const __bf16*>(a.post_pk[pb]), [&] {
+#pragma unroll
+          for (int u = 0; u < NS; ++u) t_zero(b[u]);
+        }, nothing);
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+          if (R.valid[u]) t_store(b[u], a.post_out + R.row[u] * a.ld_post + 128 * pb, kq);
+      }
+      if (a.post_zero) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+          if (R.valid[u]) { t_zero(b[u]); t_store(b[u], a.post_zero + R.row[u] * a.ld_post_zero, kq); }
+      }
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -462,7 +485,7 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     }, a.n_post > 0 ? main_halves : -1, Prod<NP>::SCALED ? 1 : 0, Prod<NP>::SCALED ? 3 : 2);
     return;
   }
-  __shared__ float rmax[4][16];                       // scaled mode: the four waves' shares of the row maxima of a block's operand
+  __shared__ float rmax[8][16];                       // scaled mode: the four waves' shares of the row maxima of a block's operand
   const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
   const long row = (long)blockIdx.x * 16 + n;
   const bool valid = row < a.M;
@@ -479,17 +502,24 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
   constexpr int NSP = Prod<NP>::NSPLIT;
   // -> the row's scale exponent (mode 3: whole-row maximum over the four waves' shares, as split_np computes it in the other forms:
   // one barrier of the compute waves' own, which the loaders join -- lat_loader: xbar)
-  auto produce = [&](const f32x4& v0, const f32x4& v1) -> int {
+  // `c0`, `c1`, `sw`: what the accumulators hold when the block of this input starts, and the (first) block's exponent -- the row's
+  // exponent is capped so that those contents survive the products' scale (split_bf16.h: SCALE_EASY / acc_room; the second
+  // maximum travels with the first, no barrier of its own)
+  auto max8 = [](const f32x4& v0, const f32x4& v1) -> float {
+    return fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                 fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+  };
+  auto produce = [&](const f32x4& v0, const f32x4& v1, const f32x4& c0, const f32x4& c1, int sw) -> int {
     bf16x8 o[3];
     int e = 0;
     float sc = 1.f;
     if constexpr (Prod<NP>::SCALED) {
-      float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
-                      fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
-      m = rows4_max(m);
-      if (kq == 0) rmax[wave][n] = m;
+      const float m = rows4_max(max8(v0, v1)), am = rows4_max(max8(c0, c1));
+      if (kq == 0) { rmax[wave][n] = m; rmax[4 + wave][n] = am; }
       wg_barrier_lds();
       e = scale_exp_of(fmaxf(fmaxf(rmax[0][n], rmax[1][n]), fmaxf(rmax[2][n], rmax[3][n])));
+      if (e + sw > hgn_split::SCALE_EASY)
+        e = min(e, hgn_split::acc_room(fmaxf(fmaxf(rmax[4][n], rmax[5][n]), fmaxf(rmax[6][n], rmax[7][n]))) - sw);
       sc = pow2f(e);
     }
     cs_split8<NP>(v0, v1, o, sc);
@@ -545,13 +575,13 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
   };
   // `T` (scaled mode): exponent of the operand rows' scale + the block's (acc is carried at 2^T through the block, true scale outside)
   auto block = [&](bool opened = false, int T = 0) {  // xch holds the operand vectors of this block's input
-    if constexpr (Prod<NP>::SCALED) { const float f = pow2f(T); acc[0] *= f; acc[1] *= f; }
+    if constexpr (Prod<NP>::SCALED) { scale4(acc[0], T); scale4(acc[1], T); }
     if (!opened) wg_barrier_lds();                    // ... visible to every wave; the block's first weight half has landed
     consume();
     sweep(std::integral_constant<int, 0>{});
     wg_barrier_lds();                                 // second half landed; every wave has read xch
     sweep(std::integral_constant<int, 1>{});
-    if constexpr (Prod<NP>::SCALED) { const float f = pow2f(-T); acc[0] *= f; acc[1] *= f; }
+    if constexpr (Prod<NP>::SCALED) { scale4(acc[0], -T); scale4(acc[1], -T); }
   };
   auto sw_of = [&](const void* pk) -> int { return Prod<NP>::SCALED ? pack_scale_exp(reinterpret_cast<const __bf16*>(pk)) : 0; };
 
@@ -587,8 +617,9 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
         }
         first = false;
       }
-      const int e = produce(v[0], v[1]);
-      block(false, e + sw_of(reinterpret_cast<const __bf16*>(s.Wpk) + (long)(k0 >> 7) * BLOCK_BF16));
+      const int sw = sw_of(reinterpret_cast<const __bf16*>(s.Wpk) + (long)(k0 >> 7) * BLOCK_BF16);
+      const int e = produce(v[0], v[1], acc[0], acc[1], sw);
+      block(false, e + sw);
     }
   }
   const float* bias[2] = {a.b2, a.b3};
@@ -599,10 +630,12 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[k][u] = fmaxf(acc[k][u], 0.f);
-    const int e = produce(acc[0], acc[1]);
-    acc[0] = chunk(bias[l] + col0);
-    acc[1] = chunk(bias[l] + col1);
-    block(false, e + sw_of(wpk[l]));
+    const f32x4 b0 = chunk(bias[l] + col0), b1 = chunk(bias[l] + col1);
+    const int sw = sw_of(wpk[l]);
+    const int e = produce(acc[0], acc[1], b0, b1, sw);
+    acc[0] = b0;
+    acc[1] = b1;
+    block(false, e + sw);
   }
   // ---- the whole pre-LayerNorm tile to every wave (row sums in the order of the other kernels) -----------------------------
   *reinterpret_cast<f32x4*>(tile + n * 132 + col0) = acc[0];
@@ -634,7 +667,8 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
   // the tile in LDS, and those from their readers.
   if (a.n_post > 0) {
     wg_barrier_lds();                                 // every wave has read the tile
-    const int e_post = produce(o2[0], o2[1]);         // (scaled mode: one more barrier inside, lat_loader: extra_n = 3)
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int e_post = produce(o2[0], o2[1], z4, z4, 0);      // (scaled mode: one more barrier inside, lat_loader: extra_n = 3; the blocks run from zero)
     wg_barrier_lds();                                 // the operand vectors of the output rows are visible
     for (int pb = 0; pb < a.n_post; ++pb) {
       acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1095,8 +1129,8 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_fwd_cs_kerne
       slot = slot == 2 ? 0 : slot + 1;
     }
     if constexpr (Prod<NP>::SCALED) {                 // (the products ran from zero: only the way back to the true scale)
-      const float f = pow2f(-(e_row + pack_scale_exp(a.pk[blk])));
-      acc[0] *= f; acc[1] *= f;
+      const int T = -(e_row + pack_scale_exp(a.pk[blk]));
+      scale4(acc[0], T); scale4(acc[1], T);
     }
     if (valid) {
       *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + 128 * blk + col0) = acc[0];

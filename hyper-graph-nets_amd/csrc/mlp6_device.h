@@ -91,8 +91,11 @@ __device__ __forceinline__ float row_max_abs(const Act& x) {
 }
 // operand split of a product mode: 6 -> three bf16 terms; 3 -> two fp16 terms of the row scaled by 2^s (returns s); 1 -> the leading
 // bf16 term; 2 -> fp16 (bit patterns in the bf16 slots)
-template <int NP>
-__device__ __forceinline__ int split_np(const Act& x, bf16x8 (&s)[3][4]) {
+// `acc` + `sw` (scaled mode): the accumulator the products of this row will be added to at scale 2^(s + sw) and the weight block's
+// exponent -- s is capped so that what `acc` already holds survives the scaling (split_bf16.h: SCALE_EASY); without them the
+// accumulator starts from zero or holds products of the same row.
+template <int NP, bool BRANCH = true>
+__device__ __forceinline__ int split_np(const Act& x, bf16x8 (&s)[3][4], const Act* acc = nullptr, int sw = 0) {
   if constexpr (NP == 2) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -100,7 +103,14 @@ __device__ __forceinline__ int split_np(const Act& x, bf16x8 (&s)[3][4]) {
       for (int j = 0; j < 8; ++j) s[0][c][j] = __builtin_bit_cast(__bf16, (_Float16)x.v[2 * c + (j >> 2)][j & 3]);
     return 0;
   } else if constexpr (NP == 3) {
-    const int e = scale_exp_of(row_max_abs(x));
+    int e = scale_exp_of(row_max_abs(x));
+    if constexpr (BRANCH) {
+      if (acc != nullptr && __builtin_amdgcn_ballot_w64(e + sw > hgn_split::SCALE_EASY) != 0)
+        e = min(e, hgn_split::acc_room(row_max_abs(*acc)) - sw);
+    } else {                                     // (the fused backward's chain: a branch there costs registers, the twenty operations do not)
+      const int room = hgn_split::acc_room(row_max_abs(*acc)) - sw;
+      e = e + sw > hgn_split::SCALE_EASY ? min(e, room) : e;
+    }
     const float sc = pow2f(e);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -118,8 +128,20 @@ __device__ __forceinline__ int split_np(const Act& x, bf16x8 (&s)[3][4]) {
 }
 // scaled modes: acc <- acc * 2^e (exact)
 __device__ __forceinline__ void scale_act(Act& a, int e) {
-  const float f = pow2f(e);
-  HGN_FOR_B(fb) a.v[fb] *= f;
+  // e = a row's exponent + a block's: |e| <= 240.  One multiplication per value while every lane's factor is a normal number (always,
+  // short of rows below 2^-100 of an ordinary weight block): a wave vote, so the common path has no second multiplication.
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(e < -hgn_split::SCALE_CLAMP || e > hgn_split::SCALE_CLAMP) == 0, 1)) {
+    const float f = pow2f(e);
+    HGN_FOR_B(fb) a.v[fb] *= f;
+  } else {
+    const int e1 = e < -hgn_split::SCALE_CLAMP ? -hgn_split::SCALE_CLAMP : (e > hgn_split::SCALE_CLAMP ? hgn_split::SCALE_CLAMP : e);
+    const float f1 = pow2f(e1), f2 = pow2f(e - e1);
+    HGN_FOR_B(fb) a.v[fb] = (a.v[fb] * f1) * f2;
+  }
+}
+__device__ __forceinline__ void scale4(f32x4& v, int e) {      // the same for one register quadruple (column-split kernels)
+  const int e1 = e < -hgn_split::SCALE_CLAMP ? -hgn_split::SCALE_CLAMP : (e > hgn_split::SCALE_CLAMP ? hgn_split::SCALE_CLAMP : e);
+  v = (v * pow2f(e1)) * pow2f(e - e1);
 }
 // one product of a mode against the fragments a[0] (hi) a[1] (mid / lo) a[2] (lo) of one operand tile, smallest terms first
 template <int NP>
@@ -341,7 +363,7 @@ __device__ __forceinline__ void gemm6(Act (&acc)[NS], Act (&b)[NS], __bf16* __re
   HGN_STAMP();                                    // 3: landed
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
-    T[u] = split_np<NP>(b[u], xs[u]) + sw;
+    T[u] = split_np<NP>(b[u], xs[u], &acc[u], sw) + sw;
     if constexpr (Prod<NP>::SCALED) scale_act(acc[u], T[u]);
   }
   post_split(b);
@@ -552,7 +574,7 @@ __device__ __forceinline__ void gemm6q(Act (&acc)[NS], Act (&b)[NS], __bf16* __r
   dma_piece6<NP>(pk, 1, lds_base, 1, ww, dma_lane_off(lane));
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
-    T[u] = split_np<NP>(b[u], xs[u]) + sw;
+    T[u] = split_np<NP>(b[u], xs[u], &acc[u], sw) + sw;
     if constexpr (Prod<NP>::SCALED) scale_act(acc[u], T[u]);
   }
   at_piece(0, b);
@@ -645,7 +667,7 @@ __device__ __forceinline__ void gemm6_lat(Act (&acc)[1], Act (&b)[1], __bf16* __
   HGN_STAMP();                                      // 1: caller's loads issued
   wg_barrier_lds();                                 // half 2 b has landed
   HGN_STAMP();                                      // 2: past the barrier of half 0
-  const int T = split_np<NP>(b[0], xs[0]) + sw;
+  const int T = split_np<NP>(b[0], xs[0], &acc[0], sw) + sw;
   if constexpr (Prod<NP>::SCALED) scale_act(acc[0], T);
   post_split(b);
   HGN_STAMP();                                      // 3: split (the caller's loads have arrived)

@@ -40,14 +40,32 @@ __device__ __forceinline__ void eight(const float (&v)[8], b8 (&s)[3]) {
 // exponent bits.  Three products hi*hi + hi*lo + lo*hi then carry what six products of three bf16 terms carry.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 constexpr int SCALE_TOP = 15;       // scaled operands: largest magnitude in [2^14, 2^15) (fp16 overflows at 2^16)
-constexpr int SCALE_CLAMP = 60;     // |exponent| of a scale: sums of two of them stay normal fp32 powers of two
+constexpr int SCALE_CLAMP = 120;    // |exponent| of ONE scale (2^+-120 is a normal fp32 number): rows / blocks down to 2^-105 keep full precision.
+                                    // A product's accumulators carry the SUM of two exponents (up to +-240): scale_pair splits it when one
+                                    // factor cannot hold it.
 
 __device__ __forceinline__ float pow2f(int e) { return __builtin_amdgcn_ldexpf(1.0f, e); }
-// the exponent s with maxabs * 2^s in [2^14, 2^15) (0 / inf / nan: frexp gives exponent 0), clamped
+// x * 2^e for |e| <= 2 SCALE_CLAMP: one multiplication while 2^e is a normal number (|e| <= 120), two beyond (exact either way, barring
+// the under- / overflow of x itself).  `e` must be UNIFORM where the branch matters for speed; it is correct for any e.
+__device__ __forceinline__ float mul_pow2(float x, int e) {
+  const int e1 = e < -SCALE_CLAMP ? -SCALE_CLAMP : (e > SCALE_CLAMP ? SCALE_CLAMP : e);
+  return (x * pow2f(e1)) * pow2f(e - e1);
+}
+// the exponent s with maxabs * 2^s in [2^14, 2^15), clamped (0 / inf / nan: frexp gives exponent 0, s = 15: "magnitude 1")
 __device__ __forceinline__ int scale_exp_of(float maxabs) {
   const int s = SCALE_TOP - __builtin_amdgcn_frexp_expf(maxabs);
   return s < -SCALE_CLAMP ? -SCALE_CLAMP : (s > SCALE_CLAMP ? SCALE_CLAMP : s);
 }
+// the same where several groups SHARE one scale, the minimum of their exponents (csrc/fused_bwd3.hip): an all-zero group -- the
+// padding rows of a tail tile, a dead row -- takes the LARGEST exponent, the limit of ever smaller data, so that it never decides
+// the minimum (as "magnitude 1" it would crush a block of data at 1e-12 to nothing)
+__device__ __forceinline__ int scale_exp_shared(float maxabs) { return maxabs == 0.f ? SCALE_CLAMP : scale_exp_of(maxabs); }
+// Accumulators that already hold something are carried at the products' scale 2^T through a block (x 2^T before, x 2^-T after).
+// When T is large (tiny operand rows) that something must not overflow: T above SCALE_EASY is capped at acc_room() of what the
+// accumulator holds (a wave-uniform test: ordinary data never takes the branch).  Below SCALE_EASY an overflow needs accumulator
+// contents of 2^62 = 4.6e18 and more.
+constexpr int SCALE_EASY = 64;
+__device__ __forceinline__ int acc_room(float acc_maxabs) { return 125 - __builtin_amdgcn_frexp_expf(acc_maxabs); }
 __device__ __forceinline__ void pair16(float x0, float x1, unsigned& hi, unsigned& lo) {
   const f2 x = {x0, x1};
   const h2 h = __builtin_convertvector(x, h2);

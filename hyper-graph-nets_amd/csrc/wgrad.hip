@@ -420,12 +420,13 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                   // every wave has finished reading the operands of block p-1
-    float unscale = 1.f, sc = 1.f;
+    float unscale = 1.f, unscale2 = 1.f, sc = 1.f;
     if constexpr (NP == 3) {
       const int eA = hgn_split::scale_exp_of(fmaxf(blkmax[0][0], blkmax[0][1]));
       const int eG = hgn_split::scale_exp_of(fmaxf(blkmax[1][0], blkmax[1][1]));
       sc = hgn_split::pow2f(arr ? eG : eA);
-      unscale = hgn_split::pow2f(-(eA + eG));
+      unscale = hgn_split::pow2f(-eA);                 // (two factors: their product 2^-(eA + eG) need not be a normal number)
+      unscale2 = hgn_split::pow2f(-eG);
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
           c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, gs[mb][1]), __builtin_bit_cast(f16x8, as[0]), c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, gs[mb][0]), __builtin_bit_cast(f16x8, as[1]), c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, gs[mb][0]), __builtin_bit_cast(f16x8, as[0]), c, 0, 0, 0);
-          acc[mb][nb] += c * unscale;
+          acc[mb][nb] += (c * unscale) * unscale2;
           continue;
         }
         f32x4 c = acc[mb][nb];

@@ -251,7 +251,7 @@ class GraphNet(nn.Module):
         return out
 
     def _update_nodes(self, lat: _Latent, aggs, nxt: Optional['GraphNet'] = None):
-        # Inference through a plain stack of blocks with ONE edge set (Processor.forward): the node kernel also forms the NEXT block's
+        # A plain stack of blocks with ONE edge set (Processor.forward): the node kernel also forms the NEXT block's
         # node-level pre-projection P = [h W1s^T | h W1r^T] and the zero fill of its aggregate buffer while the rows are in registers
         post = None
         if nxt is not None and len(lat.edges) == 1:
@@ -264,13 +264,14 @@ class GraphNet(nn.Module):
             self._node(lat, list(aggs.values()), self.node_model_cross, 0)   # graph order (graphnet.py:43)
             return
         srcs = [lat.nodes[0]] + [a.t for a in aggs.values()]
-        lat.nodes[0], got = fused_apply(self.node_model_cross, srcs, residual=0, post=post)
+        lat.nodes[0], got = fused_apply(self.node_model_cross, srcs, residual=0, post=post, share=len(lat.nodes) == 1)
         if got is not None:
             lat.pre = {next(iter(lat.edges)): got}
 
     def forward(self, graph, mask=None):
         if isinstance(graph, _Latent):
-            return self._forward_latent(graph)
+            nxt = self.__dict__.get('_next_block')            # set by Processor.forward around this call (plain blocks only)
+            return self._forward_latent(graph, nxt) if nxt is not None else self._forward_latent(graph)
         return to_public(self._forward_latent(to_latent(graph)), graph)
 
     # -- helpers shared by the hierarchical blocks (graphnet.py:86-124) -----------------------------------------
@@ -417,12 +418,17 @@ class Processor(nn.Module):
 
     def forward(self, latent_graph):
         blocks = list(self.graphnet_blocks)
-        # inference through plain GraphNet blocks on one node type: block i hands block i + 1 its pre-projection (GraphNet._update_nodes)
-        if (not torch.is_grad_enabled() and isinstance(latent_graph, _Latent) and len(latent_graph.nodes) == 1
+        # plain GraphNet blocks on one node type: block i hands block i + 1 its pre-projection (GraphNet._update_nodes) -- in inference and,
+        # since round 5, in training (the edge block's backward does not care who multiplied h by W1s / W1r in the forward)
+        if (isinstance(latent_graph, _Latent) and len(latent_graph.nodes) == 1
                 and all(type(b) in (GraphNet, MultiGraphNet) for b in blocks)):
             lat = latent_graph
             for i, b in enumerate(blocks):
-                lat = b._forward_latent(lat, blocks[i + 1] if i + 1 < len(blocks) else None)
+                b.__dict__['_next_block'] = blocks[i + 1] if i + 1 < len(blocks) else None      # (not a registered submodule)
+                try:
+                    lat = b(lat)             # through Module.__call__: forward hooks (the trainer's bucket boundaries, parallel.py) must fire
+                finally:
+                    b.__dict__['_next_block'] = None
             return lat
         return self.graphnet_blocks(latent_graph)
 

@@ -635,7 +635,7 @@ class MLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *tensors):
         n_src, idxs, residual, has_ln, train = meta[:5]
-        post = meta[5] if len(meta) > 5 else None          # (packed next-block weights, zero-fill wanted): inference only, see fused_mlp
+        post = meta[5] if len(meta) > 5 else None          # (packed next-block weights, zero-fill wanted), see fused_mlp
         given = meta[6] if len(meta) > 6 else None         # first W1 column of every source (fused_mlp: cols), or None: back to back
         share = bool(meta[7]) if len(meta) > 7 else False   # the caller vouches for the consumers of source 0 (share_grad)
         c = current()
@@ -683,7 +683,7 @@ class MLPFn(torch.autograd.Function):
         saves = _alloc_saves(M, has_ln, dev) if train else None
         res = srcs[residual] if residual >= 0 else None
         _fill_common_fwd(a, w, out, res, saves)
-        if post is not None and not train:
+        if post is not None:
             pk_next, want_zero = post
             P = torch.empty(M, 2 * LAT, device=dev)
             zero = torch.empty(M, LAT, device=dev) if want_zero else None
@@ -693,7 +693,7 @@ class MLPFn(torch.autograd.Function):
                 a.post_zero = zero.data_ptr(); a.ld_post_zero = LAT
             if M > 0 and _lib.lib().hgn_mlp_fwd_post_eligible(C.byref(a)):
                 c.post_result = (P, zero)
-            else:                                            # bigger launches: the pre-projection stays a launch of its own
+            else:                                            # not a split-product launch: the pre-projection stays a launch of its own
                 a.n_post = 0; a.post_out = None; a.post_zero = None
                 c.post_result = None
         if M > 0:
@@ -800,8 +800,7 @@ def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequen
     """`cols`: first W1 column of every source when the sources do NOT cover the input back to back -- column ranges left out stand for
     inputs that are zero for every row of this launch (an aggregate over edges none of which arrive at these rows): no operand, no
     product, a zero weight gradient.
-    `post` (inference only): (packs_of(weights of the NEXT edge block), zero-fill wanted) -- when the launch is small enough for
-    the column-split form the node-level pre-projection of that block (its P = [h W1s^T | h W1r^T]) and the zero fill of its
+    `post`: (packs_of(weights of the NEXT edge block), zero-fill wanted) -- the node-level pre-projection of that block (its P = [h W1s^T | h W1r^T]) and the zero fill of its
     aggregate buffer come out of the same launch: -> (out, (P, zeros) or None).
     `share`: the caller vouches that source 0 (a node latent) is otherwise consumed by EdgeBlockFn nodes only: its gradient tensor is
     offered to them as their accumulation target (share_grad)."""
@@ -809,12 +808,11 @@ def fused_mlp(srcs: Sequence[torch.Tensor], w: MLPWeights, idxs: Optional[Sequen
     wt = w.tensors()
     train = torch.is_grad_enabled() and any(t.requires_grad for t in list(srcs) + wt)
     cols = tuple(int(x) for x in cols) if cols is not None else None
-    if post is None or train:
-        out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, None, cols, share), *srcs, *wt)
-        return out if post is None else (out, None)
+    if post is None:
+        return MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, None, cols, share), *srcs, *wt)
     c = current()
     c.post_result = None
-    out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, post, cols), *srcs, *wt)
+    out = MLPFn.apply((len(srcs), idxs, residual, w.ln_w is not None, train, post, cols, share), *srcs, *wt)
     got, c.post_result = c.post_result, None
     return out, got
 
@@ -865,7 +863,7 @@ class EdgeBlockFn(torch.autograd.Function):
         # the `sum` aggregate formed inside the edge kernel needs a zero-filled [N, 128] buffer: filled by the pre-projection launch,
         # which passes over the same node rows anyway (hgn_linear_fwd6z), instead of a launch of its own
         agg_zeroed = None
-        if pre is not None and not train and pk is not None and parts is None and tuple(pre[0].shape) == (N, 2 * LAT):
+        if pre is not None and pk is not None and parts is None and tuple(pre[0].shape) == (N, 2 * LAT):
             P, agg_zeroed = pre                              # formed by the node kernel of the block before (fused_mlp: post)
             Ps, Pr = P.data_ptr(), P.data_ptr() + 4 * LAT
         else:
@@ -1110,7 +1108,7 @@ def edge_block(h_all: torch.Tensor, e_sorted: torch.Tensor, topo, w: MLPWeights,
     wt = w.tensors()
     hs = [h_all, e_sorted] + ([h_r] if h_r is not None else [])
     train = torch.is_grad_enabled() and any(t.requires_grad for t in hs + wt)
-    return EdgeBlockFn.apply(topo, train, tuple(agg_ops) if agg_ops is not None else None, None if train else pre, parts, h_all, h_r,
+    return EdgeBlockFn.apply(topo, train, tuple(agg_ops) if agg_ops is not None else None, pre, parts, h_all, h_r,
                              e_sorted, *wt)
 
 

@@ -164,7 +164,7 @@ typedef struct {
    * atomically: bit-reproducible as long as no segment spans more than two tiles (always true for <= 65 rows per segment;
    * callers with larger segments use hgn_segment_reduce_fwd). */
   float* seg_out; int64_t ld_seg_out; const int32_t* seg_ids;
-  /* optional, inference launches of the column-split form only (hgn_mlp_fwd_post_eligible): n_post (1..4) further packed 128 x 128
+  /* optional (hgn_mlp_fwd_post_eligible: split-product launches without gathered addends and without seg_out): n_post (1..4) further packed 128 x 128
    * blocks applied to the OUTPUT rows in the same launch,
    *   post_out[i][128 b .. 128 b + 128) = out[i] . post_pk[b]^T        (b < n_post; leading dimension ld_post),
    * bit-identical to hgn_linear_fwd6 on `out` -- the node-level pre-projection of the NEXT edge block (graphnet.py:22-32: the

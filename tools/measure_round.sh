@@ -18,7 +18,7 @@ bash tools/sq_round.sh $R $COMMIT; echo "sq rc=$?"
 python -c "import json;d=json.load(open('$O/bench_default.json'));print('default', d['ms_per_step'], d['value'], json.dumps(d['roofline']), json.dumps(d.get('cpu_baseline')), json.dumps(d.get('cold_step')), json.dumps(d.get('secondary')))"
 fi
 if [ "$PART" = "A" ]; then exit 0; fi
-for cfg in "pna --agg pna" "hyper --arch hyper --agg pna --layers 5 --clusters 16" "plate --workload plate --arch hetero --agg pna --layers 5 --clusters 31" "cylinder_fp16 --workload cylinder --arch hyper --agg pna --layers 25 --clusters 16 --precision fp16 --no-prof" "b1 --batch 1" "b8 --batch 8" "b21 --batch 21" "b64 --batch 64" "b256 --batch 256" "eager --eager" "bf16 --precision bf16" "fp16 --precision fp16"; do
+for cfg in "pna --agg pna" "hyper --arch hyper --agg pna --layers 5 --clusters 16" "plate --workload plate --arch hetero --agg pna --layers 5 --clusters 31" "cylinder_fp16 --workload cylinder --arch hyper --agg pna --layers 25 --clusters 16 --precision fp16 --no-prof" "b1 --batch 1" "b8 --batch 8" "b21 --batch 21" "b64 --batch 64" "b256 --batch 256" "eager --eager" "bf16x3 --precision fp32-bf16x3" "bf16 --precision bf16" "fp16 --precision fp16"; do
   set -- $cfg; n=$1; shift
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-cold --no-secondary --steps 20 --warmup 5 "$@" > $O/bench_$n.json 2> $O/bench_$n.err || echo "config $n failed"
   python -c "import json;d=json.load(open('$O/bench_$n.json'));print('$n', round(d['ms_per_step'],2), round(d['value']/1e6,2))" || true
