@@ -22,6 +22,15 @@
 #include <stdint.h>
 #include <type_traits>
 
+// gfx950 only.  Beyond the instructions (v_mfma_f32_16x16x32_f16 / _bf16, global_load_lds_dwordx4, v_permlane16/32_swap,
+// ds_read_b64_tr_b16) the kernels lean on gfx9-family memory behaviour that the HIP memory model does not promise: the "last
+// workgroup reduces" tickets (csrc/mlp.hip: ln_reduce_kernel, csrc/wgrad.hip) publish with sc1 write-through stores counted in
+// vmcnt and read with sc1 loads instead of device-scope fences (a fence writes back / invalidates a whole L2: measured 16 us
+// against 10), and every counted `s_waitcnt vmcnt(N)` assumes in-order return of vector memory.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "csrc/: written for gfx950 (MI355X) only -- build with --offload-arch=gfx950"
+#endif
+
 namespace hgn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -193,7 +202,23 @@ __device__ __forceinline__ void wg_barrier_lds() {
 // against each other on the final kernels, A/B on one box: edge forward 1.016 -> 0.987 ms, pre-projection 0.108 -> 0.104 ms, step
 // 59.19 / 59.03 -> 58.87 / 58.82 ms in favour of the single sweep; the gathered rows come from the Infinity Cache either way.  The paired
 // segment sums, whose second visit of a row depends on L2, keep the XCD ranges: csrc/segment.hip.)
-__device__ __forceinline__ long xcd_tile() { return blockIdx.x; }
+#ifndef HGN_XCD_RUN
+#define HGN_XCD_RUN 0
+#endif
+__device__ __forceinline__ long xcd_tile() {
+#if HGN_XCD_RUN > 0
+  // Runs of HGN_XCD_RUN consecutive tiles per XCD inside a window of 8 runs (workgroup b is dispatched to XCD b & 7): still ONE sweep
+  // through the row arrays -- the chip's concurrent workgroups cover the same span of tiles as in launch order -- but the node rows
+  // gathered by neighbouring edge tiles are found in the XCD's own L2.  Whole windows only; the tail keeps the launch order.
+  constexpr unsigned RUN = HGN_XCD_RUN, WIN = 8 * RUN;
+  const unsigned b = blockIdx.x;
+  if (b >= gridDim.x / WIN * WIN) return b;
+  const unsigned xcd = b & 7u, slot = b >> 3;
+  return (long)(((slot / RUN) * 8u + xcd) * RUN + slot % RUN);
+#else
+  return blockIdx.x;
+#endif
+}
 
 // Row-tile <-> global memory.  The lane owns 16 bytes per 16-feature block: row n, columns 16*fb + 4*kq .. +3.
 #define HGN_FOR_B(fb) _Pragma("unroll") for (int fb = 0; fb < NB; ++fb)

@@ -598,8 +598,9 @@ using namespace hgn;
 
 extern "C" int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes) {
   if (!bytes || M < 0 || n_tasks < 0 || n_tasks > HGN_MAX_WTASK) return hgn_fail(HGN_E_INVALID, "hgn_wgrad_workspace_bytes: bad argument");
-  // MFMA tasks share WG_CHUNKS chunks in total, LN tasks use up to 1024 small ones each
-  size_t mf = (size_t)WG_CHUNKS * SLAB * sizeof(float);
+  // The DMA-eligible MFMA tasks share WG_CHUNKS chunks in total, the other MFMA tasks (narrow or gathered operands: their launch
+  // follows the first one) WG_CHUNKS of their own, LN tasks use up to 1024 small ones each
+  size_t mf = (size_t)2 * WG_CHUNKS * SLAB * sizeof(float);
   size_t ln = (size_t)chunks_ln(M) * SLAB * sizeof(float) * (size_t)n_tasks;
   *bytes = mf + ln + 256;
   return HGN_OK;
@@ -624,7 +625,10 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
   for (int i = 0; i < n_tasks; ++i)
     if (!valid_products(tasks[i].products) || tasks[i].products != tasks[0].products || tasks[i].flags != tasks[0].flags)
       return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: products (0, 6, 3, 1 or 2) and flags must agree over the tasks of one launch");
-  const int nch0 = chunks_mfma(M, n0), nch1 = chunks_ln(M);
+  // The generic kernel (narrow / gathered operands: the encoders' first layers) keeps ONE 16 KB row tile in flight per workgroup: its
+  // launch gets all WG_CHUNKS workgroups for its own tasks instead of the share the whole call would leave it (an edge encoder's
+  // dW1 ran on 170 workgroups beside dW3 / dW2: 0.44-1.9 ms for 0.6-1.3 GB).
+  const int nch0 = chunks_mfma(M, nd > 0 ? nd : 1), nchg = chunks_mfma(M, ng > 0 ? ng : 1), nch1 = chunks_ln(M);
   WArgs wa; RArgs ra;
   wa.M = M;
   float* slab = (float*)workspace;
@@ -634,7 +638,7 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
     if (!t.A || !t.G || !t.dW || t.K < 1 || t.K > 128 || t.n_out < 1 || t.n_out > 128 || (t.ldg & 3) ||
         ((uintptr_t)t.G & 15))
       return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad: bad task");
-    const int nch = q < n0 ? nch0 : nch1;
+    const int nch = q < nd ? nch0 : (q < n0 ? nchg : nch1);
     wa.t[q] = {t.type, t.A, (long)t.lda, t.K, t.idxA, t.G, (long)t.ldg, slab + off};
     ra.t[q] = {t.type, t.K, t.n_out, t.accumulate ? 1 : 0, nch, t.dW, (long)t.ldw, t.db, slab + off, (long)SLAB};
     off += (size_t)nch * SLAB;
@@ -664,8 +668,8 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
     }
   }
   if (ng) {
-    wa.n_chunks = nch0; wa.rows_per_chunk = rows_per(nch0, WT_ROWS); wa.task0 = nd;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch0, (unsigned)ng), dim3(WGW), 0, (hipStream_t)stream, wa);
+    wa.n_chunks = nchg; wa.rows_per_chunk = rows_per(nchg, WT_ROWS); wa.task0 = nd;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nchg, (unsigned)ng), dim3(WGW), 0, (hipStream_t)stream, wa);
   }
   if (n1) {
     wa.n_chunks = nch1; wa.rows_per_chunk = rows_per(nch1, WT_ROWS); wa.task0 = n0;
