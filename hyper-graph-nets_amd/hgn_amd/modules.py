@@ -154,6 +154,11 @@ class _Latent:
     def n_mesh(self):
         return self.nodes[0].shape[0]
 
+    def parts_known(self) -> bool:
+        """Two node parts, and every edge set reads one part per side: nobody calls h_all(), so the part tensors are consumed by the
+        blocks' own autograd nodes (edge blocks, node updates) only -- what ops.share_grad needs to be vouched for."""
+        return len(self.nodes) == 2 and all(t.parts(self.n_mesh) is not None for t in self.topo.values())
+
 
 def _num_rows(node_features) -> int:
     return sum(x.shape[0] for x in node_features)
@@ -231,10 +236,11 @@ class GraphNet(nn.Module):
                 srcs.append(a.t)
                 cols.append(col)
             col += a.t.shape[1]
-        # (one node part: its latents are read by this update and by the block's edge blocks -- our own autograd nodes -- only: the
-        #  update's gradient tensor doubles as their accumulation target, ops.share_grad)
-        lat.nodes[which] = fused_apply(model, srcs, residual=0, cols=cols if len(srcs) <= len(aggs) else None, width=col,
-                                       share=len(lat.nodes) == 1 and type(self) in (GraphNet, MultiGraphNet, RepeatedGraphNet))
+        # (the part's latents are read by this update and by the block's edge blocks -- our own autograd nodes -- only: the update's
+        #  gradient tensor doubles as their accumulation target, ops.share_grad.  One part: the plain blocks; two parts: every
+        #  schedule, as long as no edge set needs the concatenated rows -- torch.cat would be a consumer that reports on its own)
+        share = (len(lat.nodes) == 1 and type(self) in (GraphNet, MultiGraphNet, RepeatedGraphNet)) or lat.parts_known()
+        lat.nodes[which] = fused_apply(model, srcs, residual=0, cols=cols if len(srcs) <= len(aggs) else None, width=col, share=share)
 
     # -- GraphNet.forward (graphnet.py:72-84) --------------------------------------------------------------------
     def _forward_latent(self, lat: _Latent, nxt: Optional['GraphNet'] = None) -> _Latent:
