@@ -585,6 +585,7 @@ def _wtask(typ, A, lda, K, idxA, G, ldg, n_out, dW_ptr, ldw, db_ptr, acc=0):
 # generic fused MLP over concatenated sources
 # ------------------------------------------------------------------------------------------------------------
 _SHARE_GRADS = not bool(_ENV.get('HGN_NO_SHARED_DH'))
+share_stats = {'accumulated': 0, 'own': 0}      # edge-block gradients for a node latent: added into the node update's tensor / returned as a tensor of their own
 
 
 def _share_table(c: Context):
@@ -1089,8 +1090,10 @@ class EdgeBlockFn(torch.autograd.Function):
             if dh is not None:                       # the node update's gradient for this very tensor: add into it, return nothing
                 pb = (C.c_void_p * 2)(*[pk_t.data_ptr() + (b0 + j) * _lib.PACK_BLOCK_BYTES for j in range(nb)], *([None] * (2 - nb)))
                 _lib.check(L.hgn_linear_bwd6a(gptr, ldd, n, pb, nb, dh.data_ptr(), LAT, 1, c.products(), st), 'hgn_linear_bwd6a')
+                share_stats['accumulated'] += 1
                 continue
             unshare_grad(c, hsrc)                    # a gradient tensor of our own for this h: the engine will add
+            share_stats['own'] += 1
             dh = torch.empty(n, LAT, device=dev)
             if pk_t is not None:
                 pb = (C.c_void_p * 2)(*[pk_t.data_ptr() + (b0 + j) * _lib.PACK_BLOCK_BYTES for j in range(nb)], *([None] * (2 - nb)))

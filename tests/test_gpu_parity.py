@@ -1345,6 +1345,38 @@ def test_empty_edge_set_forward_backward_vs_oracle(arch, agg):
             assert H.rel_err(p.grad, grads_o[k]) <= 2e-5, k
 
 
+@pytest.mark.parametrize('arch', ['none', 'hetero', 'hyper', 'multiscale'])
+def test_node_latent_gradients_are_shared_not_added_by_autograd(arch):
+    """ops.share_grad: the edge blocks add their share of d(h) into the tensor the node update returned (hgn_linear_bwd6a) instead of
+    handing autograd a tensor of their own to add -- in the plain stack and, when every edge set reads one node part per side, in the
+    two-part schedules (hetero / hyper / multiscale).  Counted on a two-block model; the gradients are compared with the fp64 oracle
+    (a shared tensor that the engine replaced by a sum of its own would lose every later contribution: 37 % off when it happened).
+    With an EMPTY edge set in the graph (its parts are unknown: the node rows are concatenated for it) nobody shares in the two-part
+    schedules -- test_empty_edge_set_forward_backward_vs_oracle[hetero-pna] covers the values."""
+    from hgn_amd import ops
+    g = synth.grid_graph(seed=9, nx=8, ny=7, clusters=0 if arch == 'none' else 4)
+    sets = [e.name for e in g.edge_sets]
+    shapes = O.param_shapes(arch, 'pna', 2, sets, 5, {e.name: e.features.shape[1] for e in g.edge_sets},
+                            g.node_features[1].shape[1] if len(g.node_features) > 1 else 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=6)
+    N = g.node_features[0].shape[0]
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(2))
+    mask = torch.ones(N, dtype=torch.bool)
+    out_o, loss_o, grads_o, _ = H.oracle_run(sd, g, arch, 'pna', target, mask)
+    model = H.hip_model(arch, 'pna', 2, sets, sd)
+    before = dict(ops.share_stats)
+    out, loss, grads, _ = H.hip_run(model, g, target, mask)
+    acc, own = ops.share_stats['accumulated'] - before['accumulated'], ops.share_stats['own'] - before['own']
+    # every edge block of the processor reports for its node operand(s); only the encoder's outputs (read by the first block) and the
+    # operands nobody vouches for may come back as tensors of their own
+    assert acc > 0 and acc >= own, (arch, acc, own)
+    assert H.rel_err(out, out_o) <= 1e-5
+    for k in grads_o:
+        if float(grads_o[k].abs().max()) > 0:
+            assert H.rel_err(grads[k], grads_o[k]) <= 2e-5, k
+    H._REPORT.append({'test': f'test_node_latent_gradients_are_shared_not_added_by_autograd[{arch}]', 'accumulated': acc, 'own_tensor': own})
+
+
 def test_batcher_on_device_golden_g6_and_ragged_sets():
     """f1 on the device: the vectorised batcher fed CUDA index tensors reproduces golden G6 (reference_compat) bit for bit
     (MeshSimulator.py:159-234), and batches graphs whose per-graph edge counts differ (plate world edges / balance edges)
