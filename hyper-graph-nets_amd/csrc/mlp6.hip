@@ -445,8 +445,9 @@ __global__ __launch_bounds__(WG, 2) void mlp6_fwd_edge_kernel(const hgn_mlp_fwd_
 // exchange them through 12 KB of LDS at the barrier that also opens the next weight half (lat_loader), and every wave reads
 // all four.  LayerNorm needs whole rows in the summation order of the other kernels: the pre-LayerNorm tile is gathered
 // through LDS and every wave normalises it (redundantly), then stores its own 32 columns.  Same products in the same order
-// per accumulator, same row sums: bit-identical to the other forms.  No saved activations, no in-kernel segment sums: launches
-// that need either take mlp6_fwd_kernel<1, NP, 4 + LAT_LOADERS>.
+// per accumulator, same row sums: bit-identical to the other forms, the saved activations of a training launch included (each wave
+// stores its own 32 columns of z1 / z2 / xhat and its byte of the sign words).  No in-kernel segment sums: launches that need them
+// take mlp6_fwd_kernel<1, NP, 4 + LAT_LOADERS>.
 template <int NP>
 __device__ __forceinline__ void cs_split8(const f32x4& v0, const f32x4& v1, bf16x8 (&o)[3], float sc = 1.f) {
   const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -626,10 +627,26 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
   const void* wpk[2] = {a.W2pk, a.W3pk};
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
+    // relu as the other forms do it (mlp_common.h: relu_int / relu_with_bits: integer maximum of the bit pattern and 0); training
+    // launches save z_{l+1} and its sign bits: wave w holds output blocks 2 w, 2 w + 1 of the row = byte w of the lane group's sign
+    // word (bit 4 fb + u of word kq <-> unit 16 fb + 4 kq + u), written as a byte of its own
+    unsigned sign = 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[k][u] = fmaxf(acc[k][u], 0.f);
+      for (int u = 0; u < 4; ++u) {
+        const int z = max(__float_as_int(acc[k][u]), 0);
+        acc[k][u] = __int_as_float(z);
+        sign |= (z != 0 ? 1u : 0u) << (4 * k + u);
+      }
+    if (valid) {
+      float* zs = l == 0 ? a.z1 : a.z2;
+      if (zs) {
+        *reinterpret_cast<f32x4*>(zs + row * LAT + col0) = acc[0];
+        *reinterpret_cast<f32x4*>(zs + row * LAT + col1) = acc[1];
+      }
+      if (a.relu_bits) reinterpret_cast<unsigned char*>(a.relu_bits + row * 8 + 4 * l + kq)[wave] = (unsigned char)sign;
+    }
     const f32x4 b0 = chunk(bias[l] + col0), b1 = chunk(bias[l] + col1);
     const int sw = sw_of(wpk[l]);
     const int e = produce(acc[0], acc[1], b0, b1, sw);
@@ -649,6 +666,7 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     const float var = row_sum_sq(y) * (1.f / LAT);
     const float rstd = 1.f / sqrtf(var + 1e-5f);
     HGN_FOR_B(fb) y.v[fb] *= rstd;
+    if (a.rstd && valid && wave == 0 && kq == 0) a.rstd[row] = rstd;
   }
   f32x4 o2[2];
 #pragma unroll
@@ -656,6 +674,7 @@ __global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_fwd_cs_kernel(c
     const int fb = 2 * wave + k, col = k ? col1 : col0;
     f32x4 o = y.v[0];
     HGN_FOR_B(q) if (q == fb) o = y.v[q];             // (wave-uniform select: y is a register array)
+    if (a.ln_g && a.xhat && valid) *reinterpret_cast<f32x4*>(a.xhat + row * LAT + col) = o;     // training: the normalised row
     if (a.ln_g) o = o * chunk(a.ln_g + col) + chunk(a.ln_b + col);
     if (a.res) o += chunk(a.res + rc * a.ld_res + col);
     if (valid) *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + col) = o;
@@ -966,9 +985,12 @@ extern "C" int hgn_set_big_tiles(int on) { hgn::g_big_tiles = on ? 1 : 0; return
 #endif
 namespace hgn {
 
-// inference on at most 16 rows per CU, nothing saved for a backward pass, no in-kernel segment sums: the column-split latency form
+// at most 16 rows per CU, no in-kernel segment sums: the column-split latency form (inference and, with the saves of a backward pass,
+// training: a one-graph node update is 1 600 rows -- 100 workgroups of 16 rows instead of 25 of 64)
 bool cs_eligible(const hgn_mlp_fwd_t* a) {
-  return a->M <= 16 * lat_max_tiles() && !a->seg_out && !a->z1 && !a->z2 && !a->xhat && !a->rstd && !a->relu_bits && cs_enabled();
+  if (!(a->M <= 16 * lat_max_tiles() && !a->seg_out && cs_enabled())) return false;
+  if ((a->z1 && !aligned16(a->z1)) || (a->z2 && !aligned16(a->z2)) || (a->xhat && !aligned16(a->xhat))) return false;
+  return true;
 }
 
 // the arguments of a training edge block as mlp6_fwd_edge_kernel assumes them (everything else: the general kernel)

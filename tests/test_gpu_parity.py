@@ -279,11 +279,10 @@ def test_pre_projection_forms_agree_bit_for_bit():
 @pytest.mark.parametrize('M', [1, 17, 333, 1600, 4096, 4100])
 @pytest.mark.parametrize('case', ['encoder7', 'encoder_idx', 'node2src', 'node_pna', 'latent_res'])
 def test_inference_forward_column_split_form_equals_training_forward_bit_for_bit(M, case):
-    """Without gradients nothing is saved for a backward pass, and launches of at most 4 096 rows take the column-split latency form
-    (csrc/mlp6.hip: mlp6_fwd_cs_kernel -- four waves share 16 rows, each owning 32 output columns, operand vectors exchanged
-    through LDS, LayerNorm on the gathered tile); with gradients the same call saves its activations and runs the row-per-wave
-    kernels.  Same products in the same order per accumulator and the same row sums: the outputs must be equal bit for bit
-    (4 100 rows: both sides run the row-per-wave form)."""
+    """Launches of at most 4 096 rows take the column-split latency form (csrc/mlp6.hip: mlp6_fwd_cs_kernel -- four waves share 16
+    rows, each owning 32 output columns, operand vectors exchanged through LDS, LayerNorm on the gathered tile), with gradients
+    (activations saved) and without: the outputs must be equal bit for bit (4 100 rows: both sides run the row-per-wave form).
+    Column-split against row-per-wave: test_training_forward_column_split_form_equals_the_row_per_wave_kernels_bit_for_bit."""
     from hgn_amd import ops
     gen = torch.Generator().manual_seed(M * 3 + len(case))
     residual, idx = -1, None
@@ -309,6 +308,44 @@ def test_inference_forward_column_split_form_equals_training_forward_bit_for_bit
     with torch.no_grad():
         y_inf = ops.fused_mlp(srcs, w, idxs, residual)
     assert torch.equal(y_inf, y_train)
+
+
+@pytest.mark.parametrize('M', [1, 17, 333, 1600, 4096])
+@pytest.mark.parametrize('case', ['encoder7', 'node2src', 'node_pna', 'latent_res'])
+def test_training_forward_column_split_form_equals_the_row_per_wave_kernels_bit_for_bit(M, case):
+    """Training launches of at most 4 096 rows take the column-split form too (one graph per step: a node update is 1 600 rows): every
+    wave stores its own 32 columns of z1 / z2 / xhat and its byte of the ReLU sign words.  The same M rows as the head of a launch of
+    M + 4 100 rows run the row-per-wave kernels: outputs, every saved array and the data gradients must agree bit for bit."""
+    from hgn_amd import ops
+    gen = torch.Generator().manual_seed(M * 5 + len(case))
+    residual = -1
+    if case == 'encoder7':
+        widths = [7]
+    elif case == 'node2src':
+        widths, residual = [128, 128], 0
+    elif case == 'node_pna':
+        widths, residual = [128, 512], 0
+    else:
+        widths, residual = [128], 0
+    sd = _mlp_sd(sum(widths), 128, True, seed=3)
+    w, _ = _weights(sd, True)
+    big = M + 4100
+    srcs_big = [torch.randn(big, wd, generator=gen).cuda() for wd in widths]
+    d_big = torch.randn(big, 128, generator=gen).cuda()
+
+    def run(rows):
+        xs = [x[:rows].clone().requires_grad_(True) for x in srcs_big]
+        y = ops.fused_mlp(xs, w, [None] * len(xs), residual)
+        saves = [t for t in y.grad_fn.saves]
+        y.backward(d_big[:rows].clone())
+        return y.detach(), saves, [x.grad for x in xs]
+    y_s, sv_s, dx_s = run(M)
+    y_b, sv_b, dx_b = run(big)
+    assert torch.equal(y_s, y_b[:M])
+    for name, a_, b_ in zip(('z1', 'z2', 'xhat', 'rstd', 'relu bits'), sv_s, sv_b):
+        assert torch.equal(a_, b_[:M]), name
+    for a_, b_ in zip(dx_s, dx_b):
+        assert torch.equal(a_, b_[:M])
 
 
 @pytest.mark.parametrize('M', [1, 31, 128, 333])
