@@ -598,7 +598,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused_kernel(const FusedArgs f
     bar_lds();                                        // (E) every chain wave's LayerNorm partials are in LDS
     const float sum = (lnl[tid] + lnl[256 + tid]) + (lnl[512 + tid] + lnl[768 + tid]);
     a.ln_ws[(long)blockIdx.x * 256 + tid] = sum;
-    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;               // ticket of ln_reduce_kernel (csrc/mlp.hip)
+    if (blockIdx.x == 0 && tid == 0) { reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u; reinterpret_cast<unsigned*>(a.ln_ws)[-255] = gridDim.x; }               // ticket of ln_reduce_kernel (csrc/mlp.hip)
   } else {
     // ================================= weight gradients of layers 3 and 2, and the weight ring =================================
     wgrad_role<NP>(fa, smem, t_beg, t_end);
@@ -686,7 +686,8 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
   }
   if (launch_slab_reduce(rt, 2, stream) != HGN_OK) return HGN_E_LAUNCH;
   // LayerNorm partial slabs: ln_ws holds hgn_mlp_bwd_ln_workspace_bytes(M) bytes = (tiles + parts) slabs; G <= tiles
-  if (launch_ln_reduce(fa.b.ln_ws, G, fa.b.ln_ws + G * 256, a->d_gamma, a->d_beta, a->ln_accumulate, stream) != HGN_OK) return HGN_E_LAUNCH;
+  if (!(a->flags & HGN_F_DEFER_LN) &&
+      launch_ln_reduce(fa.b.ln_ws, G, fa.b.ln_ws + G * 256, a->d_gamma, a->d_beta, a->ln_accumulate, stream) != HGN_OK) return HGN_E_LAUNCH;
   return hgn_check_launch("hgn_edge_bwd_fused (reductions)");
 }
 

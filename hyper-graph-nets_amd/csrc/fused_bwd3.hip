@@ -516,7 +516,7 @@ __global__ __launch_bounds__(FT, 2) void edge_bwd_fused3_kernel(const FusedArgs 
     bar_lds();                                        // (E)
     const float sum = (lnl[tid] + lnl[256 + tid]) + (lnl[512 + tid] + lnl[768 + tid]);
     a.ln_ws[(long)blockIdx.x * 256 + tid] = sum;
-    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;               // ticket of ln_reduce_kernel (csrc/mlp.hip)
+    if (blockIdx.x == 0 && tid == 0) { reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u; reinterpret_cast<unsigned*>(a.ln_ws)[-255] = gridDim.x; }               // ticket of ln_reduce_kernel (csrc/mlp.hip)
   } else {
     if (wave < 6) wgrad_role<true>(fa, smem, t_beg, t_end);      // (uniform)
     else wgrad_role<false>(fa, smem, t_beg, t_end);

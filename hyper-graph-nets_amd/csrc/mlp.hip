@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
 #pragma unroll
     for (int w = 0; w < WG / 64; ++w) sum += lnl[w * 256 + threadIdx.x];
     a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
-    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;      // ticket of ln_reduce_kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u; reinterpret_cast<unsigned*>(a.ln_ws)[-255] = gridDim.x; }      // ticket of ln_reduce_kernel
   }
 }
 
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(WG, 3) void mlp_bwd_kernel(const hgn_mlp_bwd_t a) {
 // in the workspace's header slab, zeroed by the kernel that wrote the slabs) adds the partials in fixed order -- one launch, and the
 // result does not depend on which block that is.  (Two launches before: 64 of them per training step, 9 % of a one-graph step.)
 constexpr int LN_PARTS = 128;
-__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ ws, long n_wg, float* part, unsigned* ticket,
-                                                        float* __restrict__ dg, float* __restrict__ db, int acc) {
+__device__ __forceinline__ void ln_reduce_block(const float* __restrict__ ws, long n_wg, float* part, unsigned* ticket,
+                                                float* __restrict__ dg, float* __restrict__ db, int acc) {
   __shared__ int is_last;
   const int c = threadIdx.x;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -225,6 +225,19 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
   const float t = (s0 + s1) + (s2 + s3);
   float* dst = c < 128 ? dg + c : db + (c - 128);
   *dst = acc ? *dst + t : t;
+}
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ ws, long n_wg, float* part, unsigned* ticket,
+                                                        float* __restrict__ dg, float* __restrict__ db, int acc) {
+  ln_reduce_block(ws, n_wg, part, ticket, dg, db, acc);
+}
+// The deferred form (hgn_ln_reduce_batch): blockIdx.y = the backward call whose slabs these are; their number was left beside the
+// ticket by the kernel that wrote them (uniform: one scalar load).
+struct LnBatchTask { float* ws; float* part; float* dg; float* db; int acc; int pad; };
+struct LnBatch { LnBatchTask t[HGN_MAX_LN_TASK]; };
+__global__ __launch_bounds__(256) void ln_reduce_batch_kernel(const LnBatch b) {
+  const LnBatchTask t = b.t[blockIdx.y];
+  unsigned* header = reinterpret_cast<unsigned*>(t.ws) - 256;
+  ln_reduce_block(t.ws, (long)header[1], t.part, header, t.dg, t.db, t.acc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -377,12 +390,26 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   } else {
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(WG), 0, (hipStream_t)stream, b);
   }
-  if (b.ln_ws) {
+  if (b.ln_ws && !(a->flags & HGN_F_DEFER_LN)) {
     // partial slabs live behind the slabs of a 64-row tiling (hgn_mlp_bwd_ln_workspace_bytes), whatever tiling ran
     float* part = b.ln_ws + ((a->M + TILE_ROWS - 1) / TILE_ROWS) * 256;
     if (launch_ln_reduce(b.ln_ws, tiles, part, a->d_gamma, a->d_beta, a->ln_accumulate, (hipStream_t)stream) != HGN_OK) return HGN_E_LAUNCH;
   }
   return hgn_check_launch("hgn_mlp_bwd");
+}
+
+extern "C" int hgn_ln_reduce_batch(const hgn_ln_task_t* tasks, int n_tasks, void* stream) {
+  if (n_tasks == 0) return HGN_OK;
+  if (!tasks || n_tasks < 0 || n_tasks > HGN_MAX_LN_TASK) return hgn_fail(HGN_E_INVALID, "hgn_ln_reduce_batch: bad task list");
+  LnBatch b;
+  for (int i = 0; i < n_tasks; ++i) {
+    const hgn_ln_task_t& t = tasks[i];
+    if (!t.ln_ws || !t.d_gamma || !t.d_beta || t.M < 1) return hgn_fail(HGN_E_INVALID, "hgn_ln_reduce_batch: bad task");
+    float* ws = t.ln_ws + 256;                        // slab 0 lies behind the header slab (ticket, slab count)
+    b.t[i] = {ws, ws + ((t.M + TILE_ROWS - 1) / TILE_ROWS) * 256, t.d_gamma, t.d_beta, t.accumulate ? 1 : 0, 0};
+  }
+  hipLaunchKernelGGL(ln_reduce_batch_kernel, dim3(LN_PARTS, (unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, b);
+  return hgn_check_launch("hgn_ln_reduce_batch");
 }
 
 static int linear_common(bool fwd, const float* x, int64_t ldx, int64_t M, const float* const* Wb, int nb, int64_t ldw,

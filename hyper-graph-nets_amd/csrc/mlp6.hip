@@ -867,7 +867,7 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
 #pragma unroll
   for (int w = 0; w < WG / 64; ++w) sum += lnl[w * 256 + threadIdx.x];
   a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = sum;
-  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u;        // ticket of ln_reduce_kernel (csrc/mlp.hip)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u; reinterpret_cast<unsigned*>(a.ln_ws)[-255] = gridDim.x; }        // ticket of ln_reduce_kernel (csrc/mlp.hip)
 }
 
 template <int NP, bool LATF = false>

@@ -17,7 +17,7 @@ PACK_BLOCK_BYTES = 98304
 HGN_MAX_PACK = 32
 NUM_KERNEL_IDS = 15
 OP_CODES = {'sum': 0, 'mean': 1, 'max': 2, 'min': 3}
-F_FP32_MFMA, F_GENERAL_FWD, F_TILE64_FWD = 1, 2, 4          # hgn_mlp_fwd_t.flags / hgn_mlp_bwd_t.flags / hgn_wtask_t.flags
+F_FP32_MFMA, F_GENERAL_FWD, F_TILE64_FWD, F_DEFER_LN = 1, 2, 4, 8          # hgn_mlp_fwd_t.flags / hgn_mlp_bwd_t.flags / hgn_wtask_t.flags
 KERNEL_NAMES = ['mlp_fwd_edge', 'mlp_fwd', 'mlp_bwd_edge', 'mlp_bwd', 'wgrad', 'seg_fwd', 'seg_bwd', 'linear_fwd',
                 'linear_bwd', 'adam', 'csr', 'wgrad_node', 'seg_fwd_agg', 'features', 'edge_bwd_fused']
 
@@ -72,6 +72,14 @@ class WFuse(C.Structure):
                 ('accumulate', C.c_int32)]
 
 
+class LnTask(C.Structure):
+    _fields_ = [('ln_ws', c_f32p), ('M', C.c_int64), ('d_gamma', c_f32p), ('d_beta', c_f32p), ('accumulate', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+HGN_MAX_LN_TASK = 48
+
+
 class Pack(C.Structure):
     _fields_ = [('W', c_f32p), ('ldw', C.c_int64), ('n_out', C.c_int32), ('n_in', C.c_int32), ('transposed', C.c_int32),
                 ('out', C.c_void_p)]
@@ -120,6 +128,7 @@ _SIGS = {
     'hgn_edge_bwd_fused_workspace_bytes': (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     'hgn_edge_bwd_fused_eligible': (C.c_int, [C.POINTER(MlpBwd)]),
     'hgn_edge_bwd_fused': (C.c_int, [C.POINTER(MlpBwd), C.POINTER(WFuse), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'hgn_ln_reduce_batch': (C.c_int, [C.POINTER(LnTask), C.c_int, C.c_void_p]),
     'hgn_wgrad_workspace_bytes': (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
     'hgn_mlp_wgrad': (C.c_int, [C.POINTER(WTask), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     'hgn_linear_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_int64,

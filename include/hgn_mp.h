@@ -40,6 +40,7 @@ extern "C" {
 #define HGN_F_FP32_MFMA 1
 #define HGN_F_GENERAL_FWD 2
 #define HGN_F_TILE64_FWD 4   /* A/B switch: 64-row forward tiles (three workgroups per CU) also for launches that would take 128-row tiles */
+#define HGN_F_DEFER_LN 8     /* hgn_mlp_bwd / hgn_edge_bwd_fused: leave the LayerNorm partial slabs in ln_ws; the caller sums them later with hgn_ln_reduce_batch */
 
 #define HGN_MAX_SRC 8
 #define HGN_MAX_ADD 2
@@ -270,6 +271,21 @@ typedef struct {
 } hgn_mlp_bwd_t;
 
 int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes /*host*/);
+/* Deferred LayerNorm-affine sums.  A backward call made with HGN_F_DEFER_LN leaves its per-workgroup slabs (and their count) in its
+ * ln_ws -- which must then be a workspace of its OWN, untouched until the sums are taken -- and skips the reduction launch; the
+ * gradients of up to HGN_MAX_LN_TASK such calls are summed by ONE launch (same two-level fixed-order sums as the reduction each call
+ * would have run: identical results).  A training step of the 15-layer model has 31 of these reductions, 7-9 us each: a tenth of a
+ * one-graph step (src/algorithms/MeshSimulator.py:141-152 runs such steps).  Nobody reads a LayerNorm gradient before the optimiser,
+ * so the caller may take the sums when the backward pass is over. */
+#define HGN_MAX_LN_TASK 48
+typedef struct {
+  float* ln_ws;                 /* the workspace handed to the deferred call (hgn_mlp_bwd_ln_workspace_bytes(M) bytes)        */
+  int64_t M;                    /* rows of that call                                                                          */
+  float* d_gamma; float* d_beta;/* [128] each                                                                                 */
+  int32_t accumulate;           /* 0: overwrite, 1: add (flat gradient buffer)                                                */
+  int32_t reserved;
+} hgn_ln_task_t;
+int hgn_ln_reduce_batch(const hgn_ln_task_t* tasks /*host*/, int n_tasks, void* stream);
 int hgn_mlp_bwd(const hgn_mlp_bwd_t* args /*host*/, void* stream);
 int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* args /*host*/);   /* 1 if hgn_mlp_bwd will take the split-bf16 kernel */
 int hgn_linear_bwd6(const float* g, int64_t ldg, int64_t M, const void* const* packed_blocks_t /*host array, transposed form*/,

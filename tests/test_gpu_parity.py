@@ -1006,6 +1006,48 @@ def test_trainer_flat_gradients_and_adam_match_torch():
         assert float(d.max()) <= 2 * 3 * 1e-3, k
 
 
+@pytest.mark.parametrize('arch,agg', [('none', 'sum'), ('hetero', 'pna')])
+def test_deferred_layernorm_sums_equal_the_per_call_reductions_bit_for_bit(arch, agg):
+    """Flat-buffer training: the LayerNorm-affine gradients of every MLP are summed by ONE launch at the end of the backward pass
+    (ops._ln_defer, hgn_ln_reduce_batch: each backward call leaves its per-workgroup slabs in a workspace of its own) instead of a
+    reduction launch per call.  Same slabs, same two-level fixed-order sums: the whole flat gradient must be bit-identical with
+    and without the deferral, eagerly and under HIP-graph capture (loss and weights after two steps)."""
+    import hgn_amd
+    from hgn_amd import parallel, ops, graphs as hg
+    graph = synth.grid_graph(seed=11, nx=12, ny=9, clusters=3 if arch == 'hetero' else 0)
+    sets = [e.name for e in graph.edge_sets]
+    shapes = O.param_shapes(arch, agg, 3, sets, 5, {e.name: e.features.shape[1] for e in graph.edge_sets},
+                            graph.node_features[1].shape[1] if len(graph.node_features) > 1 else 0, 3, 128)
+    sd = O.init_state_dict_like(shapes, seed=8)
+    N = graph.node_features[0].shape[0]
+    target = torch.randn(N, 3, generator=torch.Generator().manual_seed(3)).cuda()
+    mask = torch.ones(N, dtype=torch.bool).cuda()
+    g = hgn_amd.MultiGraph([x.cuda() for x in graph.node_features],
+                           [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in graph.edge_sets])
+
+    def run(defer, captured):
+        old = ops._DEFER_LN
+        ops._DEFER_LN = defer
+        try:
+            tr = parallel.DataParallelTrainer(H.hip_model(arch, agg, 3, sets, sd), lr=1e-3, device_step=captured)
+            step = hg.GraphedTrainStep(tr, g, target, mask, warmup=1) if captured else (lambda: tr.step(g, target, mask))
+            losses = [float(step()) for _ in range(2)]
+            torch.cuda.synchronize()
+            return losses, tr.fp.grad.clone(), tr.fp.flat.clone()
+        finally:
+            ops._DEFER_LN = old
+    base = run(False, False)
+    for defer, captured in ((True, False), (True, True)):
+        got = run(defer, captured)
+        if not captured:
+            assert got[0] == base[0]
+            assert torch.equal(got[1], base[1]), 'flat gradient'
+            assert torch.equal(got[2], base[2]), 'weights after two steps'
+        else:                                   # (the captured step warms up once more: compare with its own eager twin instead)
+            twin = run(False, True)
+            assert got[0] == twin[0] and torch.equal(got[1], twin[1]) and torch.equal(got[2], twin[2])
+
+
 def test_hip_graph_forward_and_train_step_replay():
     """f4: the forward (rollout) and the whole training step captured into a HIP graph replay bit-identically to the eager
     path on new inputs (fixed topology)."""
