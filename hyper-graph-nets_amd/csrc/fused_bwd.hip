@@ -640,7 +640,8 @@ extern "C" int hgn_edge_bwd_fused_eligible(const hgn_mlp_bwd_t* a) {
   return 1;
 }
 
-extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, void* workspace, size_t ws_bytes, void* stream_) {
+static int edge_bwd_fused_impl(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, void* workspace, size_t ws_bytes, hgn_wred_task_t* red_out,
+                               void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!a || !w) return hgn_fail(HGN_E_INVALID, "hgn_edge_bwd_fused: null args");
   if (a->M == 0) return HGN_OK;
@@ -684,11 +685,23 @@ extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, 
     rt[l].dW = dW[l]; rt[l].ldw = 128; rt[l].db = db[l]; rt[l].slab = fa.slabs + (long)l * FSLAB;
     rt[l].chunk_stride = 2L * FSLAB;
   }
-  if (launch_slab_reduce(rt, 2, stream) != HGN_OK) return HGN_E_LAUNCH;
+  if (red_out) {
+    for (int l = 0; l < 2; ++l)
+      red_out[l] = {rt[l].type, rt[l].K, rt[l].n_out, rt[l].acc, rt[l].n_chunks, 0, rt[l].dW, (int64_t)rt[l].ldw, rt[l].db, rt[l].slab,
+                    (int64_t)rt[l].chunk_stride};
+  } else if (launch_slab_reduce(rt, 2, stream) != HGN_OK) return HGN_E_LAUNCH;
   // LayerNorm partial slabs: ln_ws holds hgn_mlp_bwd_ln_workspace_bytes(M) bytes = (tiles + parts) slabs; G <= tiles
   if (!(a->flags & HGN_F_DEFER_LN) &&
       launch_ln_reduce(fa.b.ln_ws, G, fa.b.ln_ws + G * 256, a->d_gamma, a->d_beta, a->ln_accumulate, stream) != HGN_OK) return HGN_E_LAUNCH;
   return hgn_check_launch("hgn_edge_bwd_fused (reductions)");
+}
+extern "C" int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, void* workspace, size_t ws_bytes, void* stream) {
+  return edge_bwd_fused_impl(a, w, workspace, ws_bytes, nullptr, stream);
+}
+extern "C" int hgn_edge_bwd_fused_partial(const hgn_mlp_bwd_t* a, const hgn_wfuse_t* w, void* workspace, size_t ws_bytes,
+                                          hgn_wred_task_t* red, void* stream) {
+  if (!red) return hgn_fail(HGN_E_INVALID, "hgn_edge_bwd_fused_partial: null descriptor array");
+  return edge_bwd_fused_impl(a, w, workspace, ws_bytes, red, stream);
 }
 
 #ifdef HGN_FUSED_STAMPS

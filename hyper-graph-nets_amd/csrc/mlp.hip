@@ -405,6 +405,9 @@ extern "C" int hgn_ln_reduce_batch(const hgn_ln_task_t* tasks, int n_tasks, void
   for (int i = 0; i < n_tasks; ++i) {
     const hgn_ln_task_t& t = tasks[i];
     if (!t.ln_ws || !t.d_gamma || !t.d_beta || t.M < 1) return hgn_fail(HGN_E_INVALID, "hgn_ln_reduce_batch: bad task");
+    for (int j = 0; j < i; ++j)                       // (the sums are added to their targets without atomics)
+      if (tasks[j].d_gamma == t.d_gamma || tasks[j].d_beta == t.d_beta)
+        return hgn_fail(HGN_E_INVALID, "hgn_ln_reduce_batch: two tasks of one batch share a target");
     float* ws = t.ln_ws + 256;                        // slab 0 lies behind the header slab (ticket, slab count)
     b.t[i] = {ws, ws + ((t.M + TILE_ROWS - 1) / TILE_ROWS) * 256, t.d_gamma, t.d_beta, t.accumulate ? 1 : 0, 0};
   }

@@ -492,12 +492,14 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
 
 struct RTaskDev { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; long stride; };
 struct RArgs { RTaskDev t[HGN_MAX_WTASK]; };
+struct RArgsBatch { RTaskDev t[HGN_MAX_WRED]; };      // hgn_slab_reduce_batch: the pending sums of several calls in one launch
 
 // Fixed-order sum of the chunk slabs.  512 threads = 64 consecutive slab elements x 8 chunk groups: group g adds the chunks
 // c = g, g + 8, ... (four loads in flight), the eight partial sums are combined through LDS in a fixed tree -- eight times
 // the loads in flight of a one-thread-per-element loop, which at ~170 chunks per task was pure latency (60 us per launch).
 constexpr int RED_ELEMS = 64, RED_GROUPS = 8;
-__global__ __launch_bounds__(RED_ELEMS * RED_GROUPS) void wgrad_reduce_kernel(const RArgs a) {
+template <class ARGS>
+__global__ __launch_bounds__(RED_ELEMS * RED_GROUPS) void wgrad_reduce_kernel(const ARGS a) {
   __shared__ float part[RED_GROUPS][RED_ELEMS];
   const RTaskDev t = a.t[blockIdx.y];
   const int el = threadIdx.x & (RED_ELEMS - 1), grp = threadIdx.x / RED_ELEMS;
@@ -587,7 +589,7 @@ int launch_slab_reduce(const SlabReduceTask* tasks, int n_tasks, hipStream_t str
     const SlabReduceTask& t = tasks[i];
     ra.t[i] = {t.type, t.K, t.n_out, t.acc, t.n_chunks, t.dW, t.ldw, t.db, t.slab, t.chunk_stride};
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + RED_ELEMS - 1) / RED_ELEMS, (unsigned)n_tasks), dim3(RED_ELEMS * RED_GROUPS), 0,
+  hipLaunchKernelGGL(wgrad_reduce_kernel<RArgs>, dim3((SLAB + RED_ELEMS - 1) / RED_ELEMS, (unsigned)n_tasks), dim3(RED_ELEMS * RED_GROUPS), 0,
                      stream, ra);
   return hgn_check_launch("slab reduce");
 }
@@ -606,8 +608,8 @@ extern "C" int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes) 
   return HGN_OK;
 }
 
-extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, void* workspace, size_t ws_bytes,
-                             void* stream) {
+static int wgrad_impl(const hgn_wtask_t* tasks, int n_tasks, int64_t M, void* workspace, size_t ws_bytes, hgn_wred_task_t* red_out,
+                      void* stream) {
   if (n_tasks == 0) return HGN_OK;
   size_t need = 0;
   if (!tasks || hgn_wgrad_workspace_bytes(M, n_tasks, &need) != HGN_OK || !workspace || ws_bytes < need)
@@ -675,9 +677,41 @@ extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, v
     wa.n_chunks = nch1; wa.rows_per_chunk = rows_per(nch1, WT_ROWS); wa.task0 = n0;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nch1, (unsigned)n1), dim3(WGW), 0, (hipStream_t)stream, wa);
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((SLAB + RED_ELEMS - 1) / RED_ELEMS, (unsigned)n_tasks), dim3(RED_ELEMS * RED_GROUPS), 0,
+  if (red_out) {                                      // the caller takes the sums later (hgn_slab_reduce_batch); entry i <-> tasks[i]
+    for (int q = 0; q < n_tasks; ++q) {
+      const RTaskDev& r = ra.t[q];
+      red_out[order[q]] = {r.type, r.K, r.n_out, r.acc, r.n_chunks, 0, r.dW, (int64_t)r.ldw, r.db, r.slab, (int64_t)r.stride};
+    }
+    return hgn_check_launch("hgn_mlp_wgrad_partial");
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel<RArgs>, dim3((SLAB + RED_ELEMS - 1) / RED_ELEMS, (unsigned)n_tasks), dim3(RED_ELEMS * RED_GROUPS), 0,
                      (hipStream_t)stream, ra);
   return hgn_check_launch("hgn_mlp_wgrad");
+}
+extern "C" int hgn_mlp_wgrad(const hgn_wtask_t* tasks, int n_tasks, int64_t M, void* workspace, size_t ws_bytes, void* stream) {
+  return wgrad_impl(tasks, n_tasks, M, workspace, ws_bytes, nullptr, stream);
+}
+extern "C" int hgn_mlp_wgrad_partial(const hgn_wtask_t* tasks, int n_tasks, int64_t M, void* workspace, size_t ws_bytes,
+                                     hgn_wred_task_t* red, void* stream) {
+  if (!red) return hgn_fail(HGN_E_INVALID, "hgn_mlp_wgrad_partial: null descriptor array");
+  return wgrad_impl(tasks, n_tasks, M, workspace, ws_bytes, red, stream);
+}
+extern "C" int hgn_slab_reduce_batch(const hgn_wred_task_t* red, int n, void* stream) {
+  if (n == 0) return HGN_OK;
+  if (!red || n < 0 || n > HGN_MAX_WRED) return hgn_fail(HGN_E_INVALID, "hgn_slab_reduce_batch: bad task list");
+  RArgsBatch ra;
+  for (int i = 0; i < n; ++i) {
+    const hgn_wred_task_t& t = red[i];
+    if (!t.dW || !t.slab || t.n_chunks < 1 || t.K < 1 || t.K > 128 || t.n_out < 1 || t.n_out > 128 || (t.type != 0 && t.type != 1))
+      return hgn_fail(HGN_E_INVALID, "hgn_slab_reduce_batch: bad task");
+    for (int j = 0; j < i; ++j)
+      if (red[j].dW == t.dW || (t.db && red[j].db == t.db))
+        return hgn_fail(HGN_E_INVALID, "hgn_slab_reduce_batch: two sums of one batch share a target");
+    ra.t[i] = {t.type, t.K, t.n_out, t.accumulate ? 1 : 0, t.n_chunks, t.dW, (long)t.ldw, t.db, t.slab, (long)t.chunk_stride};
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel<RArgsBatch>, dim3((SLAB + RED_ELEMS - 1) / RED_ELEMS, (unsigned)n), dim3(RED_ELEMS * RED_GROUPS), 0,
+                     (hipStream_t)stream, ra);
+  return hgn_check_launch("hgn_slab_reduce_batch");
 }
 
 extern "C" int hgn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

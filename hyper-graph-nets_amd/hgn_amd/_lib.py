@@ -80,6 +80,14 @@ class LnTask(C.Structure):
 HGN_MAX_LN_TASK = 48
 
 
+class WRed(C.Structure):
+    _fields_ = [('type', C.c_int32), ('K', C.c_int32), ('n_out', C.c_int32), ('accumulate', C.c_int32), ('n_chunks', C.c_int32),
+                ('reserved', C.c_int32), ('dW', c_f32p), ('ldw', C.c_int64), ('db', c_f32p), ('slab', c_f32p), ('chunk_stride', C.c_int64)]
+
+
+HGN_MAX_WRED = 48
+
+
 class Pack(C.Structure):
     _fields_ = [('W', c_f32p), ('ldw', C.c_int64), ('n_out', C.c_int32), ('n_in', C.c_int32), ('transposed', C.c_int32),
                 ('out', C.c_void_p)]
@@ -129,6 +137,9 @@ _SIGS = {
     'hgn_edge_bwd_fused_eligible': (C.c_int, [C.POINTER(MlpBwd)]),
     'hgn_edge_bwd_fused': (C.c_int, [C.POINTER(MlpBwd), C.POINTER(WFuse), C.c_void_p, C.c_size_t, C.c_void_p]),
     'hgn_ln_reduce_batch': (C.c_int, [C.POINTER(LnTask), C.c_int, C.c_void_p]),
+    'hgn_mlp_wgrad_partial': (C.c_int, [C.POINTER(WTask), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(WRed), C.c_void_p]),
+    'hgn_edge_bwd_fused_partial': (C.c_int, [C.POINTER(MlpBwd), C.POINTER(WFuse), C.c_void_p, C.c_size_t, C.POINTER(WRed), C.c_void_p]),
+    'hgn_slab_reduce_batch': (C.c_int, [C.POINTER(WRed), C.c_int, C.c_void_p]),
     'hgn_wgrad_workspace_bytes': (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
     'hgn_mlp_wgrad': (C.c_int, [C.POINTER(WTask), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     'hgn_linear_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_int64,

@@ -47,6 +47,8 @@ class Context:
         self.wgrad_stream = None          # weight-gradient launches go to this side stream (parallel.DataParallelTrainer)
         self.wq = {}                      # (M, device) -> [tasks, tensors kept alive, set of queued dW / db target addresses]
         self.wq_graph_task = -1           # id of the autograd engine run whose final callback will flush the queue (-1: none armed)
+        self.flushing = False             # inside flush_wgrad: the launches it makes put their pending sums straight into redq
+        self.redq = []                    # deferred chunk-slab sums of weight-gradient launches: (WRed descriptor, workspace kept alive)
         self.lnq = []                     # deferred LayerNorm-affine sums: (workspace, rows, d_gamma, d_beta) of backward calls made with F_DEFER_LN
         self.pack_epoch = 0
         self.pack_in_capture = True       # graphs.GraphedForward keeps the pack launches out of its captured graph
@@ -459,20 +461,45 @@ def flush_wgrad(ctx: Optional[Context] = None) -> None:
     """Launch every queued weight-gradient task of the context now."""
     c = ctx if ctx is not None else current()
     c.wq_graph_task = -1
+    c.flushing = True
     try:
         for (M, dev), q in list(c.wq.items()):
             if q[0]:
                 _run_wgrad_here(c, q[0], M, dev, False)
         L = _lib.lib()
-        for i in range(0, len(c.lnq), _lib.HGN_MAX_LN_TASK):
-            chunk = c.lnq[i:i + _lib.HGN_MAX_LN_TASK]
-            arr = (_lib.LnTask * len(chunk))()
-            for t, (ws, M, dg, db) in zip(arr, chunk):
-                t.ln_ws = ws.data_ptr(); t.M = M; t.d_gamma = dg.data_ptr(); t.d_beta = db.data_ptr(); t.accumulate = 1
-            _lib.check(L.hgn_ln_reduce_batch(arr, len(chunk), _lib.stream_ptr()), 'hgn_ln_reduce_batch')
+        # pending chunk-slab sums (the queued launches above have just added theirs): batches of distinct targets, in queue order
+        batch, seen = [], set()
+
+        def go():
+            if batch:
+                arr = (_lib.WRed * len(batch))(*batch)
+                _lib.check(L.hgn_slab_reduce_batch(arr, len(batch), _lib.stream_ptr()), 'hgn_slab_reduce_batch')
+            batch.clear(); seen.clear()
+        for r, _ws in c.redq:
+            tg = [p_ for p_ in (r.dW, r.db) if p_]
+            if len(batch) == _lib.HGN_MAX_WRED or any(p_ in seen for p_ in tg):
+                go()
+            batch.append(r); seen.update(tg)
+        go()
+        chunk, seen_ln = [], set()
+
+        def go_ln():
+            if chunk:
+                arr = (_lib.LnTask * len(chunk))()
+                for t, (ws, M, dg, db) in zip(arr, chunk):
+                    t.ln_ws = ws.data_ptr(); t.M = M; t.d_gamma = dg.data_ptr(); t.d_beta = db.data_ptr(); t.accumulate = 1
+                _lib.check(L.hgn_ln_reduce_batch(arr, len(chunk), _lib.stream_ptr()), 'hgn_ln_reduce_batch')
+            chunk.clear(); seen_ln.clear()
+        for ent in c.lnq:                   # (one LayerNorm applied twice -- `repeated` blocks -- : two launches, in queue order)
+            if len(chunk) == _lib.HGN_MAX_LN_TASK or ent[2].data_ptr() in seen_ln:
+                go_ln()
+            chunk.append(ent); seen_ln.add(ent[2].data_ptr())
+        go_ln()
     finally:
+        c.flushing = False
         c.wq.clear()
         c.lnq.clear()
+        c.redq.clear()
 
 
 def discard_stale_wgrad(ctx: Optional[Context] = None) -> int:
@@ -481,9 +508,10 @@ def discard_stale_wgrad(ctx: Optional[Context] = None) -> int:
     must not be launched into the next step's gradient buffer.  -> number of tasks dropped.  Called at the start of every
     trainer step (parallel.DataParallelTrainer, graphs.*) and whenever a task is queued from a different engine run."""
     c = ctx if ctx is not None else current()
-    n = sum(len(q[0]) for q in c.wq.values()) + len(c.lnq)
+    n = sum(len(q[0]) for q in c.wq.values()) + len(c.lnq) + len(c.redq)
     c.wq.clear()
     c.lnq.clear()
+    c.redq.clear()
     c.wq_graph_task = -1
     return n
 
@@ -563,6 +591,24 @@ def _run_wgrad(c: Context, tasks: List[_lib.WTask], M: int, dev, edge_level: boo
     _run_wgrad_here(c, tasks, M, dev, edge_level)
 
 
+_DEFER_WRED = not bool(_ENV.get('HGN_NO_DEFER_WRED'))
+
+
+def _wred_deferrable(c: Context, accumulate) -> bool:
+    """Weight gradients that ACCUMULATE into a flat gradient buffer are read by nobody before the optimiser: the launch leaves its
+    chunk slabs in a workspace of its own and ONE launch per <= 48 pending sums adds them when the engine run ends (flush_wgrad;
+    39 reductions of 6-8 us per step of the 15-layer model otherwise)."""
+    if not (_DEFER_WRED and accumulate and c.wgrad_stream is None):
+        return False
+    if c.flushing:                          # a queued launch going out from flush_wgrad: its sums are taken a few lines further down
+        return True
+    gid = _graph_task_id()
+    if gid < 0:
+        return False
+    _arm_flush(c, gid)
+    return True
+
+
 def _run_wgrad_here(c: Context, tasks: List[_lib.WTask], M: int, dev, edge_level: bool):
     L = _lib.lib()
     L.hgn_prof_tag(0 if edge_level else 1)
@@ -571,6 +617,12 @@ def _run_wgrad_here(c: Context, tasks: List[_lib.WTask], M: int, dev, edge_level
         arr = (_lib.WTask * len(chunk))(*chunk)
         nb = C.c_size_t(0)
         _lib.check(L.hgn_wgrad_workspace_bytes(M, len(chunk), C.byref(nb)), 'hgn_wgrad_workspace_bytes')
+        if _wred_deferrable(c, all(t.accumulate for t in chunk)):
+            ws = torch.empty((nb.value + 3) // 4, dtype=torch.float32, device=dev)
+            red = (_lib.WRed * len(chunk))()
+            _lib.check(L.hgn_mlp_wgrad_partial(arr, len(chunk), M, ws.data_ptr(), 4 * ws.numel(), red, _lib.stream_ptr()), 'hgn_mlp_wgrad_partial')
+            c.redq.extend((_lib.WRed.from_buffer_copy(r), ws) for r in red)
+            continue
         ws = c.workspace(dev, nb.value)
         _lib.check(L.hgn_mlp_wgrad(arr, len(chunk), M, ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'hgn_mlp_wgrad')
 
@@ -1077,8 +1129,14 @@ class EdgeBlockFn(torch.autograd.Function):
             wf.accumulate = accs[2]
             nb = C.c_size_t(0)
             _lib.check(L.hgn_edge_bwd_fused_workspace_bytes(E, C.byref(nb)), 'hgn_edge_bwd_fused_workspace_bytes')
-            ws = c.workspace(dev, nb.value, 'fused')
-            _lib.check(L.hgn_edge_bwd_fused(C.byref(b), C.byref(wf), ws.data_ptr(), ws.numel(), st), 'hgn_edge_bwd_fused')
+            if _wred_deferrable(c, accs[2] and accs[4]):
+                ws = torch.empty((nb.value + 3) // 4, dtype=torch.float32, device=dev)
+                red = (_lib.WRed * 2)()
+                _lib.check(L.hgn_edge_bwd_fused_partial(C.byref(b), C.byref(wf), ws.data_ptr(), 4 * ws.numel(), red, st), 'hgn_edge_bwd_fused_partial')
+                c.redq.extend((_lib.WRed.from_buffer_copy(r), ws) for r in red)
+            else:
+                ws = c.workspace(dev, nb.value, 'fused')
+                _lib.check(L.hgn_edge_bwd_fused(C.byref(b), C.byref(wf), ws.data_ptr(), ws.numel(), st), 'hgn_edge_bwd_fused')
             # dW1's edge block: dz1 is in memory anyway (the sender / receiver sums read it), one streaming task
             _run_wgrad(c, [_wtask(0, e.data_ptr(), _ld(e), LAT, None, dz1.data_ptr(), LAT, LAT, dw1.data_ptr() + 4 * 2 * LAT, 3 * LAT,
                                db1.data_ptr(), accs[0])], E, dev, edge_level=True, keep=[e, dz1])

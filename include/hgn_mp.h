@@ -45,6 +45,13 @@ extern "C" {
 #define HGN_MAX_SRC 8
 #define HGN_MAX_ADD 2
 #define HGN_MAX_WTASK 16
+/* a pending sum of chunk slabs (hgn_mlp_wgrad_partial / hgn_edge_bwd_fused_partial -> hgn_slab_reduce_batch, see there) */
+#define HGN_MAX_WRED 48
+typedef struct {
+  int32_t type; int32_t K; int32_t n_out; int32_t accumulate; int32_t n_chunks; int32_t reserved;
+  float* dW; int64_t ldw; float* db;
+  const float* slab; int64_t chunk_stride;   /* first chunk's slab and the distance between two chunks' slabs, in floats */
+} hgn_wred_task_t;
 
 const char* hgn_last_error(void);
 int hgn_version(void);
@@ -276,7 +283,8 @@ int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes /*host*/);
  * gradients of up to HGN_MAX_LN_TASK such calls are summed by ONE launch (same two-level fixed-order sums as the reduction each call
  * would have run: identical results).  A training step of the 15-layer model has 31 of these reductions, 7-9 us each: a tenth of a
  * one-graph step (src/algorithms/MeshSimulator.py:141-152 runs such steps).  Nobody reads a LayerNorm gradient before the optimiser,
- * so the caller may take the sums when the backward pass is over. */
+ * so the caller may take the sums when the backward pass is over.  Two tasks of ONE batch must not share d_gamma / d_beta (the
+ * sums are added to their targets without atomics; launches on one stream serialise). */
 #define HGN_MAX_LN_TASK 48
 typedef struct {
   float* ln_ws;                 /* the workspace handed to the deferred call (hgn_mlp_bwd_ln_workspace_bytes(M) bytes)        */
@@ -316,6 +324,9 @@ int hgn_edge_bwd_fused_workspace_bytes(int64_t M, size_t* bytes /*host*/);
 int hgn_edge_bwd_fused_eligible(const hgn_mlp_bwd_t* args /*host*/);
 int hgn_edge_bwd_fused(const hgn_mlp_bwd_t* args /*host*/, const hgn_wfuse_t* w /*host*/, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* the same without the final sums of the dW3 / dW2 slabs (see hgn_mlp_wgrad_partial); red: two entries, written */
+int hgn_edge_bwd_fused_partial(const hgn_mlp_bwd_t* a /*host*/, const hgn_wfuse_t* w /*host*/, void* workspace, size_t workspace_bytes,
+                                hgn_wred_task_t* red /*host, 2 entries*/, void* stream);
 
 /* Weight / bias / LayerNorm-affine gradients: a list of tasks reduced over all rows in one launch.
  *   type 0:  dW[j][k] = sum_i G[i][j] * A[idxA ? idxA[i] : i][k]   (j < 128, k < K <= 128),  db[j] = sum_i G[i][j]
@@ -337,6 +348,18 @@ typedef struct {
 int hgn_wgrad_workspace_bytes(int64_t M, int n_tasks, size_t* bytes /*host*/);
 int hgn_mlp_wgrad(const hgn_wtask_t* tasks /*host*/, int n_tasks, int64_t M, void* workspace,
                   size_t workspace_bytes, void* stream);
+
+/* Deferred chunk-slab sums.  hgn_mlp_wgrad and hgn_edge_bwd_fused end with a launch that adds the per-workgroup partial slabs of
+ * their weight gradients in fixed order (6-8 us, 39 of them per training step of the 15-layer model: a tenth of a one-graph
+ * step).  Weight gradients that ACCUMULATE into a gradient buffer are read by nobody before the optimiser: the `_partial` forms run
+ * everything but that launch, leave the slabs in `workspace` -- which must then be the call's OWN until the sums are taken -- and
+ * describe the pending sums in `red` (host memory, one entry per task; hgn_edge_bwd_fused_partial: two, dW3 / db3 and dW2 / db2).
+ * hgn_slab_reduce_batch takes up to HGN_MAX_WRED such sums in one launch: the same additions in the same order as the launch each
+ * call would have made (identical results).  Two entries of ONE batch must not share a dW / db target (the sum is added to its
+ * target without atomics); launches on one stream serialise. */
+int hgn_mlp_wgrad_partial(const hgn_wtask_t* tasks /*host*/, int n_tasks, int64_t M, void* workspace, size_t workspace_bytes,
+                          hgn_wred_task_t* red /*host, n_tasks entries, written*/, void* stream);
+int hgn_slab_reduce_batch(const hgn_wred_task_t* red /*host*/, int n, void* stream);
 
 /* Single Linear without bias over 128-wide blocks:  out[:, 128*b : 128*b+128] = x * Wb^T  (node pre-projection
  * of the split edge layer:  [h W_s^T | h W_r^T], W_s = W1[:, 0:128], W_r = W1[:, 128:256], graphnet.py:28-30)

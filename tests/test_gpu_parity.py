@@ -1006,12 +1006,14 @@ def test_trainer_flat_gradients_and_adam_match_torch():
         assert float(d.max()) <= 2 * 3 * 1e-3, k
 
 
-@pytest.mark.parametrize('arch,agg', [('none', 'sum'), ('hetero', 'pna')])
-def test_deferred_layernorm_sums_equal_the_per_call_reductions_bit_for_bit(arch, agg):
+@pytest.mark.parametrize('arch,agg', [('none', 'sum'), ('hetero', 'pna'), ('repeated', 'sum')])
+def test_deferred_gradient_sums_equal_the_per_call_reductions_bit_for_bit(arch, agg):
     """Flat-buffer training: the LayerNorm-affine gradients of every MLP are summed by ONE launch at the end of the backward pass
     (ops._ln_defer, hgn_ln_reduce_batch: each backward call leaves its per-workgroup slabs in a workspace of its own) instead of a
-    reduction launch per call.  Same slabs, same two-level fixed-order sums: the whole flat gradient must be bit-identical with
-    and without the deferral, eagerly and under HIP-graph capture (loss and weights after two steps)."""
+    reduction launch per call, and so are the chunk slabs of the weight-gradient launches (ops._wred_deferrable,
+    hgn_mlp_wgrad_partial / hgn_edge_bwd_fused_partial -> hgn_slab_reduce_batch; sums that share a target -- `repeated` applies one
+    MLP twice -- go into separate launches).  Same slabs, same fixed-order sums: the whole flat gradient must be bit-identical
+    with and without the deferral, eagerly and under HIP-graph capture (loss and weights after two steps)."""
     import hgn_amd
     from hgn_amd import parallel, ops, graphs as hg
     graph = synth.grid_graph(seed=11, nx=12, ny=9, clusters=3 if arch == 'hetero' else 0)
@@ -1026,8 +1028,8 @@ def test_deferred_layernorm_sums_equal_the_per_call_reductions_bit_for_bit(arch,
                            [hgn_amd.EdgeSet(e.name, e.features.cuda(), e.senders.cuda(), e.receivers.cuda()) for e in graph.edge_sets])
 
     def run(defer, captured):
-        old = ops._DEFER_LN
-        ops._DEFER_LN = defer
+        old = (ops._DEFER_LN, ops._DEFER_WRED)
+        ops._DEFER_LN = ops._DEFER_WRED = defer
         try:
             tr = parallel.DataParallelTrainer(H.hip_model(arch, agg, 3, sets, sd), lr=1e-3, device_step=captured)
             step = hg.GraphedTrainStep(tr, g, target, mask, warmup=1) if captured else (lambda: tr.step(g, target, mask))
@@ -1035,7 +1037,7 @@ def test_deferred_layernorm_sums_equal_the_per_call_reductions_bit_for_bit(arch,
             torch.cuda.synchronize()
             return losses, tr.fp.grad.clone(), tr.fp.flat.clone()
         finally:
-            ops._DEFER_LN = old
+            ops._DEFER_LN, ops._DEFER_WRED = old
     base = run(False, False)
     for defer, captured in ((True, False), (True, True)):
         got = run(defer, captured)

@@ -38,6 +38,7 @@ def test_abi_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.MlpFwd) == 8 + 8 + 8 * 48 + 8 + 2 * 24 + 8 * 6 + 8 + 8 * 2 + 8 * 2 + 8 * 2 + 8 * 4 + 8 * 2 + 8 + 24 + (4 * 8 + 8 + 8 + 8 + 8 + 8) + 8
     assert C.sizeof(_lib.Pack) == 40
     assert C.sizeof(_lib.LnTask) == 8 + 8 + 8 + 8 + 4 + 4                      # hgn_ln_task_t (include/hgn_mp.h)
+    assert C.sizeof(_lib.WRed) == 6 * 4 + 8 + 8 + 8 + 8 + 8                    # hgn_wred_task_t
     assert C.sizeof(_lib.MlpBwd) == 8 + 8 + 8 + 8 + 8 * 7 + 8 + 8 * 3 + 8 + 8 * 48 + (8 + 8 + 4 + 16 + 4) + 8 * 4 + 8 * 3 + 8 + 8 * 2 + 8 + 24 + 8
 
 
