@@ -18,6 +18,9 @@ extern thread_local int g_prof_tag;           // hipGetLastError() -> HGN_OK / H
 struct SlabReduceTask { int type; int K; int n_out; int acc; int n_chunks; float* dW; long ldw; float* db; const float* slab; long chunk_stride; };
 int launch_slab_reduce(const SlabReduceTask* tasks, int n_tasks, hipStream_t stream);                 // n_tasks <= HGN_MAX_WTASK
 //   LayerNorm-affine gradients from n_slabs per-workgroup slabs of 256 floats; `part`: LN_PARTS * 256 floats of scratch
+// LayerNorm partial slabs a backward call of M rows may write (one per workgroup: 64-row tiles, or 16-row workgroups of the column-split
+// form for small launches); the reduction's own partial slabs lie behind them
+inline long ln_slab_capacity(long M) { const long t64 = (M + 63) / 64, t16 = M <= 65536 ? (M + 15) / 16 : 0; return t64 > t16 ? t64 : t16; }
 int launch_ln_reduce(float* ws, long n_slabs, float* part, float* d_gamma, float* d_beta, int accumulate, hipStream_t stream);
 
 // Records a HIP event pair around the launches issued in its scope when profiling is enabled.

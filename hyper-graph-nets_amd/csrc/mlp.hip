@@ -351,7 +351,7 @@ extern "C" int hgn_mlp_fwd(const hgn_mlp_fwd_t* a, void* stream) {
 
 extern "C" int hgn_mlp_bwd_ln_workspace_bytes(int64_t M, size_t* bytes) {
   if (!bytes || M < 0) return hgn_fail(HGN_E_INVALID, "hgn_mlp_bwd_ln_workspace_bytes: bad argument");
-  const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+  const long tiles = ln_slab_capacity(M);
   *bytes = ((size_t)tiles + LN_PARTS + 1) * 256 * sizeof(float) + 256;  // header slab (ticket) + workgroup slabs + the partial slabs of ln_reduce
   return HGN_OK;
 }
@@ -392,7 +392,7 @@ extern "C" int hgn_mlp_bwd(const hgn_mlp_bwd_t* a, void* stream) {
   }
   if (b.ln_ws && !(a->flags & HGN_F_DEFER_LN)) {
     // partial slabs live behind the slabs of a 64-row tiling (hgn_mlp_bwd_ln_workspace_bytes), whatever tiling ran
-    float* part = b.ln_ws + ((a->M + TILE_ROWS - 1) / TILE_ROWS) * 256;
+    float* part = b.ln_ws + ln_slab_capacity(a->M) * 256;
     if (launch_ln_reduce(b.ln_ws, tiles, part, a->d_gamma, a->d_beta, a->ln_accumulate, (hipStream_t)stream) != HGN_OK) return HGN_E_LAUNCH;
   }
   return hgn_check_launch("hgn_mlp_bwd");
@@ -409,7 +409,7 @@ extern "C" int hgn_ln_reduce_batch(const hgn_ln_task_t* tasks, int n_tasks, void
       if (tasks[j].d_gamma == t.d_gamma || tasks[j].d_beta == t.d_beta)
         return hgn_fail(HGN_E_INVALID, "hgn_ln_reduce_batch: two tasks of one batch share a target");
     float* ws = t.ln_ws + 256;                        // slab 0 lies behind the header slab (ticket, slab count)
-    b.t[i] = {ws, ws + ((t.M + TILE_ROWS - 1) / TILE_ROWS) * 256, t.d_gamma, t.d_beta, t.accumulate ? 1 : 0, 0};
+    b.t[i] = {ws, ws + ln_slab_capacity(t.M) * 256, t.d_gamma, t.d_beta, t.accumulate ? 1 : 0, 0};
   }
   hipLaunchKernelGGL(ln_reduce_batch_kernel, dim3(LN_PARTS, (unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, b);
   return hgn_check_launch("hgn_ln_reduce_batch");

@@ -870,6 +870,205 @@ __global__ __launch_bounds__(64 * NWV, NWV != WG / 64 ? 1 : (NS == 1 ? 3 : 2)) v
   if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u; reinterpret_cast<unsigned*>(a.ln_ws)[-255] = gridDim.x; }        // ticket of ln_reduce_kernel (csrc/mlp.hip)
 }
 
+// Column-split latency form of the backward (training launches of at most 16 x LAT_MAX_TILES rows WITHOUT a folded aggregation backward
+// or in-kernel segment sums: the node updates of a one-graph step, 1 600 rows -- 100 workgroups instead of 25).  The mirror of
+// mlp6_fwd_cs_kernel: 16 rows per workgroup, wave w owns columns 32 w .. 32 w + 31 of every layer's gradient, the operand vectors go
+// through the same 12 KB exchange buffer.  The LayerNorm backward needs whole rows in the summation order of the other kernels:
+// every wave loads the 16 full rows of d_out and x-hat in the row-per-wave layout and computes dz3 redundantly (wave 0 also forms
+// the workgroup's LayerNorm-affine partials: one slab per 16 rows).  Same products in the same order per accumulator, same row
+// sums: the data gradients are bit-identical to the other forms.
+template <int NP>
+__global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void mlp6_bwd_cs_kernel(const hgn_mlp_bwd_t a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * HALF_BF16];
+  __shared__ __attribute__((aligned(16))) bf16x8 xch[4][3][64];         // [contraction block][split][lane]
+  __shared__ float rmax[4][16];
+  __shared__ float lnl[256];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= 4) {                                    // loader waves: W3^T, W2^T, then the W1^T blocks of the requested sources
+    int stage = 0, di = 0, k0 = 0;
+    // (scaled mode: one exchange barrier in front of the blocks of halves 0, 2, 4; the further dx blocks share the operand of the first)
+    lat_loader<NP, CS_LOADERS>(lds, (unsigned)wave - 4u, [&]() -> const __bf16* {
+      if (stage == 0) { ++stage; return reinterpret_cast<const __bf16*>(a.W3pk_t); }
+      if (stage == 1) { ++stage; return reinterpret_cast<const __bf16*>(a.W2pk_t); }
+      if (di >= a.n_dx) return nullptr;
+      const __bf16* p = reinterpret_cast<const __bf16*>(a.dx[di].Wpk_t) + (long)(k0 >> 7) * BLOCK_BF16;
+      k0 += 128;
+      if (k0 >= a.dx[di].K) { ++di; k0 = 0; }
+      return p;
+    }, Prod<NP>::SCALED ? 6 : -1, Prod<NP>::SCALED ? 1 : 0, 0);
+    return;
+  }
+  const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+  const long row = (long)blockIdx.x * 16 + n;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  const int col0 = 16 * (2 * wave) + 4 * kq, col1 = col0 + 16;
+  auto chunk = [](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+  constexpr int NSP = Prod<NP>::NSPLIT;
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- dz3: LayerNorm backward on whole rows (as mlp6_bwd_kernel) ------------------------------------------------------------------
+  f32x4 acc[2];
+  {
+    Act g, xh;
+    t_load(g, a.d_out + rc * a.ld_dout, kq);
+    t_load(xh, a.xhat + rc * LAT, kq);
+    if (wave == 0) {                                  // LayerNorm-affine gradient partials of the workgroup's 16 rows
+      HGN_FOR_B(fb) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float pb = valid ? g.v[fb][w] : 0.f;
+          const float pg = row16_sum(pb * xh.v[fb][w]);
+          pb = row16_sum(pb);
+          if (n == 0) { lnl[16 * fb + 4 * kq + w] = pg; lnl[128 + 16 * fb + 4 * kq + w] = pb; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    HGN_FOR_B(fb) g.v[fb] *= *reinterpret_cast<const f32x4*>(a.ln_g + 16 * fb + 4 * kq);
+    const float m1 = row_sum(g) * (1.f / LAT);
+    const float m2 = row_dot(g, xh) * (1.f / LAT);
+    const float r = a.rstd[rc];
+    HGN_FOR_B(fb) g.v[fb] = r * (g.v[fb] - m1 - xh.v[fb] * m2);
+    acc[0] = g.v[0]; acc[1] = g.v[1];
+    HGN_FOR_B(q) if (q == 2 * wave) acc[0] = g.v[q];  // (wave-uniform select: g is a register array)
+    HGN_FOR_B(q) if (q == 2 * wave + 1) acc[1] = g.v[q];
+  }
+  if (a.dz3 && valid) {
+    *reinterpret_cast<f32x4*>(a.dz3 + row * LAT + col0) = acc[0];
+    *reinterpret_cast<f32x4*>(a.dz3 + row * LAT + col1) = acc[1];
+  }
+
+  bf16x8 xs[3][4];
+  int slot = 0;
+  auto max8 = [](const f32x4& v0, const f32x4& v1) -> float {
+    return fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                 fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+  };
+  // this wave's 32 columns of a block's operand rows -> operand vectors of contraction block `wave` (every product below starts from
+  // zero accumulators: no cap of the row exponent is needed)
+  auto produce = [&](const f32x4& v0, const f32x4& v1) -> int {
+    bf16x8 o[3];
+    int e = 0;
+    float sc = 1.f;
+    if constexpr (Prod<NP>::SCALED) {
+      const float m = rows4_max(max8(v0, v1));
+      if (kq == 0) rmax[wave][n] = m;
+      wg_barrier_lds();
+      e = scale_exp_of(fmaxf(fmaxf(rmax[0][n], rmax[1][n]), fmaxf(rmax[2][n], rmax[3][n])));
+      sc = pow2f(e);
+    }
+    cs_split8<NP>(v0, v1, o, sc);
+#pragma unroll
+    for (int sp = 0; sp < NSP; ++sp) xch[wave][sp][lane] = o[sp];
+    return e;
+  };
+  auto sweep = [&](auto HALF_) {                      // (the sweep of mlp6_fwd_cs_kernel)
+    constexpr int HALF = decltype(HALF_)::value;
+    const __bf16* lp = lds + slot * HALF_BF16 + lane * 8 + (2 * wave) * TILE_BF16;
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const int c = 2 * HALF + cl;
+      bf16x8 fr[2][3];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int sp = 0; sp < NSP; ++sp) fr[k][sp] = *reinterpret_cast<const bf16x8*>(lp + ((sp * 2 + cl) * 8 + k) * TILE_BF16);
+      f32x4 t0 = acc[0], t1 = acc[1];
+      if constexpr (NP == 3) {
+        t0 = mfma_f16(fr[0][1], xs[0][c], t0);
+        t1 = mfma_f16(fr[1][1], xs[0][c], t1);
+        t0 = mfma_f16(fr[0][0], xs[1][c], t0);
+        t1 = mfma_f16(fr[1][0], xs[1][c], t1);
+        t0 = mfma_f16(fr[0][0], xs[0][c], t0);
+        t1 = mfma_f16(fr[1][0], xs[0][c], t1);
+      } else if constexpr (NP != 6) {
+        t0 = mfma_one<NP>(fr[0][0], xs[0][c], t0);
+        t1 = mfma_one<NP>(fr[1][0], xs[0][c], t1);
+      } else {
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][2], xs[0][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][2], xs[0][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[2][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[2][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][1], xs[1][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][1], xs[1][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][1], xs[0][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][1], xs[0][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[1][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[1][c], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[0][c], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[0][c], t1, 0, 0, 0);
+      }
+      acc[0] = t0; acc[1] = t1;
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  };
+  // acc = W_block^T x (operand vectors in xch), from zero; T: exponent of the products' scale
+  auto block = [&](int T) {
+    acc[0] = z4; acc[1] = z4;
+    wg_barrier_lds();                                 // the operand vectors are visible; the block's first weight half has landed
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int sp = 0; sp < NSP; ++sp) xs[sp][c] = xch[c][sp][lane];
+    sweep(std::integral_constant<int, 0>{});
+    wg_barrier_lds();                                 // second half landed; every wave has read xch
+    sweep(std::integral_constant<int, 1>{});
+    if constexpr (Prod<NP>::SCALED) { scale4(acc[0], -T); scale4(acc[1], -T); }
+  };
+  auto sw_of = [&](const void* pk) -> int { return Prod<NP>::SCALED ? pack_scale_exp(reinterpret_cast<const __bf16*>(pk)) : 0; };
+  auto mask = [&](unsigned word) {                    // relu'(z): this wave's byte of the lane group's sign word (bit 4 k + u)
+    const unsigned m = (word >> (8 * wave)) & 0xffu;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc[k][u] = __uint_as_float(__float_as_uint(acc[k][u]) & (unsigned)__builtin_amdgcn_sbfe((int)m, 4 * k + u, 1));
+  };
+  const unsigned mb1 = a.relu_bits[rc * 8 + kq], mb2 = a.relu_bits[rc * 8 + 4 + kq];
+
+  // ---- dz2 = relu'(z2) * (W3^T dz3) ----------------------------------------------------------------------------------------------
+  int e = produce(acc[0], acc[1]);
+  block(e + sw_of(a.W3pk_t));
+  mask(mb2);
+  if (a.dz2 && valid) {
+    *reinterpret_cast<f32x4*>(a.dz2 + row * LAT + col0) = acc[0];
+    *reinterpret_cast<f32x4*>(a.dz2 + row * LAT + col1) = acc[1];
+  }
+  // ---- dz1 = relu'(z1) * (W2^T dz2) ----------------------------------------------------------------------------------------------
+  e = produce(acc[0], acc[1]);
+  block(e + sw_of(a.W2pk_t));
+  mask(mb1);
+  if (a.dz1 && valid) {
+    *reinterpret_cast<f32x4*>(a.dz1 + row * LAT + col0) = acc[0];
+    *reinterpret_cast<f32x4*>(a.dz1 + row * LAT + col1) = acc[1];
+  }
+  // ---- dx_src = dz1 W1[:, cols]  (+ d_out for the residual source) -------------------------------------------------------------------
+  if (a.n_dx > 0) e = produce(acc[0], acc[1]);        // one operand for all of them
+  for (int di = 0; di < a.n_dx; ++di) {
+    const hgn_dx_t d = a.dx[di];
+    const __bf16* pk = reinterpret_cast<const __bf16*>(d.Wpk_t);
+    for (int k0 = 0; k0 < d.K; k0 += 128) {
+      const __bf16* pkb = pk + (long)(k0 >> 7) * BLOCK_BF16;
+      block(e + sw_of(pkb));
+      if (valid) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int col = k ? col1 : col0;
+          if (k0 + col < d.K) {
+            f32x4 o = acc[k];
+            if (d.residual) o += chunk(a.d_out + rc * a.ld_dout + col);
+            *reinterpret_cast<f32x4*>(d.dx + row * d.ld + k0 + col) = o;
+          }
+        }
+      }
+    }
+  }
+  wg_barrier_lds();                                   // (the loader waves have left; wave 0's partials are in lnl since the first block)
+  a.ln_ws[(long)blockIdx.x * 256 + threadIdx.x] = lnl[threadIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<unsigned*>(a.ln_ws)[-256] = 0u; reinterpret_cast<unsigned*>(a.ln_ws)[-255] = gridDim.x; }
+}
+
 template <int NP, bool LATF = false>
 __global__ __launch_bounds__(LATF ? 64 * (4 + LAT_LOADERS) : WG, LATF ? 1 : 3) void linear6_bwd_kernel(const Lin6Args a) {
   // here a.x = g [M, 128*n_blocks], a.out = dx [M,128]; packs are transposed-form.  LATF: the latency form (see linear6_fwd_kernel)
@@ -1223,6 +1422,16 @@ extern "C" int hgn_mlp_bwd6_eligible(const hgn_mlp_bwd_t* a) {
 
 namespace hgn {
 // *n_slabs = number of 256-float LayerNorm-gradient partials written to a->ln_ws (one per workgroup)
+// the column-split backward: small launches of the plain shape (d_out given, no folded aggregation backward, no in-kernel segment sums)
+static bool cs_bwd_eligible(const hgn_mlp_bwd_t* a) {
+  if (!(a->M <= 16 * lat_max_tiles() && cs_enabled()) || a->agg_dout || a->seg_dz1 || !a->d_out || !a->relu_bits) return false;
+  if ((a->ld_dout & 3) || !aligned16(a->d_out) || !aligned16(a->xhat)) return false;
+  if ((a->dz3 && !aligned16(a->dz3)) || (a->dz2 && !aligned16(a->dz2)) || (a->dz1 && !aligned16(a->dz1))) return false;
+  for (int i = 0; i < a->n_dx; ++i)
+    if (!a->dx[i].Wpk_t || (a->dx[i].K & 3) || (a->dx[i].ld & 3) || !aligned16(a->dx[i].dx)) return false;
+  return true;
+}
+
 int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
   const int nb_ = bwd_products(a->products);
   if (tile128() && nb_ == 6 && a->M > TILE_ROWS) {
@@ -1234,6 +1443,15 @@ int launch_mlp6_bwd(const hgn_mlp_bwd_t* a, void* stream, long* n_slabs) {
     bool park = false;                      // several aggregation ops feeding a residual source gradient (pna edge blocks)
     if (a->agg_dout && a->n_agg_ops > 1)
       for (int i = 0; i < a->n_dx; ++i) park = park || a->dx[i].residual;
+    if (cs_bwd_eligible(a)) {                                   // at most 16 rows per CU: the column-split latency form
+      const long wgs = (a->M + 15) / 16;
+      constexpr int T = 64 * (4 + CS_LOADERS);
+      if (nb_ == 1) hipLaunchKernelGGL((mlp6_bwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+      else if (nb_ == 3) hipLaunchKernelGGL((mlp6_bwd_cs_kernel<3>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+      else hipLaunchKernelGGL((mlp6_bwd_cs_kernel<6>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, *a);
+      *n_slabs = wgs;
+      return hgn_check_launch("hgn_mlp_bwd (split products, column-split latency form)");
+    }
     if (tiles <= lat_max_tiles() && !park && !a->seg_dz1) {      // a tile per CU at most: the latency form (loader waves + LDS weight ring)
       constexpr int T = 64 * (4 + LAT_LOADERS);
       if (nb_ == 1) hipLaunchKernelGGL((mlp6_bwd_kernel<1, 1, false, 4 + LAT_LOADERS>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, *a);
