@@ -1094,6 +1094,118 @@ __global__ __launch_bounds__(LATF ? 64 * (4 + LAT_LOADERS) : WG, LATF ? 1 : 3) v
   if (R.valid[0]) t_store(acc[0], a.out + R.row[0] * a.ld_out, kq);
 }
 
+
+// Column-split latency form of the single-Linear backward (at most 16 x LAT_MAX_TILES rows: the pre-projection gradient of a one-graph
+// step): 16 rows per workgroup, wave w owns columns 32 w .. 32 w + 31 of dx and of every 128-wide block of g; the accumulators run
+// over the blocks exactly as in linear6_bwd_kernel (row scale capped by what they hold, same products in the same order): same bits.
+template <int NP>
+__global__ __launch_bounds__(64 * (4 + CS_LOADERS), 1) void linear6_bwd_cs_kernel(const Lin6Args a) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * HALF_BF16];
+  __shared__ __attribute__((aligned(16))) bf16x8 xch[4][3][64];
+  __shared__ float rmax[8][16];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= 4) {
+    int blk = 0;
+    lat_loader<NP, CS_LOADERS>(lds, (unsigned)wave - 4u, [&]() -> const __bf16* { return blk < a.n_blocks ? a.pk[blk++] : nullptr; }, -1,
+                               Prod<NP>::SCALED ? 1 : 0);
+    return;
+  }
+  const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+  const long row = (long)blockIdx.x * 16 + n;
+  const bool valid = row < a.M;
+  const long rc = valid ? row : a.M - 1;
+  const int col0 = 16 * (2 * wave) + 4 * kq, col1 = col0 + 16;
+  constexpr int NSP = Prod<NP>::NSPLIT;
+  auto chunk = [](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+  auto max8 = [](const f32x4& v0, const f32x4& v1) -> float {
+    return fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                 fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+  };
+  f32x4 acc[2];
+  acc[0] = a.accumulate ? chunk(a.out + rc * a.ld_out + col0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  acc[1] = a.accumulate ? chunk(a.out + rc * a.ld_out + col1) : f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 xs[3][4];
+  int slot = 0;
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    const f32x4 v0 = chunk(a.x + rc * a.ldx + 128 * blk + col0), v1 = chunk(a.x + rc * a.ldx + 128 * blk + col1);
+    int T = 0;
+    {                                                 // operand vectors of contraction block `wave`; the row's exponent (see mlp6_fwd_cs_kernel: produce)
+      bf16x8 o[3];
+      float sc = 1.f;
+      if constexpr (Prod<NP>::SCALED) {
+        const int sw = pack_scale_exp(a.pk[blk]);
+        const float m = rows4_max(max8(v0, v1)), am = rows4_max(max8(acc[0], acc[1]));
+        if (kq == 0) { rmax[wave][n] = m; rmax[4 + wave][n] = am; }
+        wg_barrier_lds();
+        int e = scale_exp_of(fmaxf(fmaxf(rmax[0][n], rmax[1][n]), fmaxf(rmax[2][n], rmax[3][n])));
+        if (e + sw > hgn_split::SCALE_EASY)
+          e = min(e, hgn_split::acc_room(fmaxf(fmaxf(rmax[4][n], rmax[5][n]), fmaxf(rmax[6][n], rmax[7][n]))) - sw);
+        sc = pow2f(e);
+        T = e + sw;
+      }
+      cs_split8<NP>(v0, v1, o, sc);
+#pragma unroll
+      for (int sp = 0; sp < NSP; ++sp) xch[wave][sp][lane] = o[sp];
+    }
+    if constexpr (Prod<NP>::SCALED) { scale4(acc[0], T); scale4(acc[1], T); }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      wg_barrier_lds();                               // this half has landed (first: the operand vectors are visible; second: every wave has read them)
+      if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int sp = 0; sp < NSP; ++sp) xs[sp][c] = xch[c][sp][lane];
+      }
+      const __bf16* lp = lds + slot * HALF_BF16 + lane * 8 + (2 * wave) * TILE_BF16;
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        bf16x8 fr[2][3];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int sp = 0; sp < NSP; ++sp) fr[k][sp] = *reinterpret_cast<const bf16x8*>(lp + ((sp * 2 + cl) * 8 + k) * TILE_BF16);
+        f32x4 t0 = acc[0], t1 = acc[1];
+#pragma unroll
+        for (int hsel = 0; hsel < 2; ++hsel) {
+          if (hsel != half) continue;                 // (xs is a register array: the contraction block is selected at compile time)
+          const int c = 2 * hsel + cl;
+          if constexpr (NP == 3) {                    // smallest terms first, the two accumulation chains interleaved
+            t0 = mfma_f16(fr[0][1], xs[0][c], t0);
+            t1 = mfma_f16(fr[1][1], xs[0][c], t1);
+            t0 = mfma_f16(fr[0][0], xs[1][c], t0);
+            t1 = mfma_f16(fr[1][0], xs[1][c], t1);
+            t0 = mfma_f16(fr[0][0], xs[0][c], t0);
+            t1 = mfma_f16(fr[1][0], xs[0][c], t1);
+          } else if constexpr (NP != 6) {
+            t0 = mfma_one<NP>(fr[0][0], xs[0][c], t0);
+            t1 = mfma_one<NP>(fr[1][0], xs[0][c], t1);
+          } else {
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][2], xs[0][c], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][2], xs[0][c], t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[2][c], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[2][c], t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][1], xs[1][c], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][1], xs[1][c], t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][1], xs[0][c], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][1], xs[0][c], t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[1][c], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[1][c], t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], xs[0][c], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], xs[0][c], t1, 0, 0, 0);
+          }
+        }
+        acc[0] = t0; acc[1] = t1;
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    if constexpr (Prod<NP>::SCALED) { scale4(acc[0], -T); scale4(acc[1], -T); }
+  }
+  if (valid) {
+    *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + col0) = acc[0];
+    *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + col1) = acc[1];
+  }
+}
 }  // namespace hgn
 
 using namespace hgn;
@@ -1491,6 +1603,14 @@ extern "C" int hgn_linear_bwd6a(const float* g, int64_t ldg, int64_t M, const vo
     if (!a.pk[i]) return hgn_fail(HGN_E_INVALID, "hgn_linear_bwd6: null packed block");
   const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
   ProfScope ps(8, (double)M, (hipStream_t)stream);
+  if (M <= 16 * hgn::lat_max_tiles() && hgn::cs_enabled()) {        // at most 16 rows per CU: the column-split latency form
+    const long wgs = (M + 15) / 16;
+    constexpr int T = 64 * (4 + hgn::CS_LOADERS);
+    if (nb_ == 1) hipLaunchKernelGGL((linear6_bwd_cs_kernel<1>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    else if (nb_ == 3) hipLaunchKernelGGL((linear6_bwd_cs_kernel<3>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((linear6_bwd_cs_kernel<6>), dim3((unsigned)wgs), dim3(T), 0, (hipStream_t)stream, a);
+    return hgn_check_launch("hgn_linear_bwd6 (column-split latency form)");
+  }
   if (tiles <= hgn::lat_max_tiles()) {
     constexpr int T = 64 * (4 + hgn::LAT_LOADERS);
     if (nb_ == 1) hipLaunchKernelGGL((linear6_bwd_kernel<1, true>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, a);

@@ -276,6 +276,35 @@ def test_pre_projection_forms_agree_bit_for_bit():
     assert H.rel_err(outs[20000][:, :128], want) <= 2e-6
 
 
+@pytest.mark.parametrize('accumulate', [0, 1])
+def test_pre_projection_backward_forms_agree_bit_for_bit(accumulate):
+    """hgn_linear_bwd6a (dh (+)= dP_s W1s + dP_r W1r) by row count: column-split latency form (<= 4 096 rows), row-per-wave latency
+    form, staged weights -- also when the accumulators start from the rows of dh (row scale capped by what they hold), and with
+    gradient rows 1e-20 apart in magnitude."""
+    import ctypes as C
+    from hgn_amd import ops, _lib
+    sd = _mlp_sd(384, 128, True, seed=9)
+    w, _ = _weights(sd, True)
+    pk_t = ops.packs_of(w, transposed=True)
+    L = _lib.lib()
+    pb = (C.c_void_p * 2)(pk_t.data_ptr(), pk_t.data_ptr() + _lib.PACK_BLOCK_BYTES)
+    gen = torch.Generator().manual_seed(6)
+    g = torch.randn(20000, 256, generator=gen)
+    g[5:9] *= 1e-20; g[11] = 0
+    g = g.cuda()
+    base = torch.randn(20000, 128, generator=gen).cuda()
+    outs = {}
+    for N in (1000, 4096, 9000, 20000):
+        dx = base[:N].clone()
+        _lib.check(L.hgn_linear_bwd6a(g.data_ptr(), 256, N, pb, 2, dx.data_ptr(), 128, accumulate, 0, _lib.stream_ptr()), 'hgn_linear_bwd6a')
+        outs[N] = dx
+    for N in (4096, 9000, 20000):
+        assert torch.equal(outs[N][:1000], outs[1000]), N
+    W = sd['m.0.layers.linear_0.weight'].double().cuda()
+    want = g[:, :128].double() @ W[:, :128] + g[:, 128:].double() @ W[:, 128:256] + (base.double() if accumulate else 0)
+    assert H.rel_err(outs[20000], want) <= 2e-6
+
+
 @pytest.mark.parametrize('M', [1, 17, 333, 1600, 4096, 4100])
 @pytest.mark.parametrize('case', ['encoder7', 'encoder_idx', 'node2src', 'node_pna', 'latent_res'])
 def test_inference_forward_column_split_form_equals_training_forward_bit_for_bit(M, case):
