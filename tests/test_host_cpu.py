@@ -68,6 +68,21 @@ def test_abi_argument_validation_without_gpu():
     assert lib.hgn_node_features(None, None, 3, 3, None, 1, None, 0, 40, 1, -1, 5, None, 43, None) == -1
     assert lib.hgn_normalize(None, 5, 0, None, None, None, 1e-8, 0, None, None) == -1
     assert lib.hgn_lincomb3(None, 1.0, None, 1.0, None, 0.0, 5, None, None) == -1
+    # deferred gradient sums (hgn_ln_reduce_batch / hgn_slab_reduce_batch): empty batches are fine, bad ones are refused before any launch
+    assert lib.hgn_ln_reduce_batch(None, 0, None) == 0 and lib.hgn_slab_reduce_batch(None, 0, None) == 0
+    assert lib.hgn_ln_reduce_batch(None, 3, None) == -1 and lib.hgn_slab_reduce_batch(None, 3, None) == -1
+    lt = (_lib.LnTask * 2)()
+    assert lib.hgn_ln_reduce_batch(lt, 2, None) == -1 and b'bad task' in lib.hgn_last_error()
+    assert lib.hgn_ln_reduce_batch(lt, _lib.HGN_MAX_LN_TASK + 1, None) == -1
+    buf = (C.c_float * 8)()
+    for t in lt:                                      # two tasks with ONE target in a batch: refused (the sums are added without atomics)
+        t.ln_ws = C.cast(buf, _lib.c_f32p); t.M = 64; t.d_gamma = C.cast(buf, _lib.c_f32p); t.d_beta = C.cast(buf, _lib.c_f32p)
+    assert lib.hgn_ln_reduce_batch(lt, 2, None) == -1 and b'share a target' in lib.hgn_last_error()
+    wr = (_lib.WRed * 2)()
+    for r in wr:
+        r.type = 0; r.K = 128; r.n_out = 128; r.n_chunks = 4; r.dW = C.cast(buf, _lib.c_f32p); r.slab = C.cast(buf, _lib.c_f32p); r.ldw = 128
+    assert lib.hgn_slab_reduce_batch(wr, 2, None) == -1 and b'share a target' in lib.hgn_last_error()
+    assert lib.hgn_mlp_wgrad_partial(None, 2, 100, None, 0, None, None) == -1
     # precision switch: 3 (default) / 6 (fp32-accurate: two scaled fp16 / three bf16 terms), 1 (bf16), 2 (fp16 forward, mode-3 backward);
     # anything else is refused and changes nothing
     assert lib.hgn_get_matmul_products() == 3
