@@ -356,7 +356,7 @@ __global__ __launch_bounds__(WGW, 2) void wgrad6_kernel(const WArgs a) {
 // operand vectors (eight rows of one feature = one bf16x8), layout [array][split][row group][feature] so that operand reads
 // are linear ds_read_b128.  The rows of block p+1 are in flight while block p is multiplied.  Against wgrad6_kernel (each of
 // the four waves re-reads and re-splits the whole A tile): 32 instead of 80 values split per lane and block, 30 b128 reads
-// instead of 80 b32 reads; 48 KB of LDS, three workgroups per CU.
+// instead of 80 b32 reads; 48 KB of LDS, two workgroups per CU (the launch has 512).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int OPS_VEC = 2 * 3 * 4 * 128;          // bf16x8 vectors per block: [A|G][split][row group][feature]
 
@@ -366,7 +366,7 @@ constexpr int OPS_VEC = 2 * 3 * 4 * 128;          // bf16x8 vectors per block: [
 // accumulators on the matrix pipe and added to the fp32 accumulators on the vector pipe with the factor 2^-(eA + eG) (exact): no
 // running scale, no overflow however the gradient magnitude moves along the rows.
 template <int NP>          // 6 / 3: fp32-accurate split products; 1: single bf16 product (hgn_set_matmul_products)
-__global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
+__global__ __launch_bounds__(WGW, 2) void wgrad6s_kernel(const WArgs a) {
   __shared__ __attribute__((aligned(16))) bf16x8 ops[OPS_VEC];                 // 48 KB
   __shared__ float blkmax[2][2];                                                // [array][producer wave of the array]
   constexpr int NSP = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
@@ -390,8 +390,12 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};             // column sums of G (bias gradient) of this lane's quad and row group
-  f32x4 x[8];
-  auto fetch = [&](int p) {
+  // TWO blocks of operand rows in flight per workgroup (two register buffers; a launch has 512 workgroups = two per CU, so the registers
+  // are there): with one, a workgroup had 32 KB under way for the length of a product phase and waited out the rest of the memory
+  // latency at every block (50 requests in flight per CU, profiles/r05_memory_counters.md): dW1e 0.249 -> 0.235 ms, a node-level task
+  // 0.099 -> 0.095.  Every fetch inside the loop is unconditional (rows past the end are clamped to the last row and never used).
+  f32x4 xa[8], xb[8];
+  auto fetch = [&](int p, f32x4 (&x)[8]) {
     const long r0 = ((long)p * gridDim.x + blockIdx.x) * 32 + 8 * kgp;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -399,10 +403,12 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
       x[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + r * ld + 4 * q));      // streamed once (see csrc/segment.hip: stream_load4)
     }
   };
-  if (nblocks > 0) fetch(0);
-  for (int p = 0; p < nblocks; ++p) {
+  if (nblocks > 0) {
+    fetch(0, xa);
+    fetch(1, xb);
+  }
+  auto body = [&](int p, f32x4 (&x)[8]) {
     const long r0 = ((long)p * gridDim.x + blockIdx.x) * 32 + 8 * kgp;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (arr) {                                      // rows past the chunk end contribute nothing
 #pragma unroll
       for (int j = 0; j < 8; ++j)
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
 #pragma unroll
       for (int sidx = 0; sidx < NSP; ++sidx) ops[((arr * 3 + sidx) * 4 + kgp) * 128 + 4 * q + f] = sp[sidx];
     }
-    if (p + 1 < nblocks) fetch(p + 1);
+    fetch(p + 2, x);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                   // operands of block p complete
     bf16x8 gs[2][3];
@@ -474,6 +480,10 @@ __global__ __launch_bounds__(WGW, 3) void wgrad6s_kernel(const WArgs a) {
         acc[mb][nb] = c;
       }
     }
+  };
+  for (int p = 0; p < nblocks; p += 2) {
+    body(p, xa);
+    if (p + 1 < nblocks) body(p + 1, xb);
   }
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
@@ -567,7 +577,7 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 }
 __global__ void step_incr_kernel(int* step) { *step += 1; }
 
-constexpr int WG_CHUNKS = 512;                    // workgroups of one weight-gradient launch (768 = three per CU measured no faster)
+constexpr int WG_CHUNKS = 512;                    // workgroups of one weight-gradient launch: two per CU (768 = three per CU measured no faster; wgrad6s_kernel is built for two)
 static int chunks_mfma(long M, int n_tasks) {
   long c = WG_CHUNKS / (n_tasks > 0 ? n_tasks : 1);
   const long by_rows = (M + 63) / 64;
