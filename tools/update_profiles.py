@@ -17,7 +17,7 @@ def last_json(path):
 
 
 out = {}
-for n in ('pna', 'hyper', 'plate', 'cylinder_fp16', 'b1', 'b8', 'b21', 'b64', 'b256', 'eager', 'bf16', 'fp16', 'two_launch_bwd'):
+for n in ('pna', 'hyper', 'plate', 'cylinder_fp16', 'b1', 'b8', 'b21', 'b64', 'b256', 'eager', 'bf16x3', 'bf16', 'fp16', 'two_launch_bwd'):
     if os.path.exists(f'{O}/bench_{n}.json'):
         d = last_json(f'{O}/bench_{n}.json')
         if d is None:
